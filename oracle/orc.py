@@ -1,0 +1,170 @@
+"""ctypes front end of the C oracle (oracle/sicp_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Builds ``oracle/_build/libsicp_oracle.so`` on first use (gcc is in the image).
+Allowed importers: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_SO = _HERE / "_build" / "libsicp_oracle.so"
+_lib = None
+
+_dp = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_bp = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def build():
+    src = _HERE / "sicp_oracle.c"
+    if not _SO.exists() or _SO.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE)], check=True, capture_output=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(str(build()))
+        L.orc_transform.argtypes = [_dp, _dp, C.c_int64, _dp]
+        L.orc_knn.argtypes = [_dp, C.c_int64, C.c_void_p, _dp, C.c_int64, C.c_int, C.c_double, C.c_int64, _ip, _dp]
+        L.orc_select_n_points.argtypes = [C.c_int64, C.c_int64, _ip]
+        L.orc_select_n_points.restype = C.c_int64
+        L.orc_normals.argtypes = [_dp, _ip, C.c_int64, C.c_int, _fp, _fp]
+        L.orc_point_to_plane.argtypes = [_dp, _fp, _dp, _dp, C.c_int64, _dp]
+        L.orc_reject.argtypes = [_dp, _fp, C.c_int64, C.c_double, _bp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_reject.restype = C.c_int64
+        L.orc_params_to_H.argtypes = [_dp, _dp]
+        L.orc_residuals.argtypes = [_dp, _dp, _fp, _dp, C.c_void_p, C.c_int64, _dp]
+        L.orc_normal_equations.argtypes = [_dp, _dp, _fp, _dp, C.c_void_p, C.c_int64, _dp]
+        L.orc_solve.argtypes = [_dp, C.c_double, _dp, _dp, _dp, _fp, _dp, C.c_void_p, C.c_int64, _dp, C.POINTER(C.c_int)]
+        L.orc_uncertainties.argtypes = [_dp, C.c_double, _dp, _dp, _dp, _fp, _dp, C.c_void_p, C.c_int64, _dp]
+        _lib = L
+    return _lib
+
+
+def _c(a, dt=np.float64):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def transform(H, X):
+    X = _c(X)
+    out = np.empty_like(X)
+    lib().orc_transform(_c(H).reshape(16), X, len(X), out)
+    return out
+
+
+def knn(P, Q, k=1, H=None, max_dist=np.inf, idx_base=0):
+    """Brute-force k-NN, ascending (d2, idx).  Returns (idx (q,k) int64, d2 (q,k) f64)."""
+    P, Q = _c(P), _c(Q)
+    idx = np.empty((len(Q), k), np.int64)
+    d2 = np.empty((len(Q), k), np.float64)
+    Hp = None if H is None else _c(H).reshape(16).ctypes.data_as(C.c_void_p)
+    Hk = None if H is None else _c(H).reshape(16)
+    if Hk is not None:
+        Hp = Hk.ctypes.data_as(C.c_void_p)
+    lib().orc_knn(P, len(P), Hp, Q, len(Q), k, float(max_dist), idx_base, idx, d2)
+    return idx, d2
+
+
+def select_n_points(ns, n):
+    pos = np.empty(max(n, 1), np.int64)
+    m = lib().orc_select_n_points(ns, n, pos)
+    return None if m < 0 else pos[:m]
+
+
+def normals(P, nn_idx):
+    nn_idx = _c(nn_idx, np.int64)
+    q, k = nn_idx.shape
+    nv = np.empty((q, 3), np.float32)
+    pl = np.empty(q, np.float32)
+    lib().orc_normals(_c(P), nn_idx, q, k, nv, pl)
+    return nv, pl
+
+
+def point_to_plane(p1, n1, p2, H):
+    d = np.empty(len(p1))
+    lib().orc_point_to_plane(_c(p1), _c(n1, np.float32), _c(p2), _c(H).reshape(16), len(p1), d)
+    return d
+
+
+def reject(d, planarity, min_planarity):
+    keep = np.empty(len(d), np.uint8)
+    med, mad = C.c_double(), C.c_double()
+    n = lib().orc_reject(_c(d), _c(planarity, np.float32), len(d), float(min_planarity), keep,
+                         C.byref(med), C.byref(mad))
+    return keep.astype(bool), int(n), med.value, mad.value
+
+
+def params_to_H(x):
+    H = np.empty(16)
+    lib().orc_params_to_H(_c(x), H)
+    return H.reshape(4, 4)
+
+
+def _keep_ptr(keep, q):
+    if keep is None:
+        return None, None
+    k = _c(keep, np.uint8)
+    assert len(k) == q
+    return k, k.ctypes.data_as(C.c_void_p)
+
+
+def residuals(x, p1, n1, p2, keep=None):
+    k, kp = _keep_ptr(keep, len(p1))
+    n = len(p1) if k is None else int(k.sum())
+    r = np.empty(n)
+    lib().orc_residuals(_c(x), _c(p1), _c(n1, np.float32), _c(p2), kp, len(p1), r)
+    return r
+
+
+def normal_equations(x, p1, n1, p2, keep=None):
+    k, kp = _keep_ptr(keep, len(p1))
+    out = np.empty(30)
+    lib().orc_normal_equations(_c(x), _c(p1), _c(n1, np.float32), _c(p2), kp, len(p1), out)
+    return out
+
+
+def solve(x0, w, obs, ow, p1, n1, p2, keep=None):
+    k, kp = _keep_ptr(keep, len(p1))
+    x = np.empty(6)
+    steps = C.c_int()
+    lib().orc_solve(_c(x0), float(w), _c(obs), _c(ow), _c(p1), _c(n1, np.float32), _c(p2), kp, len(p1), x,
+                    C.byref(steps))
+    return x, steps.value
+
+
+def uncertainties(x, w, obs, ow, p1, n1, p2, keep=None):
+    k, kp = _keep_ptr(keep, len(p1))
+    s = np.empty(6)
+    rc = lib().orc_uncertainties(_c(x), float(w), _c(obs), _c(ow), _c(p1), _c(n1, np.float32), _c(p2), kp,
+                                 len(p1), s)
+    if rc != 0:
+        raise RuntimeError("singular normal matrix")
+    return s
+
+
+def load_cloud(name):
+    """tests/golden/data/<name>.npz -> (n,3) float64, bit-identical to np.genfromtxt of the .xyz."""
+    q = np.load(_HERE.parent / "tests" / "golden" / "data" / f"{name}.npz")["q"]
+    return q.astype(np.float64) / 1e4
+
+
+def icp_iteration(X_mov, p1, n1, planarity, x_prev, x0, w, obs, ow, min_planarity):
+    """One ICP iteration per simpleicp.py:184-250 with the oracle's deterministic
+    brute-force match.  Returns dict(nn, dist, keep, n, median, mad, x, residuals)."""
+    H = params_to_H(x_prev)
+    nn, _ = knn(X_mov, p1, k=1, H=H)
+    nn = nn[:, 0]
+    p2 = _c(X_mov)[nn]
+    dist = point_to_plane(p1, n1, p2, H)
+    keep, n, med, mad = reject(dist, planarity, min_planarity)
+    if w is None:
+        w = 1.0 / (np.std(dist[keep]) ** 2)
+    x, steps = solve(x0, w, obs, ow, p1, n1, p2, keep)
+    res = residuals(x, p1, n1, p2, keep)
+    return dict(nn=nn, dist=dist, keep=keep, n=n, median=med, mad=mad, x=x, residuals=res, w=w, steps=steps)

@@ -1,0 +1,63 @@
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / "tests" / "golden"
+GOLDEN_CASES = ["dragon", "bunny", "multisensor", "webots", "dragon_q5000", "bunny_obs"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU must fail loudly, not skip silently;
+    # plain runs without a GPU skip the gpu-marked tests.
+    if has_gpu():
+        return
+    markexpr = config.getoption("-m") or ""
+    if "gpu" in markexpr and "not gpu" not in markexpr:
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    g = np.load(GOLDEN / f"{name}.npz", allow_pickle=False)
+    files = [str(f) for f in g["files"]]
+    kwargs = eval(str(g["kwargs"]), {"inf": np.inf, "np": np})  # repr() of a plain dict written by make_golden.py
+    return g, files, kwargs
+
+
+def load_cloud(stem):
+    q = np.load(GOLDEN / "data" / f"{Path(stem).stem}.npz")["q"]
+    return q.astype(np.float64) / 1e4
+
+
+@pytest.fixture(scope="session")
+def clouds():
+    cache = {}
+
+    def get(stem):
+        stem = Path(stem).stem
+        if stem not in cache:
+            cache[stem] = load_cloud(stem)
+        return cache[stem]
+    return get
