@@ -1,0 +1,181 @@
+/*
+ * simpleicp_hip.h -- C ABI of libsimpleicp_hip.so: the MI355X (gfx950) implementation of
+ * the simpleICP inner loop.
+ *
+ * The reference (pglira/simpleICP, Python flavour) has NO FFI / plugin layer: its seam is
+ * the Python API `SimpleICP.run` / `PointCloud` (python/simpleicp/__init__.py:12-14).  The
+ * entry points below are what a ctypes binding for that seam needs; each one names the
+ * reference operator (file:line under /root/reference) it stands in for.  The binding
+ * itself is simpleicp_amd/_lib.py; INTEGRATION.md shows the stub a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *   - every function returns SICP_OK (0) or a negative SICP_ERR_*; nothing throws across
+ *     the ABI; sicp_last_error() returns a thread-local message for the last failure.
+ *   - "host-or-device pointer": caller-owned, C-contiguous, valid only for the call; may be
+ *     a host pointer (numpy) or a device pointer (e.g. torch.Tensor.data_ptr()) -- copies
+ *     use hipMemcpyDefault.  Device memory created by the library is owned by the ctx.
+ *   - calls are synchronous on return.  A ctx is not thread-safe; use one per thread/GPU.
+ *   - point clouds are float64 (n,3) row-major, like PointCloud.X (pointcloud.py:81-84).
+ *   - indices are int64, 0-based; in a sharded (multi-GPU) job they are GLOBAL indices:
+ *     index_base (given at upload) + local row.
+ *
+ * Arithmetic contract (identical in oracle/sicp_oracle.c, which checks this library):
+ *   (T) x' = fma(H02,z, fma(H01,y, H00*x)) + H03             (pointcloud.py:205-217)
+ *   (D) d2 = fma(dz,dz, fma(dy,dy, dx*dx)), dx = p.x - q.x
+ *   (K) neighbours ordered ascending by (d2, index); cKDTree's tie order is arbitrary
+ *   (P) d  = (dx*nx + dy*ny) + dz*nz, no contraction, n upcast from float32
+ *                                                            (corrpts.py:195-211)
+ */
+#ifndef SIMPLEICP_HIP_H
+#define SIMPLEICP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SICP_ABI_VERSION 1
+
+#define SICP_OK               0
+#define SICP_ERR_INVALID     -1   /* bad argument / wrong call order                         */
+#define SICP_ERR_HIP         -2   /* HIP runtime failure (message has hipGetErrorString)     */
+#define SICP_ERR_NO_DEVICE   -3   /* no usable gfx950 device                                 */
+#define SICP_ERR_TOO_FEW     -4   /* < 6 correspondences left  (simpleicp.py:209-214)        */
+#define SICP_ERR_NUMERIC     -5   /* normal matrix not positive definite / no progress       */
+#define SICP_ERR_EXCHANGE    -6   /* the registered exchange callback failed                 */
+
+#define SICP_FIX 0   /* fixed cloud   (pc1 in simpleicp.py:70-73) */
+#define SICP_MOV 1   /* movable cloud (pc2)                        */
+
+typedef struct sicp_ctx sicp_ctx;
+
+/* ---- library / context ------------------------------------------------------------ */
+int         sicp_abi_version(void);
+const char *sicp_last_error(void);
+int         sicp_device_count(int *count_out);
+int         sicp_ctx_create(int device, sicp_ctx **ctx_out);
+int         sicp_ctx_destroy(sicp_ctx *ctx);
+int         sicp_ctx_device_name(sicp_ctx *ctx, char *buf, int buflen);
+
+/* ---- point clouds : PointCloud (pointcloud.py:15-49) -------------------------------- */
+/* Upload n points (host-or-device pointer) into slot SICP_FIX / SICP_MOV; replaces any
+ * previous content.  index_base = global index of row 0 (0 unless the cloud is a shard). */
+int sicp_cloud_upload(sicp_ctx *ctx, int slot, const double *xyz, int64_t n, int64_t index_base);
+int sicp_cloud_size(sicp_ctx *ctx, int slot, int64_t *n_out);
+/* PointCloud.transform_by_H (pointcloud.py:205-217): in-place, contract (T).  */
+int sicp_cloud_transform(sicp_ctx *ctx, int slot, const double H[16]);
+/* PointCloud.X (pointcloud.py:81-84): (n,3) row-major copy out. */
+int sicp_cloud_download(sicp_ctx *ctx, int slot, double *xyz_out);
+
+/* ---- nearest neighbours ------------------------------------------------------------- */
+/* What the reference asks of scipy.spatial.cKDTree(...).query(q, k, p=2[, distance_upper_bound])
+ * at corrpts.py:131-132 (k=1, cloud pre-transformed by H: simpleicp.py:188),
+ * pointcloud.py:161-165 (k=1, strict upper bound) and pointcloud.py:185-186 (k=neighbors).
+ *   H        : optional 4x4 row-major transform applied to the SEARCHED cloud on the fly
+ *              (contract (T)); NULL = identity.  Only honoured for k == 1.
+ *   max_dist : candidates need d2 < max_dist*max_dist (strict, like cKDTree); +inf = none.
+ *   idx_out  : (Q,k) int64, ascending (d2, idx); -1 where fewer than k candidates exist.
+ *   d2_out   : (Q,k) float64 SQUARED distances (+inf where idx == -1); may be NULL.
+ * Results cover the LOCAL shard only (see sicp_set_exchange for multi-GPU). */
+int sicp_knn(sicp_ctx *ctx, int slot, const double *q_xyz, int64_t Q, int k,
+             const double *H, double max_dist, int64_t *idx_out, double *d2_out);
+
+/* PointCloud.estimate_normals (pointcloud.py:173-203) for the rows sel_idx (LOCAL rows of
+ * `slot`): k-NN among ALL points of the slot (self included), sample covariance (/(k-1)),
+ * symmetric eigen-decomposition in fp64; normal = eigenvector of the smallest eigenvalue
+ * with its largest-magnitude component made positive (np.linalg.eig's sign is arbitrary),
+ * planarity = (l_mid - l_min) / l_max; both stored as float32 like the reference.
+ *   normals_out (Q,3) float32, planarity_out (Q) float32, nn_idx_out (Q,k) int64 or NULL. */
+int sicp_estimate_normals(sicp_ctx *ctx, int slot, const int64_t *sel_idx, int64_t Q, int k,
+                          float *normals_out, float *planarity_out, int64_t *nn_idx_out);
+
+/* ---- the ICP iteration (simpleicp.py:184-250) ---------------------------------------- */
+/* Declare the selected fixed points and their attributes (simpleicp.py:173-178):
+ *   sel_idx (Q) rows of the SICP_FIX slot, normals (Q,3) float32, planarity (Q) float32
+ *   (NaN planarity = rejected, corrpts.py:153-155).  Stays resident across iterations.  */
+int sicp_icp_setup(sicp_ctx *ctx, const int64_t *sel_idx, int64_t Q,
+                   const float *normals, const float *planarity);
+
+typedef struct sicp_iter_params {
+    double x[6];            /* current estimate alpha1..3 [rad], tx,ty,tz: defines H for the
+                               match AND the solver start (simpleicp.py:223-227,250)        */
+    double obs[6];          /* rbp_observed_values, angles already in rad                   */
+    double obs_weight[6];   /* rbp_observation_weights; +inf = parameter fixed              */
+    double min_planarity;   /* corrpts.py:139-163                                           */
+    double distance_weight; /* > 0; <= 0 or NaN = "None": 1/std(d)^2 (simpleicp.py:233-234) */
+    int64_t max_lm_steps;   /* cap on solver steps (0 = default 100)                        */
+} sicp_iter_params;
+
+typedef struct sicp_iter_result {
+    double  x[6];           /* new estimate (optimization.py:103-115)                       */
+    double  H[16];          /* RigidBodyParameters.H (optimization.py:334-350)              */
+    int64_t n_queries;      /* Q                                                            */
+    int64_t n_planar;       /* survivors of reject_wrt_planarity                            */
+    int64_t n_kept;         /* survivors of reject_wrt_point_to_plane_distances             */
+    double  median, mad;    /* of the planarity survivors' distances (raw MAD, scale 1.0)   */
+    double  dist_mean, dist_std;   /* kept point-to-plane distances BEFORE optimisation     */
+    double  res_mean, res_std;     /* unweighted residuals AFTER optimisation (ddof = 0)    */
+    double  weight_used;    /* distance weight actually applied                             */
+    double  cost;           /* objective at x                                               */
+    int64_t lm_steps;       /* accepted solver steps                                        */
+    int64_t ne_evals;       /* fused normal-equation reductions launched                    */
+} sicp_iter_result;
+
+/* One full iteration on the GPU: match (brute-force 1-NN of the Q selected fixed points in
+ * the movable cloud transformed by H(x)), point-to-plane distances, planarity + raw-MAD
+ * rejection, then minimisation of the reference's objective (optimization.py:65-124) by
+ * Levenberg-Marquardt on fused 6x6 normal-equation reductions with a host-side solve.     */
+int sicp_icp_iterate(sicp_ctx *ctx, const sicp_iter_params *params, sicp_iter_result *result);
+
+/* State of the LAST iteration, each (Q)-sized in query order, host-or-device, any NULL:
+ *   pc2_idx  matched movable index (corrpts.py:135), dist  distance before optimisation
+ *   (corrpts.py:195-211), keep  1 = survived both rejections, residual  unweighted residual
+ *   at the new estimate (0 where keep == 0).                                              */
+int sicp_icp_get_state(sicp_ctx *ctx, int64_t *pc2_idx, double *dist, uint8_t *keep, double *residual);
+
+/* estimate_parameter_uncertainties (optimization.py:126-170) at the last estimate; NaN for
+ * fixed parameters. */
+int sicp_icp_uncertainties(sicp_ctx *ctx, double sigma_out[6]);
+
+/* Fused reduction exposed for parity tests: normal equations of the unweighted distance
+ * residuals over the kept correspondences of the last iteration at parameters x:
+ * out[0..20] upper triangle of J^T J (row-major), out[21..26] J^T r, out[27] sum r,
+ * out[28] sum r^2, out[29] n. */
+int sicp_icp_normal_equations(sicp_ctx *ctx, const double x[6], double out[30]);
+
+/* mathutils.py:39-68,81-93: parameters -> 4x4 row-major H (host only). */
+int sicp_params_to_H(const double x[6], double H_out[16]);
+
+/* ---- multi-GPU exchange hook (one process per GPU; collectives supplied by the host) -- */
+/* The library never links RCCL: the host binding (torch.distributed over RCCL/xGMI in
+ * simpleicp_amd/dist.py) registers a callback the iteration calls at its exchange points.
+ * All pointers handed to the callback are DEVICE pointers owned by the ctx, the library's
+ * stream is idle when it is called, and the callback must complete (results visible in
+ * device memory) before it returns 0.
+ *   SICP_XCHG_BEST_MATCH : a = d2 f64[count], b = idx i64[count], c = xyz f64[3*count]
+ *                          (row-major, movable coordinates of the local winner); replace
+ *                          in place by the job-wide lexicographic (d2, idx) minimum's.
+ *   SICP_XCHG_SUM_F64    : a = f64[count]; replace in place by the sum over ranks.        */
+#define SICP_XCHG_BEST_MATCH 1
+#define SICP_XCHG_SUM_F64    2
+typedef int (*sicp_exchange_fn)(void *user, int what, void *a, void *b, void *c, int64_t count);
+/* gn_shard: 0 = every rank reduces all correspondences (no collective in the solver),
+ *           1 = rank r reduces slice r of the correspondences + SUM exchange per step.   */
+int sicp_set_exchange(sicp_ctx *ctx, sicp_exchange_fn fn, void *user, int rank, int world, int gn_shard);
+
+/* ---- kernel timing (HIP events on the library's own stream) -------------------------- */
+#define SICP_K_KNN1     0   /* brute-force 1-NN scan (dominant kernel)  */
+#define SICP_K_KNNK     1   /* brute-force k-NN scan                    */
+#define SICP_K_NORMALEQ 2   /* fused residual + normal-equation reduce  */
+#define SICP_K_SELECT   3   /* median / MAD selection                   */
+#define SICP_K_COUNT    4
+int sicp_timing_enable(sicp_ctx *ctx, int on);
+int sicp_timing_reset(sicp_ctx *ctx);
+int sicp_timing_get(sicp_ctx *ctx, int kernel, double *total_ms_out, int64_t *launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMPLEICP_HIP_H */

@@ -1,0 +1,289 @@
+"""ctypes binding of libsimpleicp_hip.so (C ABI: include/simpleicp_hip.h).
+
+There is NO CPU fallback anywhere in this package: if the shared library is missing, or no
+gfx950 device is visible, the operations raise ``BackendError`` -- they never silently run on
+the host.  (The CPU oracle under oracle/ is test infrastructure and is not imported here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libsimpleicp_hip.so"
+
+FIX, MOV = 0, 1
+OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_TOO_FEW, ERR_NUMERIC, ERR_EXCHANGE = 0, -1, -2, -3, -4, -5, -6
+XCHG_BEST_MATCH, XCHG_SUM_F64 = 1, 2
+K_KNN1, K_KNNK, K_NORMALEQ, K_SELECT = 0, 1, 2, 3
+KERNEL_NAMES = {K_KNN1: "knn1_scan", K_KNNK: "knnk_scan", K_NORMALEQ: "normal_eq", K_SELECT: "reject_select"}
+
+EXPORTS = [
+    "sicp_abi_version", "sicp_last_error", "sicp_device_count", "sicp_ctx_create", "sicp_ctx_destroy",
+    "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_size", "sicp_cloud_transform",
+    "sicp_cloud_download", "sicp_knn", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
+    "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
+    "sicp_set_exchange", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get",
+]
+
+
+class BackendError(RuntimeError):
+    """The HIP backend is unavailable or a HIP call failed."""
+
+    def __init__(self, message, code=None):
+        super().__init__(message)
+        self.code = code
+
+
+class IterParams(C.Structure):
+    _fields_ = [("x", C.c_double * 6), ("obs", C.c_double * 6), ("obs_weight", C.c_double * 6),
+                ("min_planarity", C.c_double), ("distance_weight", C.c_double), ("max_lm_steps", C.c_int64)]
+
+
+class IterResult(C.Structure):
+    _fields_ = [("x", C.c_double * 6), ("H", C.c_double * 16), ("n_queries", C.c_int64),
+                ("n_planar", C.c_int64), ("n_kept", C.c_int64), ("median", C.c_double), ("mad", C.c_double),
+                ("dist_mean", C.c_double), ("dist_std", C.c_double), ("res_mean", C.c_double),
+                ("res_std", C.c_double), ("weight_used", C.c_double), ("cost", C.c_double),
+                ("lm_steps", C.c_int64), ("ne_evals", C.c_int64)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+
+_lib = None
+
+
+def load():
+    """dlopen the library (building it first if hipcc is around and it is stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        try:
+            from . import build as _build
+            _build.build()
+        except Exception as exc:  # noqa: BLE001
+            raise BackendError(f"{LIB_PATH} is missing and could not be built ({exc}); "
+                               "run `python -m simpleicp_amd.build`") from exc
+    try:
+        L = C.CDLL(str(LIB_PATH))
+    except OSError as exc:
+        raise BackendError(f"cannot load {LIB_PATH}: {exc}") from exc
+    vp, i64, dbl, cint = C.c_void_p, C.c_int64, C.c_double, C.c_int
+    L.sicp_abi_version.restype = cint
+    L.sicp_last_error.restype = C.c_char_p
+    L.sicp_device_count.argtypes = [C.POINTER(cint)]
+    L.sicp_ctx_create.argtypes = [cint, C.POINTER(vp)]
+    L.sicp_ctx_destroy.argtypes = [vp]
+    L.sicp_ctx_device_name.argtypes = [vp, C.c_char_p, cint]
+    L.sicp_cloud_upload.argtypes = [vp, cint, vp, i64, i64]
+    L.sicp_cloud_size.argtypes = [vp, cint, C.POINTER(i64)]
+    L.sicp_cloud_transform.argtypes = [vp, cint, vp]
+    L.sicp_cloud_download.argtypes = [vp, cint, vp]
+    L.sicp_knn.argtypes = [vp, cint, vp, i64, cint, vp, dbl, vp, vp]
+    L.sicp_estimate_normals.argtypes = [vp, cint, vp, i64, cint, vp, vp, vp]
+    L.sicp_icp_setup.argtypes = [vp, vp, i64, vp, vp]
+    L.sicp_icp_iterate.argtypes = [vp, C.POINTER(IterParams), C.POINTER(IterResult)]
+    L.sicp_icp_get_state.argtypes = [vp, vp, vp, vp, vp]
+    L.sicp_icp_uncertainties.argtypes = [vp, vp]
+    L.sicp_icp_normal_equations.argtypes = [vp, vp, vp]
+    L.sicp_params_to_H.argtypes = [vp, vp]
+    L.sicp_set_exchange.argtypes = [vp, EXCHANGE_FN, vp, cint, cint, cint]
+    L.sicp_timing_enable.argtypes = [vp, cint]
+    L.sicp_timing_reset.argtypes = [vp]
+    L.sicp_timing_get.argtypes = [vp, cint, C.POINTER(dbl), C.POINTER(i64)]
+    for name in EXPORTS:
+        if name != "sicp_last_error":
+            getattr(L, name).restype = cint
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    """numpy array / torch tensor / None -> void* (host-or-device pointer)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if hasattr(a, "data_ptr"):          # torch.Tensor (host or device)
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(f"unsupported buffer type {type(a)}")
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    n = C.c_int(0)
+    load().sicp_device_count(C.byref(n))
+    return n.value
+
+
+def params_to_H(x):
+    H = np.empty(16)
+    load().sicp_params_to_H(_ptr(_f64(x)), _ptr(H))
+    return H.reshape(4, 4)
+
+
+class Context:
+    """One GPU context (= one `sicp_ctx`): device-resident clouds + ICP iteration state."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        self._h = C.c_void_p()
+        self._cb = None
+        rc = self._L.sicp_ctx_create(int(device), C.byref(self._h))
+        if rc != OK:
+            self._h = C.c_void_p()
+            raise BackendError(self._L.sicp_last_error().decode(), rc)
+        self.device = int(device)
+
+    # -- plumbing --
+    def _chk(self, rc):
+        if rc != OK:
+            raise BackendError(self._L.sicp_last_error().decode(), rc)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.sicp_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._chk(self._L.sicp_ctx_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    # -- clouds --
+    def upload(self, slot, xyz, index_base=0):
+        """xyz: (n,3) float64 numpy array or CUDA/host torch tensor."""
+        if isinstance(xyz, np.ndarray):
+            xyz = _f64(xyz)
+        n = int(xyz.shape[0])
+        if tuple(xyz.shape) != (n, 3):
+            raise ValueError("cloud must have shape (n, 3)")
+        self._chk(self._L.sicp_cloud_upload(self._h, slot, _ptr(xyz), n, int(index_base)))
+
+    def size(self, slot):
+        n = C.c_int64()
+        self._chk(self._L.sicp_cloud_size(self._h, slot, C.byref(n)))
+        return n.value
+
+    def transform(self, slot, H):
+        self._chk(self._L.sicp_cloud_transform(self._h, slot, _ptr(_f64(H).reshape(16))))
+
+    def download(self, slot):
+        out = np.empty((self.size(slot), 3))
+        self._chk(self._L.sicp_cloud_download(self._h, slot, _ptr(out)))
+        return out
+
+    # -- nearest neighbours --
+    def knn(self, slot, q_xyz, k=1, H=None, max_dist=np.inf):
+        q = _f64(q_xyz)
+        Q = len(q)
+        idx = np.empty((Q, k), np.int64)
+        d2 = np.empty((Q, k), np.float64)
+        Hc = None if H is None else _f64(H).reshape(16)
+        self._chk(self._L.sicp_knn(self._h, slot, _ptr(q), Q, int(k), _ptr(Hc), float(max_dist), _ptr(idx), _ptr(d2)))
+        return idx, d2
+
+    def estimate_normals(self, slot, sel_idx, k, want_nn=False):
+        sel = np.ascontiguousarray(sel_idx, dtype=np.int64)
+        Q = len(sel)
+        nv = np.empty((Q, 3), np.float32)
+        pl = np.empty(Q, np.float32)
+        nn = np.empty((Q, k), np.int64) if want_nn else None
+        self._chk(self._L.sicp_estimate_normals(self._h, slot, _ptr(sel), Q, int(k), _ptr(nv), _ptr(pl), _ptr(nn)))
+        return (nv, pl, nn) if want_nn else (nv, pl)
+
+    # -- ICP iteration --
+    def icp_setup(self, sel_idx, normals, planarity):
+        sel = np.ascontiguousarray(sel_idx, dtype=np.int64)
+        nv = np.ascontiguousarray(normals, dtype=np.float32)
+        pl = np.ascontiguousarray(planarity, dtype=np.float32)
+        if nv.shape != (len(sel), 3) or pl.shape != (len(sel),):
+            raise ValueError("normals must be (Q,3) and planarity (Q,)")
+        self._chk(self._L.sicp_icp_setup(self._h, _ptr(sel), len(sel), _ptr(nv), _ptr(pl)))
+        self._Q = len(sel)
+
+    def icp_iterate(self, x, obs, obs_weight, min_planarity=0.3, distance_weight=1.0, max_lm_steps=0):
+        """One iteration; distance_weight None = automatic (simpleicp.py:233-234).  Returns IterResult;
+        raises BackendError(code=ERR_TOO_FEW) when fewer than 6 correspondences survive."""
+        P = IterParams()
+        P.x[:] = list(map(float, x))
+        P.obs[:] = list(map(float, obs))
+        P.obs_weight[:] = list(map(float, obs_weight))
+        P.min_planarity = float(min_planarity)
+        P.distance_weight = -1.0 if distance_weight is None else float(distance_weight)
+        P.max_lm_steps = int(max_lm_steps)
+        R = IterResult()
+        rc = self._L.sicp_icp_iterate(self._h, C.byref(P), C.byref(R))
+        if rc != OK:
+            err = BackendError(self._L.sicp_last_error().decode(), rc)
+            err.result = R
+            raise err
+        return R
+
+    def icp_state(self, pc2_idx=True, dist=True, keep=True, residual=True):
+        Q = self._Q
+        a = np.empty(Q, np.int64) if pc2_idx else None
+        b = np.empty(Q, np.float64) if dist else None
+        c = np.empty(Q, np.uint8) if keep else None
+        d = np.empty(Q, np.float64) if residual else None
+        self._chk(self._L.sicp_icp_get_state(self._h, _ptr(a), _ptr(b), _ptr(c), _ptr(d)))
+        return a, b, (None if c is None else c.astype(bool)), d
+
+    def icp_uncertainties(self):
+        s = np.empty(6)
+        self._chk(self._L.sicp_icp_uncertainties(self._h, _ptr(s)))
+        return s
+
+    def icp_normal_equations(self, x):
+        out = np.empty(30)
+        self._chk(self._L.sicp_icp_normal_equations(self._h, _ptr(_f64(x)), _ptr(out)))
+        return out
+
+    # -- multi-GPU exchange hook --
+    def set_exchange(self, fn, rank, world, gn_shard=False):
+        """fn(what, a_ptr, b_ptr, c_ptr, count) -> 0 on success; pointers are device addresses."""
+        if fn is None:
+            self._cb = EXCHANGE_FN(0)
+        else:
+            def tramp(_user, what, a, b, c, count):
+                try:
+                    return int(fn(what, a, b, c, count) or 0)
+                except Exception:  # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = EXCHANGE_FN(tramp)
+        self._chk(self._L.sicp_set_exchange(self._h, self._cb, None, int(rank), int(world), int(bool(gn_shard))))
+
+    # -- timing --
+    def timing_enable(self, on=True):
+        self._chk(self._L.sicp_timing_enable(self._h, int(on)))
+
+    def timing_reset(self):
+        self._chk(self._L.sicp_timing_reset(self._h))
+
+    def timing(self):
+        out = {}
+        for k, name in KERNEL_NAMES.items():
+            ms, n = C.c_double(), C.c_int64()
+            self._chk(self._L.sicp_timing_get(self._h, k, C.byref(ms), C.byref(n)))
+            out[name] = {"ms": ms.value, "launches": n.value}
+        return out

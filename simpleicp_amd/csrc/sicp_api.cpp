@@ -1,0 +1,746 @@
+// sicp_api.cpp -- host side of libsimpleicp_hip.so: C ABI (include/simpleicp_hip.h), device
+// memory, kernel sequencing of one ICP iteration, and the host 6x6 Levenberg-Marquardt solve
+// that the fused GPU reductions feed.  No CPU compute fallback exists: without a gfx950 device
+// sicp_ctx_create fails with SICP_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/simpleicp_hip.h"
+#include "sicp_internal.h"
+
+using namespace sicp;
+
+#define SICP_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(SICP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+#define CHK(expr)                  \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != SICP_OK) return rc_; \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;   // elements
+    int reserve(size_t n)
+    {
+        if (n <= cap) return SICP_OK;
+        if (p) { HIPCHK(hipFree(p)); p = nullptr; cap = 0; }
+        HIPCHK(hipMalloc((void **)&p, n * sizeof(T)));
+        cap = n;
+        return SICP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Cloud {
+    int64_t n = 0, npad = 0, idx_base = 0;
+    DevBuf<double> xyz;   // x[npad] | y[npad] | z[npad]
+    const double *x() const { return xyz.p; }
+    const double *y() const { return xyz.p + npad; }
+    const double *z() const { return xyz.p + 2 * npad; }
+    double *x() { return xyz.p; }
+    double *y() { return xyz.p + npad; }
+    double *z() { return xyz.p + 2 * npad; }
+};
+
+struct EventPair { hipEvent_t a, b; int kernel; };
+
+long round_up(long v, long g) { return (v + g - 1) / g * g; }
+
+// mathutils.py:39-68 : R = Rx(a1) * Ry(a2) * Rz(a3) written out
+void euler_R(const double a[3], double R[9])
+{
+    const double c1 = std::cos(a[0]), s1 = std::sin(a[0]);
+    const double c2 = std::cos(a[1]), s2 = std::sin(a[1]);
+    const double c3 = std::cos(a[2]), s3 = std::sin(a[2]);
+    R[0] = c2 * c3;                 R[1] = -c2 * s3;                R[2] = s2;
+    R[3] = c1 * s3 + s1 * s2 * c3;  R[4] = c1 * c3 - s1 * s2 * s3;  R[5] = -s1 * c2;
+    R[6] = s1 * s3 - c1 * s2 * c3;  R[7] = s1 * c3 + c1 * s2 * s3;  R[8] = c1 * c2;
+}
+
+// analytic partial derivatives of R w.r.t. the three Euler angles
+void euler_dR(const double a[3], double dR[27])
+{
+    const double c1 = std::cos(a[0]), s1 = std::sin(a[0]);
+    const double c2 = std::cos(a[1]), s2 = std::sin(a[1]);
+    const double c3 = std::cos(a[2]), s3 = std::sin(a[2]);
+    double *A = dR, *B = dR + 9, *C = dR + 18;
+    A[0] = 0; A[1] = 0; A[2] = 0;
+    A[3] = -s1 * s3 + c1 * s2 * c3;  A[4] = -s1 * c3 - c1 * s2 * s3;  A[5] = -c1 * c2;
+    A[6] = c1 * s3 + s1 * s2 * c3;   A[7] = c1 * c3 - s1 * s2 * s3;   A[8] = -s1 * c2;
+    B[0] = -s2 * c3;       B[1] = s2 * s3;        B[2] = c2;
+    B[3] = s1 * c2 * c3;   B[4] = -s1 * c2 * s3;  B[5] = s1 * s2;
+    B[6] = -c1 * c2 * c3;  B[7] = c1 * c2 * s3;   B[8] = -c1 * s2;
+    C[0] = -c2 * s3;                 C[1] = -c2 * c3;                  C[2] = 0;
+    C[3] = c1 * c3 - s1 * s2 * s3;   C[4] = -c1 * s3 - s1 * s2 * c3;   C[5] = 0;
+    C[6] = s1 * c3 + c1 * s2 * s3;   C[7] = -s1 * s3 + c1 * s2 * c3;   C[8] = 0;
+}
+
+void params_to_H12(const double x[6], double H12[12])
+{
+    double R[9];
+    euler_R(x, R);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) H12[4 * r + c] = R[3 * r + c];
+        H12[4 * r + 3] = x[3 + r];
+    }
+}
+
+// in-place Cholesky solve of an m x m SPD system (m <= 6); returns false if not SPD
+bool spd_solve(int m, double *A, double *b)
+{
+    for (int j = 0; j < m; ++j) {
+        double s = A[j * m + j];
+        for (int k = 0; k < j; ++k) s -= A[j * m + k] * A[j * m + k];
+        if (!(s > 0.0) || !std::isfinite(s)) return false;
+        const double l = std::sqrt(s);
+        A[j * m + j] = l;
+        for (int i = j + 1; i < m; ++i) {
+            double t = A[i * m + j];
+            for (int k = 0; k < j; ++k) t -= A[i * m + k] * A[j * m + k];
+            A[i * m + j] = t / l;
+        }
+    }
+    for (int i = 0; i < m; ++i) {
+        double t = b[i];
+        for (int k = 0; k < i; ++k) t -= A[i * m + k] * b[k];
+        b[i] = t / A[i * m + i];
+    }
+    for (int i = m - 1; i >= 0; --i) {
+        double t = b[i];
+        for (int k = i + 1; k < m; ++k) t -= A[k * m + i] * b[k];
+        b[i] = t / A[i * m + i];
+    }
+    return true;
+}
+
+bool is_observed(double w) { return w > 0 && std::isfinite(w); }
+
+}  // namespace
+
+struct sicp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    Cloud cloud[2];
+    DevBuf<double> stage;          // AoS staging for uploads / downloads / query sets
+    // scan workspace
+    DevBuf<double> part_d2;
+    DevBuf<uint32_t> part_idx;
+    DevBuf<double> kq;             // SoA queries of sicp_knn: qx|qy|qz
+    DevBuf<double> k_d2;           // (Q,k) results
+    DevBuf<int64_t> k_idx;
+    DevBuf<double> floor_d2;
+    DevBuf<uint32_t> floor_idx;
+    // ICP state (selected fixed points and per-iteration products)
+    int64_t Q = 0, qpad = 0;
+    DevBuf<double> q;              // qx|qy|qz [qpad]
+    DevBuf<float> normals, planarity;
+    DevBuf<int64_t> m_idx;         // matched movable index (global)
+    DevBuf<double> m_d2, m_p2, dist, resid;
+    DevBuf<uint8_t> flag, keep;
+    DevBuf<double> small;          // [0..3] reject out, [4..6] stats out, [8..37] normal equations
+    DevBuf<double> ne_partial;
+    DevBuf<unsigned> ticket;
+    double *h_small = nullptr;     // pinned mirror of `small`
+    bool have_iter = false;
+    double last_x[6] = {0}, last_w = 1.0, last_obs[6] = {0}, last_ow[6] = {0};
+    // exchange
+    sicp_exchange_fn xfn = nullptr;
+    void *xuser = nullptr;
+    int rank = 0, world = 1, gn_shard = 0;
+    // timing
+    bool timing = false;
+    std::vector<EventPair> pending, pool;
+    double t_ms[SICP_K_COUNT] = {0};
+    int64_t t_n[SICP_K_COUNT] = {0};
+};
+
+namespace {
+
+int sync(sicp_ctx *c)
+{
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &p : c->pending) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
+        c->t_ms[p.kernel] += ms;
+        c->t_n[p.kernel] += 1;
+        c->pool.push_back(p);
+    }
+    c->pending.clear();
+    return SICP_OK;
+}
+
+struct Timed {
+    sicp_ctx *c; EventPair ev; bool on;
+    Timed(sicp_ctx *ctx, int kernel) : c(ctx), on(ctx->timing)
+    {
+        if (!on) return;
+        if (!c->pool.empty()) { ev = c->pool.back(); c->pool.pop_back(); }
+        else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
+        ev.kernel = kernel;
+        (void)hipEventRecord(ev.a, c->stream);
+    }
+    ~Timed()
+    {
+        if (!on) return;
+        (void)hipEventRecord(ev.b, c->stream);
+        c->pending.push_back(ev);
+    }
+};
+
+// how the scanned cloud is cut into chunks so the grid fills 256 CUs several times over
+void plan_chunks(const sicp_ctx *c, long npad, long qblocks, size_t bytes_per_chunk_row, int *chunk_pts, int *nchunks)
+{
+    const long target_blocks = 8L * c->prop.multiProcessorCount;
+    long want = (target_blocks + qblocks - 1) / qblocks;
+    const long tiles = npad / TILE_PTS;
+    if (want > tiles) want = tiles;
+    const size_t budget = (size_t)2 << 30;   // partial-result workspace cap: 2 GiB
+    while (want > 1 && (size_t)want * bytes_per_chunk_row > budget) want = (want + 1) / 2;
+    if (want < 1) want = 1;
+    long tiles_per_chunk = (tiles + want - 1) / want;
+    *chunk_pts = (int)(tiles_per_chunk * TILE_PTS);
+    *nchunks = (int)((tiles + tiles_per_chunk - 1) / tiles_per_chunk);
+}
+
+int check_slot(sicp_ctx *c, int slot, bool need_data)
+{
+    if (!c) return fail(SICP_ERR_INVALID, "null ctx");
+    if (slot != SICP_FIX && slot != SICP_MOV) return fail(SICP_ERR_INVALID, "slot must be SICP_FIX or SICP_MOV");
+    if (need_data && c->cloud[slot].n <= 0) return fail(SICP_ERR_INVALID, "cloud slot %d is empty", slot);
+    return SICP_OK;
+}
+
+void H16_to_Xf(const double H[16], Xf *o) { for (int i = 0; i < 12; ++i) o->m[i] = H[i]; }
+
+// 1-NN of SoA queries (qx|qy|qz with stride qpad) in a slot; results in device buffers
+int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, const Xf *H, double max_dist,
+                double *d2_out, int64_t *idx_out, double *p2_out)
+{
+    Cloud &cl = c->cloud[slot];
+    int chunk_pts, nchunks;
+    const long qblocks = qpad / QPAD;
+    plan_chunks(c, cl.npad, qblocks, (size_t)qpad * 12, &chunk_pts, &nchunks);
+    CHK(c->part_d2.reserve((size_t)nchunks * qpad));
+    CHK(c->part_idx.reserve((size_t)nchunks * qpad));
+    {
+        Timed t(c, SICP_K_KNN1);
+        launch_knn1_scan(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, (int)qpad, cl.x(), cl.y(), cl.z(), cl.npad,
+                         chunk_pts, nchunks, H, c->part_d2.p, c->part_idx.p);
+    }
+    const double max_d2 = max_dist * max_dist;
+    launch_knn1_reduce(c->stream, c->part_d2.p, c->part_idx.p, nchunks, (int)qpad, Q, max_d2, cl.idx_base, cl.x(),
+                       cl.y(), cl.z(), d2_out, idx_out, p2_out);
+    HIPCHK(hipGetLastError());
+    return SICP_OK;
+}
+
+// k-NN (k >= 2, or k == 1 without transform) of SoA queries; (Q,k) device outputs
+int knnk_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, int k, double *d2_out, int64_t *idx_out)
+{
+    Cloud &cl = c->cloud[slot];
+    int done = 0;
+    bool floor_valid = false;
+    while (done < k) {
+        const int rem = k - done;
+        const int K = rem <= 8 ? 8 : rem <= 16 ? 16 : rem <= 32 ? 32 : 64;
+        const int kout = rem < K ? rem : K;
+        int chunk_pts, nchunks;
+        plan_chunks(c, cl.npad, qpad / KNN_BLOCK, (size_t)qpad * K * 12, &chunk_pts, &nchunks);
+        CHK(c->part_d2.reserve((size_t)nchunks * qpad * K));
+        CHK(c->part_idx.reserve((size_t)nchunks * qpad * K));
+        const bool more = done + kout < k;
+        if (more || floor_valid) { CHK(c->floor_d2.reserve(qpad)); CHK(c->floor_idx.reserve(qpad)); }
+        {
+            Timed t(c, SICP_K_KNNK);
+            launch_knnk_pass(c->stream, K, qsoa, qsoa + qpad, qsoa + 2 * qpad, (int)qpad, Q, cl.x(), cl.y(), cl.z(),
+                             cl.npad, chunk_pts, nchunks, floor_valid ? c->floor_d2.p : nullptr,
+                             floor_valid ? c->floor_idx.p : nullptr, c->part_d2.p, c->part_idx.p, kout, done, k,
+                             cl.idx_base, d2_out, idx_out, more ? c->floor_d2.p : nullptr,
+                             more ? c->floor_idx.p : nullptr);
+        }
+        HIPCHK(hipGetLastError());
+        floor_valid = more;
+        done += kout;
+    }
+    return SICP_OK;
+}
+
+// fused reduction at parameters x over [lo,hi) -> host out[30] (sums over ranks if sharded)
+int normal_eq_host(sicp_ctx *c, const double x[6], bool write_resid, bool allow_shard, double out[30])
+{
+    double H12[12], dR[27];
+    params_to_H12(x, H12);
+    euler_dR(x, dR);
+    long lo = 0, hi = c->Q;
+    const bool shard = allow_shard && c->world > 1 && c->gn_shard && c->xfn;
+    if (shard) {
+        const long per = (c->Q + c->world - 1) / c->world;
+        lo = std::min<long>(c->Q, per * c->rank);
+        hi = std::min<long>(c->Q, lo + per);
+    }
+    double *d_out = c->small.p + 8;
+    {
+        Timed t(c, SICP_K_NORMALEQ);
+        launch_normal_eq(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->m_p2.p, c->keep.p,
+                         lo, hi, H12, dR, c->ne_partial.p, c->ticket.p, d_out, write_resid ? c->resid.p : nullptr);
+    }
+    HIPCHK(hipGetLastError());
+    if (shard) {
+        CHK(sync(c));
+        if (c->xfn(c->xuser, SICP_XCHG_SUM_F64, d_out, nullptr, nullptr, 30) != 0)
+            return fail(SICP_ERR_EXCHANGE, "exchange callback (SUM_F64) failed");
+    }
+    HIPCHK(hipMemcpyAsync(c->h_small + 8, d_out, 30 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CHK(sync(c));
+    std::memcpy(out, c->h_small + 8, 30 * sizeof(double));
+    return SICP_OK;
+}
+
+double objective(const double ne[30], double w, const double x[6], const double obs[6], const double ow[6])
+{
+    double cst = w * w * ne[28];
+    for (int j = 0; j < 6; ++j)
+        if (is_observed(ow[j])) { const double e = ow[j] * (x[j] - obs[j]); cst += e * e; }
+    return cst;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+SICP_EXPORT int sicp_abi_version(void) { return SICP_ABI_VERSION; }
+SICP_EXPORT const char *sicp_last_error(void) { return g_err.c_str(); }
+
+SICP_EXPORT int sicp_device_count(int *count_out)
+{
+    if (!count_out) return fail(SICP_ERR_INVALID, "count_out is null");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count_out = n;
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
+{
+    if (!ctx_out) return fail(SICP_ERR_INVALID, "ctx_out is null");
+    *ctx_out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(SICP_ERR_NO_DEVICE, "no HIP device visible: libsimpleicp_hip has no CPU path");
+    if (device < 0 || device >= n) return fail(SICP_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    sicp_ctx *c = new sicp_ctx();
+    c->device = device;
+    if (hipGetDeviceProperties(&c->prop, device) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipGetDeviceProperties failed"); }
+    if (std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        const std::string arch = c->prop.gcnArchName;
+        delete c;
+        return fail(SICP_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, arch.c_str());
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipStreamCreate failed"); }
+    if (hipHostMalloc((void **)&c->h_small, 64 * sizeof(double)) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipHostMalloc failed"); }
+    int rc = c->small.reserve(64);
+    if (rc == SICP_OK) rc = c->ne_partial.reserve((size_t)NE_MAX_GRID * 32);
+    if (rc == SICP_OK) rc = c->ticket.reserve(4);
+    if (rc == SICP_OK && hipMemsetAsync(c->ticket.p, 0, 4 * sizeof(unsigned), c->stream) != hipSuccess) rc = SICP_ERR_HIP;
+    if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
+    *ctx_out = c;
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
+{
+    if (!c) return SICP_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto &p : c->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto &cl : c->cloud) cl.xyz.release();
+    c->stage.release(); c->part_d2.release(); c->part_idx.release(); c->kq.release(); c->k_d2.release();
+    c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->q.release(); c->normals.release();
+    c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
+    c->resid.release(); c->flag.release(); c->keep.release(); c->small.release(); c->ne_partial.release();
+    c->ticket.release();
+    if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_ctx_device_name(sicp_ctx *c, char *buf, int buflen)
+{
+    if (!c || !buf || buflen <= 0) return fail(SICP_ERR_INVALID, "bad arguments");
+    std::snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", c->prop.name, c->prop.gcnArchName, c->prop.multiProcessorCount);
+    return SICP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+SICP_EXPORT int sicp_cloud_upload(sicp_ctx *c, int slot, const double *xyz, int64_t n, int64_t index_base)
+{
+    CHK(check_slot(c, slot, false));
+    if (!xyz || n <= 0) return fail(SICP_ERR_INVALID, "cloud must have at least one point");
+    if (n >= (int64_t)0xffffffffLL) return fail(SICP_ERR_INVALID, "at most 2^32-2 points per GPU shard");
+    HIPCHK(hipSetDevice(c->device));
+    Cloud &cl = c->cloud[slot];
+    cl.n = n; cl.npad = round_up(n, TILE_PTS); cl.idx_base = index_base;
+    CHK(cl.xyz.reserve((size_t)3 * cl.npad));
+    CHK(c->stage.reserve((size_t)3 * n));
+    HIPCHK(hipMemcpyAsync(c->stage.p, xyz, (size_t)3 * n * sizeof(double), hipMemcpyDefault, c->stream));
+    launch_aos_to_soa(c->stream, c->stage.p, n, cl.npad, cl.x(), cl.y(), cl.z());
+    HIPCHK(hipGetLastError());
+    return sync(c);
+}
+
+SICP_EXPORT int sicp_cloud_size(sicp_ctx *c, int slot, int64_t *n_out)
+{
+    CHK(check_slot(c, slot, false));
+    if (!n_out) return fail(SICP_ERR_INVALID, "n_out is null");
+    *n_out = c->cloud[slot].n;
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_cloud_transform(sicp_ctx *c, int slot, const double H[16])
+{
+    CHK(check_slot(c, slot, true));
+    if (!H) return fail(SICP_ERR_INVALID, "H is null");
+    HIPCHK(hipSetDevice(c->device));
+    Xf X; H16_to_Xf(H, &X);
+    Cloud &cl = c->cloud[slot];
+    launch_transform(c->stream, cl.x(), cl.y(), cl.z(), cl.n, X);
+    HIPCHK(hipGetLastError());
+    return sync(c);
+}
+
+SICP_EXPORT int sicp_cloud_download(sicp_ctx *c, int slot, double *xyz_out)
+{
+    CHK(check_slot(c, slot, true));
+    if (!xyz_out) return fail(SICP_ERR_INVALID, "xyz_out is null");
+    HIPCHK(hipSetDevice(c->device));
+    Cloud &cl = c->cloud[slot];
+    CHK(c->stage.reserve((size_t)3 * cl.n));
+    launch_soa_to_aos(c->stream, cl.x(), cl.y(), cl.z(), cl.n, c->stage.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(xyz_out, c->stage.p, (size_t)3 * cl.n * sizeof(double), hipMemcpyDefault, c->stream));
+    return sync(c);
+}
+
+// ------------------------------------------------------------------------------------------
+SICP_EXPORT int sicp_knn(sicp_ctx *c, int slot, const double *q_xyz, int64_t Q, int k, const double *H, double max_dist,
+                         int64_t *idx_out, double *d2_out)
+{
+    CHK(check_slot(c, slot, true));
+    if (!q_xyz || !idx_out) return fail(SICP_ERR_INVALID, "q_xyz / idx_out is null");
+    if (Q <= 0) return fail(SICP_ERR_INVALID, "Q must be > 0");
+    if (k < 1) return fail(SICP_ERR_INVALID, "k must be >= 1");
+    if (k > 1 && (H || std::isfinite(max_dist)))
+        return fail(SICP_ERR_INVALID, "H / max_dist are only supported for k == 1");
+    if (std::isnan(max_dist) || max_dist < 0) return fail(SICP_ERR_INVALID, "max_dist must be >= 0");
+    HIPCHK(hipSetDevice(c->device));
+    const long qpad = round_up(Q, QPAD);
+    CHK(c->kq.reserve((size_t)3 * qpad));
+    CHK(c->stage.reserve((size_t)3 * Q));
+    CHK(c->k_d2.reserve((size_t)Q * k));
+    CHK(c->k_idx.reserve((size_t)Q * k));
+    HIPCHK(hipMemcpyAsync(c->stage.p, q_xyz, (size_t)3 * Q * sizeof(double), hipMemcpyDefault, c->stream));
+    launch_aos_queries(c->stream, c->stage.p, Q, qpad, c->kq.p, c->kq.p + qpad, c->kq.p + 2 * qpad);
+    if (k == 1) {
+        Xf X;
+        if (H) H16_to_Xf(H, &X);
+        CHK(knn1_device(c, slot, c->kq.p, Q, qpad, H ? &X : nullptr, max_dist, c->k_d2.p, c->k_idx.p, nullptr));
+    } else {
+        CHK(knnk_device(c, slot, c->kq.p, Q, qpad, k, c->k_d2.p, c->k_idx.p));
+    }
+    HIPCHK(hipMemcpyAsync(idx_out, c->k_idx.p, (size_t)Q * k * sizeof(int64_t), hipMemcpyDefault, c->stream));
+    if (d2_out) HIPCHK(hipMemcpyAsync(d2_out, c->k_d2.p, (size_t)Q * k * sizeof(double), hipMemcpyDefault, c->stream));
+    return sync(c);
+}
+
+SICP_EXPORT int sicp_estimate_normals(sicp_ctx *c, int slot, const int64_t *sel_idx, int64_t Q, int k, float *normals_out,
+                                      float *planarity_out, int64_t *nn_idx_out)
+{
+    CHK(check_slot(c, slot, true));
+    if (!sel_idx || !normals_out || !planarity_out) return fail(SICP_ERR_INVALID, "null argument");
+    if (Q <= 0) return fail(SICP_ERR_INVALID, "Q must be > 0");
+    if (k < 2) return fail(SICP_ERR_INVALID, "neighbors must be >= 2");
+    Cloud &cl = c->cloud[slot];
+    if (k > cl.n) return fail(SICP_ERR_INVALID, "neighbors (%d) exceeds the number of points (%lld)", k, (long long)cl.n);
+    HIPCHK(hipSetDevice(c->device));
+    const long qpad = round_up(Q, QPAD);
+    CHK(c->kq.reserve((size_t)3 * qpad));
+    CHK(c->k_d2.reserve((size_t)Q * k));
+    CHK(c->k_idx.reserve((size_t)Q * k));
+    // selected rows -> device (reuse m_idx-sized scratch in k_idx tail? keep it simple: own buffer)
+    DevBuf<int64_t> sel; DevBuf<float> nv, pl;
+    int rc = sel.reserve(Q);
+    if (rc == SICP_OK) rc = nv.reserve((size_t)3 * Q);
+    if (rc == SICP_OK) rc = pl.reserve(Q);
+    auto body = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(sel.p, sel_idx, (size_t)Q * sizeof(int64_t), hipMemcpyDefault, c->stream));
+        launch_gather_queries(c->stream, cl.x(), cl.y(), cl.z(), sel.p, Q, qpad, c->kq.p, c->kq.p + qpad, c->kq.p + 2 * qpad);
+        CHK(knnk_device(c, slot, c->kq.p, Q, qpad, k, c->k_d2.p, c->k_idx.p));
+        launch_normals(c->stream, cl.x(), cl.y(), cl.z(), c->k_idx.p, Q, k, cl.idx_base, nv.p, pl.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(normals_out, nv.p, (size_t)3 * Q * sizeof(float), hipMemcpyDefault, c->stream));
+        HIPCHK(hipMemcpyAsync(planarity_out, pl.p, (size_t)Q * sizeof(float), hipMemcpyDefault, c->stream));
+        if (nn_idx_out) HIPCHK(hipMemcpyAsync(nn_idx_out, c->k_idx.p, (size_t)Q * k * sizeof(int64_t), hipMemcpyDefault, c->stream));
+        return sync(c);
+    };
+    if (rc == SICP_OK) rc = body();
+    (void)hipStreamSynchronize(c->stream);
+    sel.release(); nv.release(); pl.release();
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+SICP_EXPORT int sicp_icp_setup(sicp_ctx *c, const int64_t *sel_idx, int64_t Q, const float *normals, const float *planarity)
+{
+    CHK(check_slot(c, SICP_FIX, true));
+    if (!sel_idx || !normals || !planarity) return fail(SICP_ERR_INVALID, "null argument");
+    if (Q <= 0) return fail(SICP_ERR_INVALID, "Q must be > 0");
+    HIPCHK(hipSetDevice(c->device));
+    Cloud &cl = c->cloud[SICP_FIX];
+    c->Q = Q; c->qpad = round_up(Q, QPAD);
+    CHK(c->q.reserve((size_t)3 * c->qpad));
+    CHK(c->normals.reserve((size_t)3 * Q)); CHK(c->planarity.reserve(Q));
+    CHK(c->m_idx.reserve(Q)); CHK(c->m_d2.reserve(Q)); CHK(c->m_p2.reserve((size_t)3 * Q));
+    CHK(c->dist.reserve(Q)); CHK(c->resid.reserve(Q)); CHK(c->flag.reserve(Q)); CHK(c->keep.reserve(Q));
+    HIPCHK(hipMemcpyAsync(c->m_idx.p, sel_idx, (size_t)Q * sizeof(int64_t), hipMemcpyDefault, c->stream));
+    launch_gather_queries(c->stream, cl.x(), cl.y(), cl.z(), c->m_idx.p, Q, c->qpad, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->normals.p, normals, (size_t)3 * Q * sizeof(float), hipMemcpyDefault, c->stream));
+    HIPCHK(hipMemcpyAsync(c->planarity.p, planarity, (size_t)Q * sizeof(float), hipMemcpyDefault, c->stream));
+    c->have_iter = false;
+    return sync(c);
+}
+
+SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
+{
+    if (!c || !P || !R) return fail(SICP_ERR_INVALID, "null argument");
+    if (c->Q <= 0) return fail(SICP_ERR_INVALID, "call sicp_icp_setup first");
+    CHK(check_slot(c, SICP_MOV, true));
+    HIPCHK(hipSetDevice(c->device));
+    std::memset(R, 0, sizeof *R);
+    const long Q = c->Q;
+    int nfree = 0, freeidx[6];
+    for (int j = 0; j < 6; ++j) {
+        if (std::isnan(P->obs_weight[j]) || P->obs_weight[j] < 0) return fail(SICP_ERR_INVALID, "obs_weight[%d] must be >= 0", j);
+        if (std::isfinite(P->obs_weight[j])) freeidx[nfree++] = j;
+    }
+
+    // ---- match: simpleicp.py:188-202, corrpts.py:124-137 (transform fused into the scan) ----
+    double H12[12];
+    params_to_H12(P->x, H12);
+    Xf X; for (int i = 0; i < 12; ++i) X.m[i] = H12[i];
+    CHK(knn1_device(c, SICP_MOV, c->q.p, Q, c->qpad, &X, std::numeric_limits<double>::infinity(), c->m_d2.p, c->m_idx.p, c->m_p2.p));
+    if (c->world > 1 && c->xfn) {
+        CHK(sync(c));
+        if (c->xfn(c->xuser, SICP_XCHG_BEST_MATCH, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q) != 0)
+            return fail(SICP_ERR_EXCHANGE, "exchange callback (BEST_MATCH) failed");
+    }
+    // ---- distances + rejections: corrpts.py:139-211 ----
+    launch_postmatch(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, c->m_p2.p,
+                     c->m_idx.p, Q, X, (float)P->min_planarity, c->dist.p, c->flag.p);
+    {
+        Timed t(c, SICP_K_SELECT);
+        launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p);
+    }
+    launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_small, c->small.p, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CHK(sync(c));
+    R->n_queries = Q;
+    R->n_planar = (int64_t)c->h_small[0];
+    R->median = c->h_small[1]; R->mad = c->h_small[2];
+    R->n_kept = (int64_t)c->h_small[3];
+    R->dist_mean = c->h_small[5]; R->dist_std = c->h_small[6];
+    c->have_iter = true;
+    std::memcpy(c->last_x, P->x, sizeof c->last_x);
+    if (R->n_kept < 6) {
+        std::memcpy(R->x, P->x, sizeof R->x);
+        return fail(SICP_ERR_TOO_FEW, "Too few correspondences! At least 6 correspondences are needed to estimate the 6 "
+                                      "rigid body transformation parameters. The current number of correspondences is %lld.",
+                    (long long)R->n_kept);
+    }
+    double w = P->distance_weight;
+    if (!(w > 0)) w = 1.0 / (R->dist_std * R->dist_std);   // simpleicp.py:233-234
+    R->weight_used = w;
+
+    // ---- optimisation: optimization.py:65-124 as LM on fused 6x6 reductions ----
+    const double *obs = P->obs, *ow = P->obs_weight;
+    double x[6]; std::memcpy(x, P->x, sizeof x);
+    double ne[30];
+    CHK(normal_eq_host(c, x, false, true, ne)); R->ne_evals++;
+    double cost = objective(ne, w, x, obs, ow);
+    double lambda = 0.0;
+    const int max_steps = P->max_lm_steps > 0 ? (int)P->max_lm_steps : 100;
+    for (int it = 0; it < max_steps && nfree > 0; ++it) {
+        double N[36], g[6];
+        int t = 0;
+        for (int u = 0; u < 6; ++u) for (int v = u; v < 6; ++v) { N[u * 6 + v] = N[v * 6 + u] = w * w * ne[t++]; }
+        for (int u = 0; u < 6; ++u) g[u] = w * w * ne[21 + u];
+        for (int j = 0; j < 6; ++j)
+            if (is_observed(ow[j])) { N[j * 6 + j] += ow[j] * ow[j]; g[j] += ow[j] * ow[j] * (x[j] - obs[j]); }
+        bool accepted = false;
+        double xn[6], nen[30], costn = cost, dxmax = 0;
+        for (int tries = 0; tries < 40; ++tries) {
+            double A[36], b[6];
+            for (int u = 0; u < nfree; ++u) {
+                for (int v = 0; v < nfree; ++v) A[u * nfree + v] = N[freeidx[u] * 6 + freeidx[v]];
+                A[u * nfree + u] += lambda * N[freeidx[u] * 6 + freeidx[u]];
+                b[u] = -g[freeidx[u]];
+            }
+            if (!spd_solve(nfree, A, b)) { lambda = lambda > 0 ? lambda * 10 : 1e-6; continue; }
+            std::memcpy(xn, x, sizeof x);
+            dxmax = 0;
+            for (int u = 0; u < nfree; ++u) { xn[freeidx[u]] += b[u]; dxmax = std::max(dxmax, std::fabs(b[u])); }
+            CHK(normal_eq_host(c, xn, false, true, nen)); R->ne_evals++;
+            costn = objective(nen, w, xn, obs, ow);
+            if (costn <= cost * (1 + 1e-14) || dxmax < 1e-15) { accepted = true; break; }
+            lambda = lambda > 0 ? lambda * 10 : 1e-6;
+        }
+        if (!accepted) break;
+        std::memcpy(x, xn, sizeof x); std::memcpy(ne, nen, sizeof ne);
+        cost = costn;
+        lambda = lambda > 0 ? lambda * 0.1 : 0.0;
+        if (lambda < 1e-12) lambda = 0.0;
+        R->lm_steps++;
+        double xmax = 0; for (int j = 0; j < 6; ++j) xmax = std::max(xmax, std::fabs(x[j]));
+        if (dxmax <= 1e-13 * (1.0 + xmax)) break;
+    }
+    if (!std::isfinite(cost)) return fail(SICP_ERR_NUMERIC, "objective is not finite");
+
+    // ---- residuals at the optimum (optimization.py:117-124) + their mean/std (simpleicp.py:356-379) ----
+    CHK(normal_eq_host(c, x, true, false, ne)); R->ne_evals++;
+    launch_stats(c->stream, c->resid.p, c->keep.p, Q, c->small.p + 4);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_small + 4, c->small.p + 4, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CHK(sync(c));
+    R->res_mean = c->h_small[5]; R->res_std = c->h_small[6];
+    R->cost = cost;
+    std::memcpy(R->x, x, sizeof x);
+    params_to_H12(x, R->H);
+    R->H[12] = 0; R->H[13] = 0; R->H[14] = 0; R->H[15] = 1;
+    std::memcpy(c->last_x, x, sizeof x);
+    c->last_w = w;
+    std::memcpy(c->last_obs, obs, sizeof c->last_obs);
+    std::memcpy(c->last_ow, ow, sizeof c->last_ow);
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_icp_get_state(sicp_ctx *c, int64_t *pc2_idx, double *dist, uint8_t *keep, double *residual)
+{
+    if (!c) return fail(SICP_ERR_INVALID, "null ctx");
+    if (!c->have_iter) return fail(SICP_ERR_INVALID, "no iteration has run yet");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t Q = (size_t)c->Q;
+    if (pc2_idx) HIPCHK(hipMemcpyAsync(pc2_idx, c->m_idx.p, Q * sizeof(int64_t), hipMemcpyDefault, c->stream));
+    if (dist) HIPCHK(hipMemcpyAsync(dist, c->dist.p, Q * sizeof(double), hipMemcpyDefault, c->stream));
+    if (keep) HIPCHK(hipMemcpyAsync(keep, c->keep.p, Q * sizeof(uint8_t), hipMemcpyDefault, c->stream));
+    if (residual) HIPCHK(hipMemcpyAsync(residual, c->resid.p, Q * sizeof(double), hipMemcpyDefault, c->stream));
+    return sync(c);
+}
+
+SICP_EXPORT int sicp_icp_normal_equations(sicp_ctx *c, const double x[6], double out[30])
+{
+    if (!c || !x || !out) return fail(SICP_ERR_INVALID, "null argument");
+    if (!c->have_iter) return fail(SICP_ERR_INVALID, "no iteration has run yet");
+    HIPCHK(hipSetDevice(c->device));
+    return normal_eq_host(c, x, false, false, out);
+}
+
+SICP_EXPORT int sicp_icp_uncertainties(sicp_ctx *c, double sigma_out[6])
+{
+    if (!c || !sigma_out) return fail(SICP_ERR_INVALID, "null argument");
+    if (!c->have_iter) return fail(SICP_ERR_INVALID, "no iteration has run yet");
+    HIPCHK(hipSetDevice(c->device));
+    double ne[30];
+    CHK(normal_eq_host(c, c->last_x, false, false, ne));
+    const double w = c->last_w, *ow = c->last_ow, *obs = c->last_obs, *x = c->last_x;
+    int freeidx[6], m = 0, nobs = 0;
+    for (int j = 0; j < 6; ++j) { sigma_out[j] = std::numeric_limits<double>::quiet_NaN(); if (std::isfinite(ow[j])) freeidx[m++] = j; }
+    // optimization.py:154-159: N = A^T diag(w) A with LINEAR weights, s0^2 = v^T P v / (n_obs - n_prm)
+    double N[36]; int t = 0;
+    for (int u = 0; u < 6; ++u) for (int v = u; v < 6; ++v) { N[u * 6 + v] = N[v * 6 + u] = w * ne[t++]; }
+    double vPv = w * ne[28];
+    for (int j = 0; j < 6; ++j)
+        if (is_observed(ow[j])) { N[j * 6 + j] += ow[j]; const double e = x[j] - obs[j]; vPv += ow[j] * e * e; ++nobs; }
+    const double s02 = vPv / ((ne[29] + nobs) - m);
+    for (int u = 0; u < m; ++u) {
+        double A[36], b[6];
+        for (int a = 0; a < m; ++a) { for (int q = 0; q < m; ++q) A[a * m + q] = N[freeidx[a] * 6 + freeidx[q]]; b[a] = (a == u) ? 1.0 : 0.0; }
+        if (!spd_solve(m, A, b)) return fail(SICP_ERR_NUMERIC, "normal matrix is not positive definite");
+        sigma_out[freeidx[u]] = std::sqrt(s02 * b[u]);
+    }
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_params_to_H(const double x[6], double H_out[16])
+{
+    if (!x || !H_out) return fail(SICP_ERR_INVALID, "null argument");
+    params_to_H12(x, H_out);
+    H_out[12] = 0; H_out[13] = 0; H_out[14] = 0; H_out[15] = 1;
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_set_exchange(sicp_ctx *c, sicp_exchange_fn fn, void *user, int rank, int world, int gn_shard)
+{
+    if (!c) return fail(SICP_ERR_INVALID, "null ctx");
+    if (world < 1 || rank < 0 || rank >= world) return fail(SICP_ERR_INVALID, "bad rank/world");
+    if (world > 1 && !fn) return fail(SICP_ERR_INVALID, "world > 1 needs an exchange callback");
+    c->xfn = fn; c->xuser = user; c->rank = rank; c->world = world; c->gn_shard = gn_shard ? 1 : 0;
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_timing_enable(sicp_ctx *c, int on)
+{
+    if (!c) return fail(SICP_ERR_INVALID, "null ctx");
+    c->timing = on != 0;
+    return SICP_OK;
+}
+SICP_EXPORT int sicp_timing_reset(sicp_ctx *c)
+{
+    if (!c) return fail(SICP_ERR_INVALID, "null ctx");
+    for (int i = 0; i < SICP_K_COUNT; ++i) { c->t_ms[i] = 0; c->t_n[i] = 0; }
+    return SICP_OK;
+}
+SICP_EXPORT int sicp_timing_get(sicp_ctx *c, int kernel, double *total_ms_out, int64_t *launches_out)
+{
+    if (!c || kernel < 0 || kernel >= SICP_K_COUNT) return fail(SICP_ERR_INVALID, "bad arguments");
+    if (total_ms_out) *total_ms_out = c->t_ms[kernel];
+    if (launches_out) *launches_out = c->t_n[kernel];
+    return SICP_OK;
+}

@@ -1,0 +1,49 @@
+// sicp_internal.h -- shared between the host side (sicp_api.cpp) and the kernels (sicp_kernels.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sicp {
+
+// rows 0..2 of a 4x4 row-major homogeneous transform (row 3 is 0 0 0 1)
+struct Xf { double m[12]; };
+
+constexpr int    KNN_BLOCK = 256;     // lanes per workgroup of the scan kernels (4 waves, 1 per SIMD)
+constexpr int    KNN1_R    = 4;       // queries per lane in the 1-NN scan
+constexpr int    TILE_PTS  = 1024;    // cloud points staged in LDS per step (24 KiB)
+constexpr int    QPAD      = KNN_BLOCK * KNN1_R;   // query padding granule
+constexpr int    NE_BLOCK  = 256;
+constexpr int    NE_MAX_GRID = 1024;
+constexpr double SICP_PAD_COORD_V = 1.0e300;
+#define SICP_PAD_COORD 1.0e300
+
+void launch_aos_to_soa(hipStream_t s, const double *aos, long n, long npad, double *x, double *y, double *z);
+void launch_soa_to_aos(hipStream_t s, const double *x, const double *y, const double *z, long n, double *aos);
+void launch_transform(hipStream_t s, double *x, double *y, double *z, long n, const Xf &H);
+void launch_gather_queries(hipStream_t s, const double *x, const double *y, const double *z, const int64_t *sel,
+                           long Q, long qpad, double *qx, double *qy, double *qz);
+void launch_aos_queries(hipStream_t s, const double *aos, long Q, long qpad, double *qx, double *qy, double *qz);
+void launch_knn1_scan(hipStream_t s, const double *qx, const double *qy, const double *qz, int qpad,
+                      const double *px, const double *py, const double *pz, long npad, int chunk_pts, int nchunks,
+                      const Xf *H, double *part_d2, uint32_t *part_idx);
+void launch_knn1_reduce(hipStream_t s, const double *part_d2, const uint32_t *part_idx, int nchunks, int qpad, long Q,
+                        double max_d2, int64_t idx_base, const double *px, const double *py, const double *pz,
+                        double *d2_out, int64_t *idx_out, double *p2_out);
+void launch_knnk_pass(hipStream_t s, int K, const double *qx, const double *qy, const double *qz, int qpad, long Q,
+                      const double *px, const double *py, const double *pz, long npad, int chunk_pts, int nchunks,
+                      const double *floor_d2_in, const uint32_t *floor_idx_in, double *part_d2, uint32_t *part_idx,
+                      int kout, int col0, int kstride, int64_t idx_base, double *d2_out, int64_t *idx_out,
+                      double *floor_d2_out, uint32_t *floor_idx_out);
+void launch_normals(hipStream_t s, const double *px, const double *py, const double *pz, const int64_t *nn, long Q, int k,
+                    int64_t idx_base, float *normals, float *planarity);
+void launch_postmatch(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
+                      const float *planarity, const double *p2, const int64_t *idx, long Q, const Xf &H,
+                      float min_planarity, double *dist, uint8_t *flag);
+void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4);
+void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3);
+int  ne_grid_for(long count);
+void launch_normal_eq(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
+                      const double *p2, const uint8_t *keep, long lo, long hi, const double H12[12], const double dR[27],
+                      double *partial, unsigned *ticket, double *out30, double *resid);
+
+}  // namespace sicp

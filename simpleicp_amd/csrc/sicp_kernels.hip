@@ -1,0 +1,766 @@
+// sicp_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the simpleICP inner loop.
+//
+// Compile with -ffp-contract=off: every fused multiply-add below is an explicit fma() so the
+// arithmetic contract (T)/(D)/(P) of include/simpleicp_hip.h holds bit-for-bit against
+// oracle/sicp_oracle.c.
+//
+// Data layout in HBM (all owned by the ctx, see sicp_internal.h):
+//   cloud slot : SoA  x[npad] | y[npad] | z[npad]  float64, npad = n rounded up to TILE_PTS,
+//                pad rows hold SICP_PAD_COORD (their squared distance overflows to +inf and
+//                can never win a strict `<`), so no scan kernel needs a tail branch.
+//   queries    : SoA  qx|qy|qz [qpad] float64, qpad = Q rounded up to 1024.
+//   partials   : [nchunks][qpad] (d2 f64, idx u32) -- one row per chunk of the scanned cloud.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sicp_internal.h"
+
+namespace sicp {
+
+// ------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void xform(const Xf &H, double x, double y, double z,
+                                      double &ox, double &oy, double &oz)
+{
+    double t;
+    t = H.m[0] * x;  t = fma(H.m[1], y, t);  t = fma(H.m[2], z, t);   ox = t + H.m[3];
+    t = H.m[4] * x;  t = fma(H.m[5], y, t);  t = fma(H.m[6], z, t);   oy = t + H.m[7];
+    t = H.m[8] * x;  t = fma(H.m[9], y, t);  t = fma(H.m[10], z, t);  oz = t + H.m[11];
+}
+
+__device__ __forceinline__ double plane_dist(double dx, double dy, double dz, float nx, float ny, float nz)
+{
+    const double a = dx * (double)nx;
+    const double b = dy * (double)ny;
+    const double c = dz * (double)nz;
+    return (a + b) + c;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------
+// cloud upload: AoS (n,3) -> padded SoA                       PointCloud ctor, pointcloud.py:15-49
+// ------------------------------------------------------------------------------------
+__global__ void k_aos_to_soa(const double *__restrict__ aos, long n, long npad,
+                             double *__restrict__ x, double *__restrict__ y, double *__restrict__ z)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    if (i < n) { x[i] = aos[3 * i]; y[i] = aos[3 * i + 1]; z[i] = aos[3 * i + 2]; }
+    else       { x[i] = SICP_PAD_COORD; y[i] = SICP_PAD_COORD; z[i] = SICP_PAD_COORD; }
+}
+
+__global__ void k_soa_to_aos(const double *__restrict__ x, const double *__restrict__ y,
+                             const double *__restrict__ z, long n, double *__restrict__ aos)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    aos[3 * i] = x[i]; aos[3 * i + 1] = y[i]; aos[3 * i + 2] = z[i];
+}
+
+// PointCloud.transform_by_H, pointcloud.py:205-217 -- in place, HBM-bound (48 B/point).
+__global__ void k_transform(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z, long n, Xf H)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double X, Y, Z;
+    xform(H, x[i], y[i], z[i], X, Y, Z);
+    x[i] = X; y[i] = Y; z[i] = Z;
+}
+
+// gather rows of a SoA cloud into SoA queries (selected fixed points)
+__global__ void k_gather_queries(const double *__restrict__ x, const double *__restrict__ y,
+                                 const double *__restrict__ z, const int64_t *__restrict__ sel, long Q, long qpad,
+                                 double *__restrict__ qx, double *__restrict__ qy, double *__restrict__ qz)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= qpad) return;
+    if (i < Q) { const int64_t s = sel[i]; qx[i] = x[s]; qy[i] = y[s]; qz[i] = z[s]; }
+    else       { qx[i] = 0.0; qy[i] = 0.0; qz[i] = 0.0; }
+}
+
+__global__ void k_aos_queries(const double *__restrict__ aos, long Q, long qpad,
+                              double *__restrict__ qx, double *__restrict__ qy, double *__restrict__ qz)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= qpad) return;
+    if (i < Q) { qx[i] = aos[3 * i]; qy[i] = aos[3 * i + 1]; qz[i] = aos[3 * i + 2]; }
+    else       { qx[i] = 0.0; qy[i] = 0.0; qz[i] = 0.0; }
+}
+
+// ------------------------------------------------------------------------------------
+// K1: brute-force 1-NN scan              CorrPts.match, corrpts.py:124-137 (+ simpleicp.py:188)
+//
+// lane  = R queries held in registers (query-stationary);
+// block = 256 lanes -> 256*R queries, scans one chunk of the cloud;
+// the cloud streams through LDS in TILE_PTS-point tiles: coalesced 8-B/lane global loads,
+// the H transform is applied ONCE per point on the way into LDS (fused transform_by_H, the
+// reference's O(N) pandas pass per iteration disappears), then every lane reads the tile by
+// LDS broadcast (all lanes same address: conflict-free).
+// Ascending scan + strict `<` == lexicographic (d2, idx) minimum within the chunk.
+// ------------------------------------------------------------------------------------
+template <int R, bool XFORM>
+__global__ __launch_bounds__(KNN_BLOCK) void k_knn1_scan(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, int qpad,
+    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
+    long npad, int chunk_pts, Xf H, double *__restrict__ part_d2, uint32_t *__restrict__ part_idx)
+{
+    __shared__ double sx[TILE_PTS], sy[TILE_PTS], sz[TILE_PTS];
+    const int tid = threadIdx.x;
+    const long q0 = (long)blockIdx.x * (KNN_BLOCK * R);
+
+    double ax[R], ay[R], az[R], best[R];
+    uint32_t bidx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long q = q0 + r * KNN_BLOCK + tid;
+        ax[r] = qx[q]; ay[r] = qy[q]; az[r] = qz[q];
+        best[r] = __builtin_inf(); bidx[r] = 0xffffffffu;
+    }
+
+    const long c0 = (long)blockIdx.y * chunk_pts;
+    long c1 = c0 + chunk_pts;
+    if (c1 > npad) c1 = npad;
+
+    for (long t0 = c0; t0 < c1; t0 += TILE_PTS) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < TILE_PTS / KNN_BLOCK; ++u) {
+            const int s = u * KNN_BLOCK + tid;
+            double X = px[t0 + s], Y = py[t0 + s], Z = pz[t0 + s];
+            if (XFORM) { double a, b, c; xform(H, X, Y, Z, a, b, c); X = a; Y = b; Z = c; }
+            sx[s] = X; sy[s] = Y; sz[s] = Z;
+        }
+        __syncthreads();
+        const uint32_t base = (uint32_t)t0;
+#pragma unroll 4
+        for (int j = 0; j < TILE_PTS; ++j) {
+            const double X = sx[j], Y = sy[j], Z = sz[j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double dx = X - ax[r], dy = Y - ay[r], dz = Z - az[r];
+                const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                if (d2 < best[r]) { best[r] = d2; bidx[r] = base + (uint32_t)j; }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long q = q0 + r * KNN_BLOCK + tid;
+        part_d2[(long)blockIdx.y * qpad + q] = best[r];
+        part_idx[(long)blockIdx.y * qpad + q] = bidx[r];
+    }
+}
+
+// chunk partials -> per-query winner (ascending chunk order + strict `<` keeps the lowest
+// index on ties), strict upper bound (pointcloud.py:163-167), gather of the winner's
+// ORIGINAL coordinates (what the optimiser consumes, optimization.py:172-211).
+__global__ void k_knn1_reduce(const double *__restrict__ part_d2, const uint32_t *__restrict__ part_idx,
+                              int nchunks, int qpad, long Q, double max_d2, int64_t idx_base,
+                              const double *__restrict__ px, const double *__restrict__ py,
+                              const double *__restrict__ pz,
+                              double *__restrict__ d2_out, int64_t *__restrict__ idx_out,
+                              double *__restrict__ p2_out /* (Q,3) row-major, may be null */)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    double best = __builtin_inf();
+    uint32_t bi = 0xffffffffu;
+    for (int c = 0; c < nchunks; ++c) {
+        const double d = part_d2[(long)c * qpad + q];
+        if (d < best) { best = d; bi = part_idx[(long)c * qpad + q]; }
+    }
+    const bool ok = (bi != 0xffffffffu) && (best < max_d2);
+    d2_out[q] = ok ? best : __builtin_inf();
+    idx_out[q] = ok ? (idx_base + (int64_t)bi) : (int64_t)-1;
+    if (p2_out) {
+        p2_out[3 * q]     = ok ? px[bi] : 0.0;
+        p2_out[3 * q + 1] = ok ? py[bi] : 0.0;
+        p2_out[3 * q + 2] = ok ? pz[bi] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K2: brute-force k-NN scan                       estimate_normals, pointcloud.py:185-186
+//
+// One query per lane, its K best (d2, idx) kept SORTED in registers (static indexing only:
+// the bubble is fully unrolled).  The insertion branch is taken ~K*ln(n/K) times per lane,
+// the scan itself is the same LDS-broadcast loop as K1.  A per-query lexicographic floor
+// lets the host ask for neighbours K+1..2K in a second pass (k > 64).
+// ------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(KNN_BLOCK) void k_knnk_scan(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, int qpad,
+    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
+    long npad, int chunk_pts, const double *__restrict__ floor_d2, const uint32_t *__restrict__ floor_idx,
+    double *__restrict__ part_d2, uint32_t *__restrict__ part_idx)
+{
+    __shared__ double sx[TILE_PTS], sy[TILE_PTS], sz[TILE_PTS];
+    const int tid = threadIdx.x;
+    const long q = (long)blockIdx.x * KNN_BLOCK + tid;
+    const double ax = qx[q], ay = qy[q], az = qz[q];
+    const bool has_floor = floor_d2 != nullptr;
+    const double fd = has_floor ? floor_d2[q] : -1.0;
+    const uint32_t fi = has_floor ? floor_idx[q] : 0u;
+
+    double d[K];
+    uint32_t ix[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) { d[s] = __builtin_inf(); ix[s] = 0xffffffffu; }
+
+    const long c0 = (long)blockIdx.y * chunk_pts;
+    long c1 = c0 + chunk_pts;
+    if (c1 > npad) c1 = npad;
+
+    for (long t0 = c0; t0 < c1; t0 += TILE_PTS) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < TILE_PTS / KNN_BLOCK; ++u) {
+            const int s = u * KNN_BLOCK + tid;
+            sx[s] = px[t0 + s]; sy[s] = py[t0 + s]; sz[s] = pz[t0 + s];
+        }
+        __syncthreads();
+        const uint32_t base = (uint32_t)t0;
+        for (int j = 0; j < TILE_PTS; ++j) {
+            const double dx = sx[j] - ax, dy = sy[j] - ay, dz = sz[j] - az;
+            const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+            const uint32_t id = base + (uint32_t)j;
+            bool take = d2 < d[K - 1];
+            if (has_floor) take = take && ((d2 > fd) || (d2 == fd && id > fi));
+            if (take) {
+                d[K - 1] = d2; ix[K - 1] = id;
+#pragma unroll
+                for (int s = K - 1; s > 0; --s) {
+                    const bool sw = d[s] < d[s - 1];   // strict: equal d2 keeps the lower index first
+                    const double lo = sw ? d[s] : d[s - 1], hi = sw ? d[s - 1] : d[s];
+                    const uint32_t li = sw ? ix[s] : ix[s - 1], hi_i = sw ? ix[s - 1] : ix[s];
+                    d[s - 1] = lo; d[s] = hi; ix[s - 1] = li; ix[s] = hi_i;
+                }
+            }
+        }
+    }
+    const long o = ((long)blockIdx.y * qpad + q) * K;
+#pragma unroll
+    for (int s = 0; s < K; ++s) { part_d2[o + s] = d[s]; part_idx[o + s] = ix[s]; }
+}
+
+// merge the per-chunk sorted lists of one query; writes `kout` neighbours starting at
+// column `col0` of the (Q, kstride) outputs, and the new floor for a following pass.
+template <int K>
+__global__ void k_knnk_merge(const double *__restrict__ part_d2, const uint32_t *__restrict__ part_idx,
+                             int nchunks, int qpad, long Q, int kout, int col0, int kstride, int64_t idx_base,
+                             double *__restrict__ d2_out, int64_t *__restrict__ idx_out,
+                             double *__restrict__ floor_d2, uint32_t *__restrict__ floor_idx)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    double d[K];
+    uint32_t ix[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) { d[s] = __builtin_inf(); ix[s] = 0xffffffffu; }
+    for (int c = 0; c < nchunks; ++c) {
+        const long o = ((long)c * qpad + q) * K;
+        for (int e = 0; e < K; ++e) {
+            const double d2 = part_d2[o + e];
+            if (!(d2 < d[K - 1])) break;          // lists are sorted: nothing further can enter
+            d[K - 1] = d2; ix[K - 1] = part_idx[o + e];
+#pragma unroll
+            for (int s = K - 1; s > 0; --s) {
+                const bool sw = d[s] < d[s - 1];
+                const double lo = sw ? d[s] : d[s - 1], hi = sw ? d[s - 1] : d[s];
+                const uint32_t li = sw ? ix[s] : ix[s - 1], hi_i = sw ? ix[s - 1] : ix[s];
+                d[s - 1] = lo; d[s] = hi; ix[s - 1] = li; ix[s] = hi_i;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        if (s < kout) {
+            const bool ok = ix[s] != 0xffffffffu;
+            if (d2_out) d2_out[q * kstride + col0 + s] = ok ? d[s] : __builtin_inf();
+            idx_out[q * kstride + col0 + s] = ok ? idx_base + (int64_t)ix[s] : (int64_t)-1;
+        }
+    }
+    if (floor_d2) {
+        // last emitted neighbour becomes the exclusive lower bound of the next pass
+        double fd = -1.0; uint32_t fi = 0;
+#pragma unroll
+        for (int s = 0; s < K; ++s) if (s == kout - 1) { fd = d[s]; fi = ix[s]; }
+        floor_d2[q] = fd; floor_idx[q] = fi;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K3: covariance + symmetric 3x3 eigen-decomposition     pointcloud.py:188-198
+// one query per lane, fp64, same operation order as oracle/sicp_oracle.c:orc_normals.
+// ------------------------------------------------------------------------------------
+__device__ void jacobi3(double a[3][3], double v[3][3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        if (off == 0.0) break;
+#pragma unroll
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = (pq == 2) ? 1 : 0;
+            const int q = (pq == 0) ? 1 : 2;
+            const int r = 3 - p - q;
+            if (a[p][q] == 0.0) continue;
+            const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            const double apq = a[p][q];
+            a[p][p] -= t * apq; a[q][q] += t * apq; a[p][q] = 0.0; a[q][p] = 0.0;
+            const double arp = a[r][p], arq = a[r][q];
+            a[r][p] = c * arp - s * arq; a[p][r] = a[r][p];
+            a[r][q] = s * arp + c * arq; a[q][r] = a[r][q];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double vip = v[i][p], viq = v[i][q];
+                v[i][p] = c * vip - s * viq;
+                v[i][q] = s * vip + c * viq;
+            }
+        }
+    }
+}
+
+__global__ void k_normals(const double *__restrict__ px, const double *__restrict__ py,
+                          const double *__restrict__ pz, const int64_t *__restrict__ nn, long Q, int k,
+                          int64_t idx_base, float *__restrict__ normals, float *__restrict__ planarity)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const int64_t *row = nn + q * k;
+    double m[3] = {0, 0, 0};
+    for (int s = 0; s < k; ++s) {
+        const int64_t i = row[s] - idx_base;
+        m[0] += px[i]; m[1] += py[i]; m[2] += pz[i];
+    }
+    m[0] /= (double)k; m[1] /= (double)k; m[2] /= (double)k;
+    double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int s = 0; s < k; ++s) {
+        const int64_t i = row[s] - idx_base;
+        const double d0 = px[i] - m[0], d1 = py[i] - m[1], d2 = pz[i] - m[2];
+        C[0][0] = fma(d0, d0, C[0][0]); C[0][1] = fma(d0, d1, C[0][1]); C[0][2] = fma(d0, d2, C[0][2]);
+        C[1][1] = fma(d1, d1, C[1][1]); C[1][2] = fma(d1, d2, C[1][2]); C[2][2] = fma(d2, d2, C[2][2]);
+    }
+    const double inv = 1.0 / (double)(k - 1);
+    C[0][0] *= inv; C[0][1] *= inv; C[0][2] *= inv; C[1][1] *= inv; C[1][2] *= inv; C[2][2] *= inv;
+    C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
+    double V[3][3];
+    jacobi3(C, V);
+    const double w[3] = {C[0][0], C[1][1], C[2][2]};
+    int lo = 0, hi = 0;
+#pragma unroll
+    for (int c = 1; c < 3; ++c) { if (w[c] < w[lo]) lo = c; if (w[c] > w[hi]) hi = c; }
+    if (lo == hi) { lo = 2; hi = 0; }
+    const int mid = 3 - lo - hi;
+    double wl = 0, wm = 0, wh = 0, n0 = 0, n1 = 0, n2 = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (c == lo) { wl = w[c]; n0 = V[0][c]; n1 = V[1][c]; n2 = V[2][c]; }
+        if (c == mid) wm = w[c];
+        if (c == hi) wh = w[c];
+    }
+    int big = 0; double bigv = fabs(n0);
+    if (fabs(n1) > bigv) { big = 1; bigv = fabs(n1); }
+    if (fabs(n2) > bigv) { big = 2; }
+    const double lead = (big == 0) ? n0 : (big == 1) ? n1 : n2;
+    if (lead < 0) { n0 = -n0; n1 = -n1; n2 = -n2; }
+    normals[3 * q] = (float)n0; normals[3 * q + 1] = (float)n1; normals[3 * q + 2] = (float)n2;
+    planarity[q] = (float)((wm - wl) / wh);
+}
+
+// ------------------------------------------------------------------------------------
+// K5: point-to-plane distances of the fresh matches + planarity flag
+//     corrpts.py:195-211, corrpts.py:139-163
+// flag: 1 = passes the planarity test (float32 compare, NaN fails) and has a match
+// ------------------------------------------------------------------------------------
+__global__ void k_postmatch(const double *__restrict__ qx, const double *__restrict__ qy,
+                            const double *__restrict__ qz, const float *__restrict__ normals,
+                            const float *__restrict__ planarity, const double *__restrict__ p2,
+                            const int64_t *__restrict__ idx, long Q, Xf H, float min_planarity,
+                            double *__restrict__ dist, uint8_t *__restrict__ flag)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    double X, Y, Z;
+    xform(H, p2[3 * q], p2[3 * q + 1], p2[3 * q + 2], X, Y, Z);
+    dist[q] = plane_dist(X - qx[q], Y - qy[q], Z - qz[q], normals[3 * q], normals[3 * q + 1], normals[3 * q + 2]);
+    flag[q] = (idx[q] >= 0 && planarity[q] >= min_planarity) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------
+// K6: median / raw-MAD rejection      corrpts.py:165-188  (np.median: mean of the two
+// middle values for even counts; scipy median_abs_deviation with scale = 1.0)
+//
+// One 1024-lane workgroup, everything in a single launch: exact order statistics by
+// 8-bit-digit radix selection on the order-preserving uint64 image of the doubles
+// (8 passes per rank, LDS histogram + wave scan), then the keep mask and its count.
+// out[0]=m (planarity survivors) out[1]=median out[2]=mad out[3]=n_kept
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ord_key(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord_val(uint64_t k)
+{
+    const uint64_t b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// selects the element of rank `rank` (0-based) among flagged values f(d[i]); ABSDEV: f = |d - center|
+template <bool ABSDEV>
+__device__ double radix_select(const double *__restrict__ d, const uint8_t *__restrict__ flag, long Q,
+                               long rank, double center, unsigned *hist /*[256]*/, unsigned long long *sh /*[2]*/)
+{
+    const int tid = threadIdx.x;
+    uint64_t prefix = 0;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (long i = tid; i < Q; i += blockDim.x) {
+            if (!flag[i]) continue;
+            const double v = ABSDEV ? fabs(d[i] - center) : d[i];
+            const uint64_t k = ord_key(v);
+            if (pass == 0 || (k >> (shift + 8)) == (prefix >> (shift + 8)))
+                atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // wave 0: lane l owns bins 4l..4l+3
+            const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const unsigned mine = h0 + h1 + h2 + h3;
+            unsigned incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned t = __shfl_up(incl, off, 64);
+                if (tid >= off) incl += t;
+            }
+            const unsigned long long excl = incl - mine;
+            const unsigned long long r = (unsigned long long)rank;
+            if (r >= excl && r < excl + mine) {
+                unsigned long long acc = excl; int bin = 4 * tid;
+                if (r >= acc + h0) { acc += h0; bin++; if (r >= acc + h1) { acc += h1; bin++; if (r >= acc + h2) { acc += h2; bin++; } } }
+                sh[0] = (unsigned long long)bin;
+                sh[1] = r - acc;
+            }
+        }
+        __syncthreads();
+        prefix |= ((uint64_t)sh[0]) << shift;
+        rank = (long)sh[1];
+        __syncthreads();
+    }
+    return ord_val(prefix);
+}
+
+__global__ __launch_bounds__(1024) void k_reject(const double *__restrict__ dist, const uint8_t *__restrict__ flag,
+                                                 long Q, uint8_t *__restrict__ keep, double *__restrict__ out)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long sh[2];
+    __shared__ unsigned long long cnt;
+    const int tid = threadIdx.x;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    unsigned long long local = 0;
+    for (long i = tid; i < Q; i += blockDim.x) local += flag[i] ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((tid & 63) == 0 && local) atomicAdd(&cnt, local);
+    __syncthreads();
+    const long m = (long)cnt;
+    __syncthreads();
+    if (m == 0) {
+        for (long i = tid; i < Q; i += blockDim.x) keep[i] = 0;
+        if (tid == 0) { out[0] = 0; out[1] = __builtin_nan(""); out[2] = __builtin_nan(""); out[3] = 0; }
+        return;
+    }
+    const double a = radix_select<false>(dist, flag, Q, (m - 1) / 2, 0.0, hist, sh);
+    const double b = (m & 1) ? a : radix_select<false>(dist, flag, Q, m / 2, 0.0, hist, sh);
+    const double med = (a + b) / 2.0;
+    const double c = radix_select<true>(dist, flag, Q, (m - 1) / 2, med, hist, sh);
+    const double e = (m & 1) ? c : radix_select<true>(dist, flag, Q, m / 2, med, hist, sh);
+    const double mad = (c + e) / 2.0;
+    const double bound = 3 * mad;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    local = 0;
+    for (long i = tid; i < Q; i += blockDim.x) {
+        const uint8_t kq = (flag[i] && fabs(dist[i] - med) <= bound) ? 1 : 0;
+        keep[i] = kq; local += kq;
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((tid & 63) == 0 && local) atomicAdd(&cnt, local);
+    __syncthreads();
+    if (tid == 0) { out[0] = (double)m; out[1] = med; out[2] = mad; out[3] = (double)cnt; }
+}
+
+// ------------------------------------------------------------------------------------
+// masked mean / population std (two-pass, np.std ddof=0)     simpleicp.py:233-234,356-379
+// single workgroup; out[0]=n out[1]=mean out[2]=std
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_stats(const double *__restrict__ v, const uint8_t *__restrict__ keep,
+                                                long Q, double *__restrict__ out)
+{
+    __shared__ double red[16];
+    __shared__ double bc[2];
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    double s = 0, n = 0;
+    for (long i = tid; i < Q; i += blockDim.x) if (keep[i]) { s += v[i]; n += 1; }
+    s = wave_sum(s); n = wave_sum(n);
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    if (tid == 0) { double t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w]; bc[0] = t; }
+    __syncthreads();
+    if (lane == 0) red[wid] = n;
+    __syncthreads();
+    if (tid == 0) { double t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w]; bc[1] = t; }
+    __syncthreads();
+    const double cnt = bc[1];
+    const double mean = bc[0] / cnt;
+    double ss = 0;
+    for (long i = tid; i < Q; i += blockDim.x) if (keep[i]) { const double e = v[i] - mean; ss += e * e; }
+    ss = wave_sum(ss);
+    __syncthreads();
+    if (lane == 0) red[wid] = ss;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        out[0] = cnt; out[1] = mean; out[2] = sqrt(t / cnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K7: fused residual + rejection mask + 6x6 normal-equation reduction
+//     optimization.py:172-288 (residual), c++/src/corrpts.cpp:110-156 (row layout twin)
+//
+// Per kept correspondence: p = R(x) p2 + t (contract T), r = n.(p - p1) (contract P),
+// J = [n.(dR1 p2), n.(dR2 p2), n.(dR3 p2), n];  accumulates the 21 upper-triangle
+// entries of J^T J, the 6 of J^T r, sum r, sum r^2, n -- 30 doubles -- in registers,
+// wave reduction by DPP/shuffle, one LDS hop per wave, block partials to global; the
+// LAST block (agent-scope release/acquire ticket) folds the partials in fixed order, so
+// the result is deterministic for a given grid.  72 B and ~75 flop per correspondence:
+// HBM/latency-bound by construction.
+// Optionally writes the residual vector (0 where masked).
+// ------------------------------------------------------------------------------------
+struct NeArgs {
+    Xf H;            // R(x) | t
+    double dR[27];   // dR/dalpha1, dR/dalpha2, dR/dalpha3 (row-major 3x3 each)
+};
+
+__global__ __launch_bounds__(NE_BLOCK) void k_normal_eq(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+    const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep,
+    long lo, long hi, NeArgs A, double *__restrict__ partial /*[grid][32]*/, unsigned *__restrict__ ticket,
+    double *__restrict__ out /*[30]*/, double *__restrict__ resid /* nullable, (Q) */)
+{
+    __shared__ double red[NE_BLOCK / 64][32];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    double acc[30];
+#pragma unroll
+    for (int i = 0; i < 30; ++i) acc[i] = 0.0;
+
+    for (long i = lo + (long)blockIdx.x * NE_BLOCK + tid; i < hi; i += (long)gridDim.x * NE_BLOCK) {
+        const bool k = keep[i] != 0;
+        double r = 0.0;
+        if (k) {
+            const double x = p2[3 * i], y = p2[3 * i + 1], z = p2[3 * i + 2];
+            double X, Y, Z;
+            xform(A.H, x, y, z, X, Y, Z);
+            const float fx = normals[3 * i], fy = normals[3 * i + 1], fz = normals[3 * i + 2];
+            r = plane_dist(X - qx[i], Y - qy[i], Z - qz[i], fx, fy, fz);
+            const double nx = fx, ny = fy, nz = fz;
+            double a[6];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double *D = A.dR + 9 * c;
+                const double gx = D[0] * x + D[1] * y + D[2] * z;
+                const double gy = D[3] * x + D[4] * y + D[5] * z;
+                const double gz = D[6] * x + D[7] * y + D[8] * z;
+                a[c] = nx * gx + ny * gy + nz * gz;
+            }
+            a[3] = nx; a[4] = ny; a[5] = nz;
+            int t = 0;
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+#pragma unroll
+                for (int v = u; v < 6; ++v) { acc[t] += a[u] * a[v]; ++t; }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) acc[21 + u] += a[u] * r;
+            acc[27] += r; acc[28] += r * r; acc[29] += 1.0;
+        }
+        if (resid) resid[i] = r;
+    }
+#pragma unroll
+    for (int i = 0; i < 30; ++i) {
+        const double s = wave_sum(acc[i]);
+        if (lane == 0) red[wid][i] = s;
+    }
+    __syncthreads();
+    if (tid < 30) {
+        double s = 0;
+#pragma unroll
+        for (int w = 0; w < NE_BLOCK / 64; ++w) s += red[w][tid];
+        partial[(long)blockIdx.x * 32 + tid] = s;
+    }
+    // publish this block's partial, then take a ticket (guide G16: stores -> vmcnt(0) ->
+    // barrier -> one-lane agent release -> ticket; last arriver: agent acquire -> plain loads)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (t == gridDim.x - 1) ? 1 : 0;
+        if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (is_last) {
+        if (tid < 30) {
+            double s = 0;
+            for (unsigned b = 0; b < gridDim.x; ++b) s += partial[(long)b * 32 + tid];
+            out[tid] = s;
+        }
+        if (tid == 0) *ticket = 0;   // re-arm for the next launch on this stream
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// launchers (host)
+// ------------------------------------------------------------------------------------
+static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
+void launch_aos_to_soa(hipStream_t s, const double *aos, long n, long npad, double *x, double *y, double *z)
+{
+    hipLaunchKernelGGL(k_aos_to_soa, dim3(cdiv(npad, 256)), dim3(256), 0, s, aos, n, npad, x, y, z);
+}
+void launch_soa_to_aos(hipStream_t s, const double *x, const double *y, const double *z, long n, double *aos)
+{
+    if (n > 0) hipLaunchKernelGGL(k_soa_to_aos, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, n, aos);
+}
+void launch_transform(hipStream_t s, double *x, double *y, double *z, long n, const Xf &H)
+{
+    if (n > 0) hipLaunchKernelGGL(k_transform, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, n, H);
+}
+void launch_gather_queries(hipStream_t s, const double *x, const double *y, const double *z, const int64_t *sel,
+                           long Q, long qpad, double *qx, double *qy, double *qz)
+{
+    hipLaunchKernelGGL(k_gather_queries, dim3(cdiv(qpad, 256)), dim3(256), 0, s, x, y, z, sel, Q, qpad, qx, qy, qz);
+}
+void launch_aos_queries(hipStream_t s, const double *aos, long Q, long qpad, double *qx, double *qy, double *qz)
+{
+    hipLaunchKernelGGL(k_aos_queries, dim3(cdiv(qpad, 256)), dim3(256), 0, s, aos, Q, qpad, qx, qy, qz);
+}
+
+void launch_knn1_scan(hipStream_t s, const double *qx, const double *qy, const double *qz, int qpad,
+                      const double *px, const double *py, const double *pz, long npad, int chunk_pts, int nchunks,
+                      const Xf *H, double *part_d2, uint32_t *part_idx)
+{
+    const dim3 grid(qpad / (KNN_BLOCK * KNN1_R), nchunks), block(KNN_BLOCK);
+    Xf id = {};
+    if (H)
+        hipLaunchKernelGGL((k_knn1_scan<KNN1_R, true>), grid, block, 0, s, qx, qy, qz, qpad, px, py, pz, npad,
+                           chunk_pts, *H, part_d2, part_idx);
+    else
+        hipLaunchKernelGGL((k_knn1_scan<KNN1_R, false>), grid, block, 0, s, qx, qy, qz, qpad, px, py, pz, npad,
+                           chunk_pts, id, part_d2, part_idx);
+}
+
+void launch_knn1_reduce(hipStream_t s, const double *part_d2, const uint32_t *part_idx, int nchunks, int qpad, long Q,
+                        double max_d2, int64_t idx_base, const double *px, const double *py, const double *pz,
+                        double *d2_out, int64_t *idx_out, double *p2_out)
+{
+    hipLaunchKernelGGL(k_knn1_reduce, dim3(cdiv(Q, 256)), dim3(256), 0, s, part_d2, part_idx, nchunks, qpad, Q, max_d2,
+                       idx_base, px, py, pz, d2_out, idx_out, p2_out);
+}
+
+template <int K>
+static void knnk_pass(hipStream_t s, const double *qx, const double *qy, const double *qz, int qpad, long Q,
+                      const double *px, const double *py, const double *pz, long npad, int chunk_pts, int nchunks,
+                      const double *floor_d2_in, const uint32_t *floor_idx_in, double *part_d2, uint32_t *part_idx,
+                      int kout, int col0, int kstride, int64_t idx_base, double *d2_out, int64_t *idx_out,
+                      double *floor_d2_out, uint32_t *floor_idx_out)
+{
+    hipLaunchKernelGGL((k_knnk_scan<K>), dim3(qpad / KNN_BLOCK, nchunks), dim3(KNN_BLOCK), 0, s, qx, qy, qz, qpad, px,
+                       py, pz, npad, chunk_pts, floor_d2_in, floor_idx_in, part_d2, part_idx);
+    hipLaunchKernelGGL((k_knnk_merge<K>), dim3(cdiv(Q, 64)), dim3(64), 0, s, part_d2, part_idx, nchunks, qpad, Q, kout,
+                       col0, kstride, idx_base, d2_out, idx_out, floor_d2_out, floor_idx_out);
+}
+
+void launch_knnk_pass(hipStream_t s, int K, const double *qx, const double *qy, const double *qz, int qpad, long Q,
+                      const double *px, const double *py, const double *pz, long npad, int chunk_pts, int nchunks,
+                      const double *floor_d2_in, const uint32_t *floor_idx_in, double *part_d2, uint32_t *part_idx,
+                      int kout, int col0, int kstride, int64_t idx_base, double *d2_out, int64_t *idx_out,
+                      double *floor_d2_out, uint32_t *floor_idx_out)
+{
+#define SICP_KNNK_CASE(KK)                                                                                          \
+    case KK:                                                                                                        \
+        knnk_pass<KK>(s, qx, qy, qz, qpad, Q, px, py, pz, npad, chunk_pts, nchunks, floor_d2_in, floor_idx_in,      \
+                      part_d2, part_idx, kout, col0, kstride, idx_base, d2_out, idx_out, floor_d2_out,              \
+                      floor_idx_out);                                                                               \
+        break;
+    switch (K) {
+        SICP_KNNK_CASE(8)
+        SICP_KNNK_CASE(16)
+        SICP_KNNK_CASE(32)
+        SICP_KNNK_CASE(64)
+    }
+#undef SICP_KNNK_CASE
+}
+
+void launch_normals(hipStream_t s, const double *px, const double *py, const double *pz, const int64_t *nn, long Q, int k,
+                    int64_t idx_base, float *normals, float *planarity)
+{
+    hipLaunchKernelGGL(k_normals, dim3(cdiv(Q, 64)), dim3(64), 0, s, px, py, pz, nn, Q, k, idx_base, normals, planarity);
+}
+
+void launch_postmatch(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
+                      const float *planarity, const double *p2, const int64_t *idx, long Q, const Xf &H,
+                      float min_planarity, double *dist, uint8_t *flag)
+{
+    hipLaunchKernelGGL(k_postmatch, dim3(cdiv(Q, 256)), dim3(256), 0, s, qx, qy, qz, normals, planarity, p2, idx, Q, H,
+                       min_planarity, dist, flag);
+}
+
+void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4)
+{
+    hipLaunchKernelGGL(k_reject, dim3(1), dim3(1024), 0, s, dist, flag, Q, keep, out4);
+}
+
+void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3)
+{
+    hipLaunchKernelGGL(k_stats, dim3(1), dim3(1024), 0, s, v, keep, Q, out3);
+}
+
+int ne_grid_for(long count)
+{
+    long g = (count + NE_BLOCK - 1) / NE_BLOCK;
+    if (g < 1) g = 1;
+    if (g > NE_MAX_GRID) g = NE_MAX_GRID;
+    return (int)g;
+}
+
+void launch_normal_eq(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
+                      const double *p2, const uint8_t *keep, long lo, long hi, const double H12[12], const double dR[27],
+                      double *partial, unsigned *ticket, double *out30, double *resid)
+{
+    NeArgs A;
+    for (int i = 0; i < 12; ++i) A.H.m[i] = H12[i];
+    for (int i = 0; i < 27; ++i) A.dR[i] = dR[i];
+    hipLaunchKernelGGL(k_normal_eq, dim3(ne_grid_for(hi - lo)), dim3(NE_BLOCK), 0, s, qx, qy, qz, normals, p2, keep, lo,
+                       hi, A, partial, ticket, out30, resid);
+}
+
+}  // namespace sicp

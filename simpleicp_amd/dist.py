@@ -1,0 +1,116 @@
+"""Multi-GPU exchange of the ICP iteration: one process per GPU, torch.distributed collectives
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU for the tests).
+
+Partitioning: the MOVABLE cloud is sharded by contiguous index range,
+the Q selected fixed points (+ normals, planarity) are replicated.  Per iteration there is ONE
+exchange step after the local brute-force scan:
+
+    every rank holds, per query, its shard's best (d2, global idx, xyz of that point)
+    -> all_gather of the three arrays (Q * 40 B per rank)
+    -> lexicographic (d2, idx) minimum over ranks  == the single-GPU (d2, idx) rule, bit-exact
+
+after which every rank owns the complete correspondence set, so the rejection statistics
+(median / MAD are not sums) need no further collective.  The 6x6 normal-equation reduction can
+either be replicated (no collective) or sharded over ranks with a SUM all-reduce of the 30
+accumulators per solver step (``gn_shard=True``) -- the latter pays off only for very large Q.
+
+The functions here work on torch tensors of any device so that the gloo/CPU tests exercise the
+exact code the GPU path runs.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def is_distributed() -> bool:
+    try:
+        import torch.distributed as td
+        return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+    except Exception:  # noqa: BLE001
+        return False
+
+
+def rank_world():
+    import torch.distributed as td
+    return td.get_rank(), td.get_world_size()
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    """Contiguous [lo, hi) slice of n rows owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def exchange_best_match(d2, idx, xyz, group=None):
+    """In place: replace (d2[Q], idx[Q] int64, xyz[Q,3]) by the job-wide lexicographic
+    (d2, idx) minimum and the coordinates that travel with it.  idx == -1 marks "no candidate"
+    (d2 == +inf) and loses against any real candidate."""
+    import torch
+    import torch.distributed as td
+    world = td.get_world_size(group)
+    g_d2 = [torch.empty_like(d2) for _ in range(world)]
+    g_idx = [torch.empty_like(idx) for _ in range(world)]
+    g_xyz = [torch.empty_like(xyz) for _ in range(world)]
+    td.all_gather(g_d2, d2.contiguous(), group=group)
+    td.all_gather(g_idx, idx.contiguous(), group=group)
+    td.all_gather(g_xyz, xyz.contiguous(), group=group)
+    D = torch.stack(g_d2)                                   # (world, Q)
+    I = torch.stack(g_idx)
+    X = torch.stack(g_xyz)                                  # (world, Q, 3)
+    dmin = D.min(dim=0).values
+    big = torch.iinfo(torch.int64).max
+    cand = torch.where((D == dmin) & (I >= 0), I, torch.full_like(I, big))
+    imin = cand.min(dim=0).values
+    winner = (cand == imin).to(torch.int64).argmax(dim=0)   # first rank holding the winner
+    none = imin == big
+    d2.copy_(torch.where(none, torch.full_like(dmin, float("inf")), dmin))
+    idx.copy_(torch.where(none, torch.full_like(imin, -1), imin))
+    picked = X.gather(0, winner.view(1, -1, 1).expand(1, -1, 3))[0]
+    xyz.copy_(torch.where(none.unsqueeze(1), torch.zeros_like(picked), picked))
+    return d2, idx, xyz
+
+
+def allreduce_sum(buf, group=None):
+    import torch.distributed as td
+    td.all_reduce(buf, op=td.ReduceOp.SUM, group=group)
+    return buf
+
+
+class _DevArray:
+    """Zero-copy view of library-owned device memory for torch (CUDA array interface v2)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _wrap(ptr, shape, typestr, device):
+    import torch
+    return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device)
+
+
+def make_exchange(device, group=None):
+    """Callback for Context.set_exchange: receives DEVICE pointers owned by the library."""
+    import torch
+
+    dev = torch.device("cuda", device)
+
+    def fn(what, a, b, c, count):
+        with torch.cuda.device(dev):
+            if what == _lib.XCHG_BEST_MATCH:
+                d2 = _wrap(a, (count,), "<f8", dev)
+                idx = _wrap(b, (count,), "<i8", dev)
+                xyz = _wrap(c, (count, 3), "<f8", dev)
+                exchange_best_match(d2, idx, xyz, group)
+            elif what == _lib.XCHG_SUM_F64:
+                allreduce_sum(_wrap(a, (count,), "<f8", dev), group)
+            else:
+                return 1
+            torch.cuda.current_stream(dev).synchronize()
+        return 0
+    return fn

@@ -1,0 +1,265 @@
+"""SimpleICP -- call-compatible with /root/reference/python/simpleicp/simpleicp.py:41-379.
+
+Same constructor, ``add_point_clouds``, ``run(**kwargs)`` signature, return tuple, exceptions,
+side effects on the two PointCloud objects and log lines as the reference; the per-iteration
+work (match, point-to-plane distances, planarity + MAD rejection, least-squares estimate) is
+ONE C-ABI call into the HIP library with both clouds resident in HBM for the whole run.
+
+Differences by design (documented in DESIGN.md):
+  * the movable cloud is never transformed back and forth on the host (simpleicp.py:188,202):
+    the transform is fused into the GPU scan, so the reference's ulp-level coordinate drift
+    does not occur;
+  * the NLLS problem of optimization.py:93-101 is minimised by Levenberg-Marquardt on fused
+    6x6 normal-equation reductions instead of lmfit/scipy TRF with a finite-difference
+    Jacobian -- same objective, same minimiser (tests pin H against the reference);
+  * under torch.distributed (world_size > 1) the movable cloud is sharded across the GPUs.
+"""
+from __future__ import annotations
+
+import logging
+import time
+from dataclasses import fields
+from pathlib import Path
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib, backend, dist
+from .pointcloud import PointCloud
+from .rbp import H_from_params, RigidBodyParameters
+
+_log = logging.getLogger(__name__)
+_PKG_LOG = logging.getLogger(__package__)
+_ATTRS = ("nx", "ny", "nz", "planarity")
+
+
+class SimpleICPException(Exception):
+    """Raised when the SimpleICP class is misused (simpleicp.py:382)."""
+
+
+def _enable_verbose_logging() -> None:
+    """INFO to stdout, once (simpleicp.py:25-38)."""
+    _PKG_LOG.setLevel(logging.INFO)
+    for h in _PKG_LOG.handlers:
+        if getattr(h, "_simpleicp_verbose", False):
+            return
+    h = logging.StreamHandler()
+    h.setFormatter(logging.Formatter("%(message)s"))
+    h._simpleicp_verbose = True
+    _PKG_LOG.addHandler(h)
+
+
+def _percent_change(new: float, old: float) -> float:
+    if old == 0:
+        return 0.0 if new == 0 else np.inf
+    return abs((new - old) / old * 100)
+
+
+class SimpleICP:
+    def __init__(self, verbose: bool = True) -> None:
+        self.pc1: Optional[PointCloud] = None
+        self.pc2: Optional[PointCloud] = None
+        self.last_run_info: dict = {}
+        if verbose:
+            _enable_verbose_logging()
+
+    def add_point_clouds(self, pc_fix: PointCloud, pc_mov: PointCloud) -> None:
+        self.pc1 = pc_fix      # fixed
+        self.pc2 = pc_mov      # movable: gets transformed
+
+    # --------------------------------------------------------------------------------------
+    def run(
+        self,
+        correspondences: int = 1000,
+        neighbors: int = 10,
+        min_planarity: float = 0.3,
+        max_overlap_distance: float = np.inf,
+        min_change: float = 1.0,
+        max_iterations: int = 100,
+        distance_weights: Optional[float] = 1,
+        rbp_observed_values: Tuple[float] = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0),
+        rbp_observation_weights: Tuple[float] = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0),
+        debug_dirpath: str = "",
+    ) -> Tuple[np.ndarray, np.ndarray, RigidBodyParameters, np.ndarray]:
+        """See the reference docstring (simpleicp.py:88-133): identical arguments/returns.
+        Returns (H, X_mov_transformed, rbp, distance_residuals)."""
+        self._check_arguments(distance_weights, rbp_observed_values, rbp_observation_weights)
+        t_start = time.time()
+        pc1, pc2 = self.pc1, self.pc2
+        ctx = backend.get_context()
+        sharded = dist.is_distributed()
+
+        if debug_dirpath:
+            _log.info(f'Write debug files to directory "{debug_dirpath}"')
+            Path(debug_dirpath).mkdir(parents=True, exist_ok=True)
+
+        obs = np.array(rbp_observed_values, dtype=float)
+        obs[:3] = obs[:3] * np.pi / 180                       # degree -> rad (simpleicp.py:146-148)
+        ow = np.array(rbp_observation_weights, dtype=float)
+        H = H_from_params(obs)
+
+        # both clouds go to HBM once and stay there
+        X_fix = pc1.X
+        ctx.upload(_lib.FIX, X_fix)
+        X_mov = pc2.X
+        if sharded:
+            rank, world = dist.rank_world()
+            lo, hi = dist.shard_bounds(len(X_mov), rank, world)
+            ctx.upload(_lib.MOV, X_mov[lo:hi], index_base=lo)
+            ctx.set_exchange(dist.make_exchange(ctx.device), rank, world, gn_shard=correspondences >= 262144)
+        else:
+            ctx.upload(_lib.MOV, X_mov)
+            ctx.set_exchange(None, 0, 1)
+
+        if np.isfinite(max_overlap_distance):
+            _log.info("Consider partial overlap of point clouds ...")
+            cur = pc1.idx_selected
+            if len(cur):
+                idx = self._nn_in_movable(ctx, X_fix[cur], H, float(max_overlap_distance), sharded)
+                pc1.idx_selected = cur[idx >= 0]
+            if not pc1.num_selected_points > 0:
+                raise SimpleICPException(
+                    "Point clouds do not overlap within max_overlap_distance = "
+                    f"{max_overlap_distance:.5f}! Consider increasing the value of "
+                    "max_overlap_distance."
+                )
+
+        _log.info("Select points for correspondences in fixed point cloud ...")
+        pc1.select_n_points(correspondences)
+        selected_orig = pc1["selected"].to_numpy().copy()
+        sel = pc1.idx_selected
+
+        if not set(_ATTRS).issubset(pc1.columns):
+            _log.info("Estimate normals of selected points ...")
+            pc1.estimate_normals(neighbors, _ctx=ctx, _uploaded=True)
+        normals = np.column_stack([np.asarray(pc1[c].to_numpy(), dtype=np.float32)[sel] for c in _ATTRS[:3]])
+        planarity = np.asarray(pc1["planarity"].to_numpy(), dtype=np.float32)[sel]
+        ctx.icp_setup(sel, normals, planarity)
+
+        x = obs.copy()
+        w = distance_weights
+        stats = []            # (n, mean, std) of the residuals per iteration
+        R = None
+        it = -1
+        _log.info("Start iterations ...")
+        for it in range(0, max_iterations):
+            if debug_dirpath:
+                if it == 0:
+                    pc1.write_xyz(Path(debug_dirpath).joinpath(f"iteration{it:03d}_preoptim_pcfix.xyz"))
+                self._write_cloud(Path(debug_dirpath).joinpath(f"iteration{it:03d}_preoptim_pcmov.xyz"), X_mov, H)
+            x_start = x.copy()
+            try:
+                R = ctx.icp_iterate(x, obs, ow, min_planarity, w)
+            except _lib.BackendError as e:
+                if e.code == _lib.ERR_TOO_FEW:
+                    raise SimpleICPException(str(e)) from None
+                raise
+            if debug_dirpath:
+                self._write_correspondences(ctx, Path(debug_dirpath).joinpath(
+                    f"iteration{it:03d}_preoptim_correspondences.xyz"), X_fix, X_mov, sel, H)
+            if w is None:
+                w = R.weight_used                            # frozen after iteration 0 (simpleicp.py:229-234)
+            x = np.array(R.x[:])
+            H = np.array(R.H[:]).reshape(4, 4)
+            stats.append((int(R.n_kept), R.res_mean, R.res_std))
+            pc1["selected"] = selected_orig                  # simpleicp.py:254
+
+            if it > 0 and self._converged(stats[it], stats[it - 1], min_change):
+                _log.info("Convergence criteria fulfilled -> stop iteration!")
+                break
+
+            if it == 0:
+                _log.info(f"{'Iteration':>9s} | {'correspondences':>15s} | {'mean(residuals)':>15s} | "
+                          f"{'std(residuals)':>15s}")
+                _log.info(f"{'orig:0':>9s} | {int(R.n_kept):15d} | {R.dist_mean:15.4f} | {R.dist_std:15.4f}")
+            _log.info(f"{it + 1:9d} | {stats[it][0]:15d} | {stats[it][1]:15.4f} | {stats[it][2]:15.4f}")
+
+        rbp = RigidBodyParameters()
+        rbp.set_parameter_attributes_from_list("observed_value", list(obs))
+        rbp.set_parameter_attributes_from_list("observation_weight", list(ow))
+        residuals = np.empty(0)
+        if R is not None:
+            rbp.set_parameter_attributes_from_list("initial_value", list(x_start))
+            rbp.set_parameter_attributes_from_list("estimated_value", list(x))
+            sigma = ctx.icp_uncertainties()
+            for name, s, free in zip(("alpha1", "alpha2", "alpha3", "tx", "ty", "tz"), sigma, np.isfinite(ow)):
+                if free:
+                    getattr(rbp, name).estimated_uncertainty = float(s)
+            _, _, keep, res = ctx.icp_state(pc2_idx=False, dist=False)
+            residuals = res[keep]
+
+        self._log_result(H, rbp)
+
+        # final transformation of the caller's movable cloud (simpleicp.py:316)
+        if sharded:
+            ctx.upload(_lib.MOV, X_mov)
+        pc2.transform_by_H(H, _ctx=ctx, _slot=_lib.MOV)
+        if debug_dirpath:
+            pc2.write_xyz(Path(debug_dirpath).joinpath(f"iteration{it:03d}_postoptim_pcmov.xyz"))
+
+        self.last_run_info = {"iterations": it + 1, "stats": stats, "seconds": time.time() - t_start}
+        _log.info(f"Finished in {time.time() - t_start:.3f} seconds!")
+        return H, pc2.X, rbp, residuals
+
+    # --------------------------------------------------------------------------------------
+    def _nn_in_movable(self, ctx, queries, H, max_dist, sharded):
+        """1-NN index (or -1) of `queries` in the H-transformed movable cloud (all shards)."""
+        idx, d2 = ctx.knn(_lib.MOV, queries, k=1, H=H, max_dist=max_dist)
+        if not sharded:
+            return idx[:, 0]
+        import torch
+        import torch.distributed as td
+        dev = torch.device("cuda", ctx.device) if td.get_backend() == "nccl" else torch.device("cpu")
+        t_d2 = torch.from_numpy(d2[:, 0].copy()).to(dev)
+        t_idx = torch.from_numpy(idx[:, 0].copy()).to(dev)
+        t_xyz = torch.zeros((len(queries), 3), dtype=torch.float64, device=dev)
+        dist.exchange_best_match(t_d2, t_idx, t_xyz)
+        return t_idx.cpu().numpy()
+
+    @staticmethod
+    def _converged(new, old, min_change) -> bool:
+        """simpleicp.py:356-379 on (n, mean, std) triples."""
+        return (_percent_change(new[1], old[1]) < min_change) and (_percent_change(new[2], old[2]) < min_change)
+
+    @staticmethod
+    def _write_cloud(file, X, H):
+        Xh = np.column_stack((X, np.ones(len(X))))
+        Xt = (H @ Xh.T).T[:, :3]
+        np.savetxt(file, Xt, fmt="%.3f", delimiter=" ", header="//X Y Z", comments="")
+
+    @staticmethod
+    def _write_correspondences(ctx, file, X_fix, X_mov, sel, H):
+        """corrpts.py:213-237: kept correspondences, movable points in the pre-optimisation pose."""
+        idx, d, keep, _ = ctx.icp_state(residual=False)
+        p2 = X_mov[idx[keep]]
+        p2 = (H @ np.column_stack((p2, np.ones(len(p2)))).T).T[:, :3]
+        np.savetxt(file, np.column_stack((X_fix[sel[keep]], p2, d[keep])), delimiter=" ",
+                   header="X1 Y1 Z1 X2 Y2 Z2 point_to_plane_distance", comments="//")
+
+    @staticmethod
+    def _log_result(H, rbp):
+        _log.info("Estimated transformation matrix H:")
+        for r in range(4):
+            _log.info(f"[{H[r, 0]:12.6f} {H[r, 1]:12.6f} {H[r, 2]:12.6f} {H[r, 3]:12.6f}]")
+        _log.info("... which corresponds to the following rigid-body transformation parameters:")
+        _log.info(f"{'parameter':>9s} | {'est.value':>15s} | {'est.uncertainty':>15s} | {'obs.value':>15s} | "
+                  f"{'obs.weight':>15s}")
+        for f in fields(rbp):
+            p = getattr(rbp, f.name)
+            _log.info(f"{f.name:>9s} | {p.estimated_value_scaled:15.6f} | {p.estimated_uncertainty_scaled:15.6f} | "
+                      f"{p.observed_value_scaled:15.6f} | {p.observation_weight:15.3e}")
+        _log.info("(Unit of est.value, est.uncertainty, and obs.value for alpha1/2/3 is degree)")
+
+    @staticmethod
+    def _check_arguments(distance_weights, rbp_observed_values, rbp_observation_weights):
+        """simpleicp.py:327-353 -- same checks, same messages."""
+        if distance_weights is not None and distance_weights <= 0:
+            raise SimpleICPException("distance_weights must be > 0.")
+        if len(rbp_observed_values) != 6:
+            raise SimpleICPException("rbp_observed_values must have exactly 6 elements.")
+        if len(rbp_observation_weights) != 6:
+            raise SimpleICPException("rbp_observation_weights must have exactly 6 elements.")
+        if not all(w >= 0 for w in rbp_observation_weights):
+            raise SimpleICPException("All elements of rbp_observation_weights must be >= 0.")
+        if not any(np.isfinite(rbp_observation_weights)):
+            raise SimpleICPException("At least one element in rbp_observation_weights must be finite.")

@@ -1,0 +1,167 @@
+"""Parity of the HIP kernels (through the C ABI) against the CPU oracle.  GPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from simpleicp_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _H(seed=0):
+    rng = np.random.default_rng(seed)
+    x = np.concatenate((rng.uniform(-0.3, 0.3, 3), rng.uniform(-1, 1, 3)))
+    return orc.params_to_H(x)
+
+
+@pytest.mark.parametrize("n,q", [(1, 1), (5, 3), (1000, 7), (1024, 1024), (1025, 1025), (50_000, 1000), (333_333, 2500)])
+def test_knn1_bit_exact_random(ctx, n, q):
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(n + q)
+    P = rng.uniform(-50, 50, (n, 3))
+    Qp = rng.uniform(-50, 50, (q, 3))
+    ctx.upload(_lib.MOV, P)
+    for H in (None, _H(1)):
+        idx, d2 = ctx.knn(_lib.MOV, Qp, k=1, H=H)
+        ridx, rd2 = orc.knn(P, Qp, k=1, H=H)
+        assert np.array_equal(idx, ridx)
+        assert np.array_equal(d2, rd2)          # contract (T)+(D): bit-exact squared distances
+
+
+def test_knn1_ties_lowest_index(ctx):
+    """Quantised coordinates + exact duplicates: lexicographic (d2, idx) must hold."""
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(5)
+    P = np.round(rng.uniform(-3, 3, (40_000, 3)), 1)
+    P[20_000:] = P[:20_000]                      # every point twice
+    Qp = np.round(rng.uniform(-3, 3, (900, 3)), 1)
+    ctx.upload(_lib.MOV, P)
+    idx, d2 = ctx.knn(_lib.MOV, Qp, k=1)
+    ridx, rd2 = orc.knn(P, Qp, k=1)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+    assert np.all(idx < 20_000)
+
+
+def test_knn1_upper_bound_strict(ctx):
+    """select_in_range semantics (pointcloud.py:163-167): d < max_range strictly."""
+    from simpleicp_amd import _lib
+    P = np.array([[0.0, 0, 0], [3.0, 0, 0], [0, 4.0, 0]])
+    Qp = np.array([[1.0, 0, 0], [3.0, 4.0, 0], [100.0, 0, 0]])
+    ctx.upload(_lib.MOV, P)
+    idx, d2 = ctx.knn(_lib.MOV, Qp, k=1, max_dist=3.0)
+    ridx, rd2 = orc.knn(P, Qp, k=1, max_dist=3.0)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+    assert idx[:, 0].tolist() == [0, -1, -1]     # query 1 is at distance exactly 3 -> excluded
+    assert np.isinf(d2[1, 0])
+
+
+@pytest.mark.parametrize("n,q,k", [(20, 5, 2), (5000, 300, 10), (5000, 300, 16), (30_000, 1100, 40),
+                                   (3000, 64, 70), (100, 3, 100), (50, 4, 60)])
+def test_knnk_bit_exact(ctx, n, q, k):
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(k)
+    P = np.round(rng.uniform(-5, 5, (n, 3)), 2)   # quantised: plenty of exact ties
+    Qp = P[rng.choice(n, q, replace=False)]
+    ctx.upload(_lib.FIX, P)
+    idx, d2 = ctx.knn(_lib.FIX, Qp, k=k)
+    ridx, rd2 = orc.knn(P, Qp, k=k)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(d2, rd2)
+
+
+def test_transform_bit_exact(ctx):
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(2)
+    P = rng.uniform(-500, 500, (100_001, 3))
+    H = _H(3)
+    ctx.upload(_lib.MOV, P)
+    ctx.transform(_lib.MOV, H)
+    got = ctx.download(_lib.MOV)
+    assert np.array_equal(got, orc.transform(H, P))
+    # and that is numpy's own `H @ Xh.T` (pointcloud.py:205-217) on this image
+    Xh = np.column_stack((P, np.ones(len(P))))
+    ref = (H @ Xh.T).T
+    assert np.array_equal(got, ref[:, :3] / ref[:, 3:4])
+
+
+@pytest.mark.parametrize("name", ["dragon", "webots", "bunny"])
+def test_normals_vs_oracle(ctx, name, clouds):
+    from simpleicp_amd import _lib
+    g, files, kw = load_golden(name)
+    Xf = clouds(files[0])
+    k = kw.get("neighbors", 10)
+    sel = g["sel_idx"]
+    ctx.upload(_lib.FIX, Xf)
+    nv, pl, nn = ctx.estimate_normals(_lib.FIX, sel, k, want_nn=True)
+    rnn, _ = orc.knn(Xf, Xf[sel], k=k)
+    assert np.array_equal(nn, rnn)
+    rnv, rpl = orc.normals(Xf, rnn)
+    # same operation order on both sides; allow 1 ulp(float32) for the fp64 sqrt/div paths
+    assert np.abs(nv - rnv).max() <= 2e-7
+    assert np.abs(pl - rpl).max() <= 2e-6
+    # and against the reference's normals (LAPACK) up to sign, where neighbour sets are untied
+    dot = np.abs(np.sum(nv.astype(np.float64) * g["normals"], axis=1))
+    assert np.mean(dot > 1 - 1e-5) > (0.70 if name == "webots" else 0.995)
+
+
+@pytest.mark.parametrize("name", ["dragon", "bunny", "multisensor", "webots", "bunny_obs"])
+def test_iteration_vs_oracle(ctx, name, clouds):
+    """Whole iterations (match -> reject -> LM on fused reductions) against the oracle, fed with
+    the reference's normals; indices / masks bit-exact, parameters to 1e-11."""
+    from simpleicp_amd import _lib
+    g, files, kw = load_golden(name)
+    Xf, Xm = clouds(files[0]), clouds(files[1])
+    obs = np.array(kw.get("rbp_observed_values", (0.,) * 6), float)
+    obs[:3] *= np.pi / 180
+    ow = np.array(kw.get("rbp_observation_weights", (0.,) * 6), float)
+    sel = g["sel_idx"]
+    ctx.upload(_lib.FIX, Xf)
+    ctx.upload(_lib.MOV, Xm)
+    ctx.icp_setup(sel, g["normals"], g["planarity"])
+    x = obs.copy()
+    w = kw.get("distance_weights", 1)
+    for it in range(min(int(g["iterations"]), 6)):
+        R = ctx.icp_iterate(x, obs, ow, kw.get("min_planarity", 0.3), w)
+        o = orc.icp_iteration(Xm, Xf[sel], g["normals"], g["planarity"], x, x, w, obs, ow, kw.get("min_planarity", 0.3))
+        idx, dist, keep, resid = ctx.icp_state()
+        assert np.array_equal(idx, o["nn"])
+        assert np.array_equal(dist, o["dist"])               # contract (P): bit-exact
+        assert np.array_equal(keep, o["keep"])
+        assert R.n_kept == o["n"] and R.median == o["median"] and R.mad == o["mad"]
+        xg = np.array(R.x[:])
+        assert np.abs(xg - o["x"]).max() < 1e-11
+        assert np.allclose(resid[keep], orc.residuals(xg, Xf[sel], g["normals"], Xm[idx], keep), rtol=0, atol=1e-15)
+        assert abs(R.res_mean - resid[keep].mean()) < 1e-15 and abs(R.res_std - resid[keep].std()) < 1e-14
+        assert abs(R.dist_std - dist[keep].std()) < 1e-14
+        ne = ctx.icp_normal_equations(xg)
+        one = orc.normal_equations(xg, Xf[sel], g["normals"], Xm[idx], keep)
+        assert np.allclose(ne, one, rtol=1e-12, atol=1e-13 * np.abs(one).max())   # J^T r ~ 0 at the optimum
+        w = R.weight_used if w is None else w
+        x = xg
+    s = ctx.icp_uncertainties()
+    so = orc.uncertainties(x, w, obs, ow, Xf[sel], g["normals"], Xm[idx], keep)
+    free = np.isfinite(ow)
+    assert np.allclose(s[free], so[free], rtol=1e-9) and np.all(np.isnan(s[~free]))
+
+
+def test_too_few_correspondences(ctx):
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(0)
+    P = rng.uniform(0, 1, (100, 3))
+    ctx.upload(_lib.FIX, P)
+    ctx.upload(_lib.MOV, P + 0.01)
+    sel = np.arange(10)
+    pl = np.full(10, np.nan, np.float32)
+    pl[:4] = 1.0
+    ctx.icp_setup(sel, np.tile(np.float32([0, 0, 1]), (10, 1)), pl)
+    with pytest.raises(_lib.BackendError) as e:
+        ctx.icp_iterate(np.zeros(6), np.zeros(6), np.zeros(6))
+    assert e.value.code == _lib.ERR_TOO_FEW and "Too few correspondences" in str(e.value)

@@ -1,0 +1,107 @@
+"""End-to-end: simpleicp_amd.SimpleICP.run on the bundled datasets against fixtures of the
+unmodified reference (tests/golden, made by oracle/make_golden.py).  GPU only."""
+import io
+import logging
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN_CASES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(name, clouds, inject_normals, verbose=False):
+    from simpleicp_amd import PointCloud, SimpleICP
+    g, files, kw = load_golden(name)
+    pc_fix = PointCloud(clouds(files[0]), columns=["x", "y", "z"])
+    pc_mov = PointCloud(clouds(files[1]).copy(), columns=["x", "y", "z"])
+    if inject_normals:
+        # the reference's own bypass (simpleicp.py:176): precomputed attribute columns
+        sel = g["sel_idx"]
+        for j, c in enumerate(("nx", "ny", "nz")):
+            v = np.full(len(pc_fix), np.nan, np.float32)
+            v[sel] = g["normals"][:, j]
+            pc_fix[c] = pd.arrays.SparseArray(v)
+        v = np.full(len(pc_fix), np.nan, np.float32)
+        v[sel] = g["planarity"]
+        pc_fix["planarity"] = pd.arrays.SparseArray(v)
+    icp = SimpleICP(verbose=verbose)
+    icp.add_point_clouds(pc_fix, pc_mov)
+    out = icp.run(**kw)
+    return g, kw, icp, pc_fix, pc_mov, out
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_run_with_reference_normals(name, clouds):
+    """Identical inputs to the loop (the reference's normals): H must match the reference to
+    1e-7 absolute per entry (its own least_squares tolerance is 1e-8 relative), iteration count
+    and correspondence counts must be the reference's (cKDTree tie picks may flip <= 2)."""
+    g, kw, icp, pc_fix, pc_mov, (H, X, rbp, res) = _run(name, clouds, True)
+    tol = 2e-6 if name == "bunny_obs" else 1e-7
+    assert np.abs(H - g["H"]).max() < tol
+    assert icp.last_run_info["iterations"] == int(g["iterations"])
+    counts = np.array([s[0] for s in icp.last_run_info["stats"]])
+    assert np.abs(counts - g["counts"]).max() <= 2
+    x = np.array(rbp.get_parameter_attributes_as_list("estimated_value"))
+    assert np.abs(x - g["x"]).max() < tol
+    sig = np.array(rbp.get_parameter_attributes_as_list("estimated_uncertainty"))
+    free = np.isfinite(np.array(kw.get("rbp_observation_weights", (0.,) * 6), float))
+    assert np.allclose(sig[free], g["sigma"][free], rtol=2e-3) and np.all(np.isnan(sig[~free]))
+    assert abs(len(res) - len(g["residuals"])) <= 2
+    assert abs(res.std() - g["residuals"].std()) < 1e-6
+    # side effects (simpleicp.py:316, :254): movable cloud transformed in place, selection kept
+    assert X.shape == (len(pc_mov), 3) and np.array_equal(X, pc_mov.X)
+    assert np.abs(X[:64] - g["X_mov_transformed_head"]).max() < 1e-5
+    assert np.abs(X.sum(axis=0) - g["X_mov_transformed_sum"]).max() < 1e-4 * len(X)
+    assert np.array_equal(pc_fix.idx_selected, g["sel_idx"])
+
+
+@pytest.mark.parametrize("name", ["dragon", "bunny", "multisensor", "webots"])
+def test_run_own_normals(name, clouds):
+    """Everything on the GPU including normals (sign convention differs from LAPACK's):
+    stated end-to-end tolerance 1e-4 absolute per H entry."""
+    g, kw, icp, pc_fix, pc_mov, (H, X, rbp, res) = _run(name, clouds, False)
+    assert np.abs(H - g["H"]).max() < 1e-4
+    assert np.array_equal(pc_fix.idx_selected, g["sel_idx"])          # overlap + sub-sampling parity
+    for c in ("nx", "ny", "nz", "planarity"):
+        col = pc_fix[c].to_numpy()
+        assert col.dtype == np.float32 and np.isnan(col).sum() == len(pc_fix) - len(g["sel_idx"])
+    assert abs(icp.last_run_info["iterations"] - int(g["iterations"])) <= 2
+
+
+def test_log_lines_match_reference_format(clouds):
+    """Same lines as the reference prints (python/README.md:44-75); numbers to printed precision."""
+    log = logging.getLogger("simpleicp_amd")
+    buf = io.StringIO()
+    h = logging.StreamHandler(buf)
+    h.setFormatter(logging.Formatter("%(message)s"))
+    log.addHandler(h)
+    log.setLevel(logging.INFO)
+    try:
+        g, kw, icp, *_ = _run("bunny", clouds, True)
+    finally:
+        log.removeHandler(h)
+    ours = buf.getvalue().splitlines()
+    ref = str(g["log"]).splitlines()
+    assert len(ours) == len(ref)
+    same = sum(a == b for a, b in zip(ours[:-1], ref[:-1]))
+    assert same >= len(ref) - 4                    # counts can differ by one on a tie flip
+    assert ours[-1].startswith("Finished in ") and ours[-1].endswith(" seconds!")
+    assert ours[4].split("|")[0] == ref[4].split("|")[0]
+
+
+def test_exceptions(clouds):
+    from simpleicp_amd import PointCloud, SimpleICP, SimpleICPException
+    X = clouds("bunny_part1")
+    icp = SimpleICP(verbose=False)
+    icp.add_point_clouds(PointCloud(X, columns=["x", "y", "z"]), PointCloud(X + 1000.0, columns=["x", "y", "z"]))
+    with pytest.raises(SimpleICPException, match="do not overlap"):
+        icp.run(max_overlap_distance=0.5)
+    with pytest.raises(SimpleICPException, match="distance_weights"):
+        icp.run(distance_weights=0)
+    with pytest.raises(SimpleICPException, match="exactly 6"):
+        icp.run(rbp_observed_values=(0, 0, 0))
+    with pytest.raises(SimpleICPException, match="finite"):
+        icp.run(rbp_observation_weights=(np.inf,) * 6)
