@@ -1,0 +1,91 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the exchange step in simpleicp_amd/dist.py --
+the same functions the RCCL path calls on device tensors.  Local shard results come from the
+CPU oracle (tests may use it); the assertion is that sharded == unsharded, bit-exact."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import orc
+        from simpleicp_amd import dist
+
+        assert dist.is_distributed() and dist.rank_world() == (rank, world)
+        rng = np.random.default_rng(7)                       # same data on every rank
+        n, q = 30_001, 700
+        Xm = np.round(rng.uniform(-5, 5, (n, 3)), 1)         # quantised -> exact ties across shards
+        Xm[n // 2:n // 2 + 200] = Xm[:200]                   # duplicates living in different shards
+        Qp = np.round(rng.uniform(-5, 5, (q, 3)), 1)
+        H = orc.params_to_H(np.array([0.1, -0.2, 0.05, 0.3, 0.1, -0.2]))
+        lo, hi = dist.shard_bounds(n, rank, world)
+
+        for max_dist in (np.inf, 0.15):
+            idx, d2 = orc.knn(Xm[lo:hi], Qp, k=1, H=H, max_dist=max_dist, idx_base=lo)
+            idx, d2 = idx[:, 0].copy(), d2[:, 0].copy()
+            xyz = np.where((idx >= 0)[:, None], Xm[np.maximum(idx, 0)], 0.0)
+            t_d2, t_idx, t_xyz = torch.from_numpy(d2), torch.from_numpy(idx), torch.from_numpy(xyz)
+            dist.exchange_best_match(t_d2, t_idx, t_xyz)
+            fidx, fd2 = orc.knn(Xm, Qp, k=1, H=H, max_dist=max_dist)
+            assert np.array_equal(t_idx.numpy(), fidx[:, 0])
+            assert np.array_equal(t_d2.numpy(), fd2[:, 0])
+            ok = fidx[:, 0] >= 0
+            assert np.array_equal(t_xyz.numpy()[ok], Xm[fidx[ok, 0]]) and np.all(t_xyz.numpy()[~ok] == 0)
+            if np.isfinite(max_dist):
+                assert (~ok).any() and ok.any()
+
+        # sharded 6x6 normal-equation reduction + SUM exchange == unsharded (to rounding)
+        p1 = rng.uniform(-5, 5, (q, 3))
+        n1 = rng.normal(size=(q, 3)); n1 = (n1 / np.linalg.norm(n1, axis=1, keepdims=True)).astype(np.float32)
+        p2 = p1 + rng.normal(0, 0.05, (q, 3))
+        keep = rng.uniform(size=q) < 0.8
+        x = np.array([0.01, 0.02, -0.01, 0.1, 0.0, -0.1])
+        per = (q + world - 1) // world
+        a, b = min(q, per * rank), min(q, per * rank + per)
+        part = orc.normal_equations(x, p1[a:b], n1[a:b], p2[a:b], keep[a:b])
+        t = torch.from_numpy(part.copy())
+        dist.allreduce_sum(t)
+        full = orc.normal_equations(x, p1, n1, p2, keep)
+        assert np.allclose(t.numpy(), full, rtol=1e-13, atol=1e-12)
+        assert t.numpy()[29] == keep.sum()
+        Path(tmp, f"ok{rank}").write_text("ok")
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_world(world, tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_shard_bounds_partition():
+    sys.path.insert(0, str(ROOT))
+    from simpleicp_amd.dist import shard_bounds
+    for n in (0, 1, 7, 8, 10_000_001):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1

@@ -66,8 +66,8 @@ def test_run_own_normals(name, clouds):
     assert np.abs(H - g["H"]).max() < 1e-4
     assert np.array_equal(pc_fix.idx_selected, g["sel_idx"])          # overlap + sub-sampling parity
     for c in ("nx", "ny", "nz", "planarity"):
-        col = pc_fix[c].to_numpy()
-        assert col.dtype == np.float32 and np.isnan(col).sum() == len(pc_fix) - len(g["sel_idx"])
+        assert str(pc_fix[c].dtype) == "Sparse[float32, nan]"           # pointcloud.py:180-183,200-203
+        assert np.isnan(pc_fix[c].to_numpy()).sum() == len(pc_fix) - len(g["sel_idx"])
     assert abs(icp.last_run_info["iterations"] - int(g["iterations"])) <= 2
 
 

@@ -1,0 +1,152 @@
+"""CPU-side checks: C-ABI surface, loud failure without a GPU, host mirror of the reference API."""
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import ROOT, has_gpu
+
+
+def _declared():
+    text = (ROOT / "include" / "simpleicp_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sicp_[A-Za-z0-9_]+)\s*\(", text)) - {"sicp_exchange_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    """hipcc cross-compiles without a GPU: the .so must load here and export the whole header."""
+    from simpleicp_amd import _lib
+    L = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/simpleicp_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == names
+    assert L.sicp_abi_version() == 1
+
+
+def test_params_to_H_matches_reference_convention():
+    """mathutils.py:39-68,81-93 (host-only entry point, no device needed)."""
+    from oracle import orc, ref_port
+    from simpleicp_amd import _lib
+    from simpleicp_amd.rbp import H_from_params
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        x = np.concatenate((rng.uniform(-np.pi, np.pi, 3), rng.uniform(-10, 10, 3)))
+        H = _lib.params_to_H(x)
+        assert np.array_equal(H, orc.params_to_H(x))
+        assert np.allclose(H, ref_port.params_to_H(x), rtol=0, atol=1e-15)
+        assert np.allclose(H, H_from_params(x), rtol=0, atol=1e-15)
+        assert np.allclose(H[:3, :3] @ H[:3, :3].T, np.eye(3), atol=1e-14)
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu():
+    """No silent CPU fallback: every compute entry point raises BackendError when no MI355X is visible."""
+    from simpleicp_amd import PointCloud, SimpleICP, _lib, backend
+    assert _lib.device_count() == 0
+    with pytest.raises(_lib.BackendError) as e:
+        _lib.Context(0)
+    assert e.value.code == _lib.ERR_NO_DEVICE and "no CPU path" in str(e.value)
+    backend.reset_context()
+    X = np.random.default_rng(0).uniform(0, 1, (50, 3))
+    pc = PointCloud(X, columns=["x", "y", "z"])
+    for call in (lambda: pc.estimate_normals(5), lambda: pc.transform_by_H(np.eye(4)),
+                 lambda: pc.select_in_range(X, 0.1)):
+        with pytest.raises(_lib.BackendError):
+            call()
+    icp = SimpleICP(verbose=False)
+    icp.add_point_clouds(pc, PointCloud(X.copy(), columns=["x", "y", "z"]))
+    with pytest.raises(_lib.BackendError):
+        icp.run()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under simpleicp_amd/ may reference it."""
+    for f in (ROOT / "simpleicp_amd").rglob("*"):
+        if f.suffix in (".py", ".cpp", ".hip", ".h"):
+            t = f.read_text()
+            assert "import oracle" not in t and "from oracle" not in t and "libsicp_oracle" not in t, f
+            assert "orc_" not in t.replace("sicp_oracle.c:orc_normals", ""), f   # a comment cites the oracle twin
+    code = "import sys; sys.path.insert(0, %r); import simpleicp_amd; assert not any(m.startswith('oracle') for m in sys.modules)" % str(ROOT)
+    subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def test_pointcloud_mirror_of_reference_api():
+    """pointcloud.py:15-147 behaviours that need no device."""
+    from simpleicp_amd import PointCloud, PointCloudException
+    X = np.arange(30, dtype=float).reshape(10, 3)
+    pc = PointCloud(X, columns=["x", "y", "z"])
+    assert isinstance(pc, pd.DataFrame) and pc.num_points == 10 and pc.num_selected_points == 10
+    assert pc["selected"].dtype == bool
+    assert np.array_equal(pc.X, X) and np.array_equal(pc.x, X[:, 0]) and np.array_equal(pc.z, X[:, 2])
+    with pytest.raises(PointCloudException, match='Column "z" is missing'):
+        PointCloud(X[:, :2], columns=["x", "y"])
+    pc.select_n_points(4)                                   # round-half-even of linspace(0, 9, 4) = 0 3 6 9
+    assert pc.idx_selected.tolist() == [0, 3, 6, 9]
+    assert np.array_equal(pc.X_selected, X[[0, 3, 6, 9]]) and np.array_equal(pc.y_selected, X[[0, 3, 6, 9], 1])
+    pc.select_by_indices([3, 4, 9])
+    assert pc.idx_selected.tolist() == [3, 9]
+    pc.select_n_points(5)                                   # fewer selected than n: untouched
+    assert pc.idx_selected.tolist() == [3, 9]
+    pc.unselect_all_points()
+    assert pc.num_selected_points == 0
+    pc.select_all_points()
+    pc.idx_selected = [1, 2]
+    assert pc.idx_selected.tolist() == [1, 2]
+    # half-to-even rounding case: linspace(0, 4, 3) -> 0 2 4 ; linspace(0,5,3) -> 0 2.5->2 5
+    pc2 = PointCloud(np.zeros((6, 3)), columns=["x", "y", "z"])
+    pc2.select_n_points(3)
+    assert pc2.idx_selected.tolist() == [0, 2, 5]
+
+
+def test_select_n_points_matches_reference_on_golden(clouds):
+    from conftest import load_golden
+    from simpleicp_amd import PointCloud
+    g, files, kw = load_golden("dragon")
+    pc = PointCloud(clouds(files[0]), columns=["x", "y", "z"])
+    pc.select_n_points(1000)
+    assert np.array_equal(pc.idx_selected, g["sel_idx"])
+
+
+def test_write_xyz_format(tmp_path):
+    from simpleicp_amd import PointCloud
+    pc = PointCloud(np.array([[1.23456, 2.0, -3.5], [0.0004, 0.0005, 10]]), columns=["x", "y", "z"])
+    pc.write_xyz(tmp_path / "a.xyz")
+    assert (tmp_path / "a.xyz").read_text().splitlines() == ["//X Y Z", "1.235 2.000 -3.500", "0.000 0.001 10.000"]
+
+
+def test_rigid_body_parameters_mirror():
+    """optimization.py:291-382."""
+    from simpleicp_amd import RigidBodyParameters
+    rbp = RigidBodyParameters()
+    assert np.isnan(rbp.alpha1.estimated_value) and rbp.tx.scale_for_logging == 1
+    rbp.set_parameter_attributes_from_list("estimated_value", [0.1, 0.2, 0.3, 1, 2, 3])
+    assert rbp.get_parameter_attributes_as_list("estimated_value") == [0.1, 0.2, 0.3, 1, 2, 3]
+    assert np.isclose(rbp.alpha3.estimated_value_scaled, np.degrees(0.3)) and rbp.tz.estimated_value_scaled == 3
+    H = rbp.H
+    assert H.shape == (4, 4) and np.array_equal(H[3], [0, 0, 0, 1]) and np.array_equal(H[:3, 3], [1, 2, 3])
+    # R = Rx(a1) Ry(a2) Rz(a3) (README.md:96-100)
+    def rx(a): return np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    def ry(a): return np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    def rz(a): return np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    assert np.allclose(H[:3, :3], rx(0.1) @ ry(0.2) @ rz(0.3), atol=1e-15)
+    from simpleicp_amd.rbp import euler_from_rotation
+    assert np.allclose(euler_from_rotation(H[:3, :3]), [0.1, 0.2, 0.3], atol=1e-15)
+
+
+def test_argument_checks_need_no_gpu():
+    """simpleicp.py:327-353: same exceptions, raised before any device work."""
+    from simpleicp_amd import SimpleICP, SimpleICPException
+    icp = SimpleICP(verbose=False)
+    for kw, msg in [({"distance_weights": -1}, "distance_weights must be > 0."),
+                    ({"rbp_observed_values": (0,) * 5}, "rbp_observed_values must have exactly 6 elements."),
+                    ({"rbp_observation_weights": (0,) * 7}, "rbp_observation_weights must have exactly 6 elements."),
+                    ({"rbp_observation_weights": (0, 0, -1, 0, 0, 0)}, "must be >= 0"),
+                    ({"rbp_observation_weights": (np.inf,) * 6}, "At least one element")]:
+        with pytest.raises(SimpleICPException, match=msg):
+            icp.run(**kw)
