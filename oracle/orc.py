@@ -168,3 +168,40 @@ def icp_iteration(X_mov, p1, n1, planarity, x_prev, x0, w, obs, ow, min_planarit
     x, steps = solve(x0, w, obs, ow, p1, n1, p2, keep)
     res = residuals(x, p1, n1, p2, keep)
     return dict(nn=nn, dist=dist, keep=keep, n=n, median=med, mad=mad, x=x, residuals=res, w=w, steps=steps)
+
+
+def run(X_fix, X_mov, correspondences=1000, neighbors=10, min_planarity=0.3, max_overlap_distance=np.inf,
+        min_change=1.0, max_iterations=100, distance_weights=1, rbp_observed_values=(0.,) * 6,
+        rbp_observation_weights=(0.,) * 6, normals=None, planarity=None):
+    """Whole simpleicp.py:135-324 loop on the oracle primitives (deterministic brute-force kNN,
+    own normals with the fixed sign convention unless injected).  Returns a dict."""
+    X_fix, X_mov = _c(X_fix), _c(X_mov)
+    obs = np.array(rbp_observed_values, float)
+    obs[:3] *= np.pi / 180
+    ow = np.array(rbp_observation_weights, float)
+    sel = np.arange(len(X_fix))
+    if np.isfinite(max_overlap_distance):
+        idx, _ = knn(X_mov, X_fix[sel], k=1, H=params_to_H(obs), max_dist=max_overlap_distance)
+        sel = sel[idx[:, 0] >= 0]
+    pos = select_n_points(len(sel), correspondences)
+    if pos is not None:
+        sel = np.unique(sel[pos])
+    if normals is None:
+        nn, _ = knn(X_fix, X_fix[sel], k=neighbors)
+        normals, planarity = _normals(X_fix, nn)
+    x, w, stats, r = obs.copy(), distance_weights, [], None
+    for it in range(max_iterations):
+        r = icp_iteration(X_mov, X_fix[sel], normals, planarity, x, x, w, obs, ow, min_planarity)
+        w, x = r["w"], r["x"]
+        stats.append((r["n"], r["residuals"].mean(), r["residuals"].std()))
+        if it > 0:
+            def ch(a, b):
+                return (0.0 if a == 0 else np.inf) if b == 0 else abs((a - b) / b * 100)
+            if ch(stats[it][1], stats[it - 1][1]) < min_change and ch(stats[it][2], stats[it - 1][2]) < min_change:
+                break
+    sigma = uncertainties(x, w, obs, ow, X_fix[sel], normals, X_mov[r["nn"]], r["keep"])
+    return dict(H=params_to_H(x), x=x, sigma=sigma, sel=sel, normals=normals, planarity=planarity,
+                iterations=len(stats), stats=stats, residuals=r["residuals"])
+
+
+_normals = normals

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -66,6 +67,7 @@ struct DevBuf {
 
 struct Cloud {
     int64_t n = 0, npad = 0, idx_base = 0;
+    double rmax = 0.0;    // largest point norm (error bound of the filtered scan)
     DevBuf<double> xyz;   // x[npad] | y[npad] | z[npad]
     const double *x() const { return xyz.p; }
     const double *y() const { return xyz.p + npad; }
@@ -164,6 +166,10 @@ struct sicp_ctx {
     DevBuf<int64_t> k_idx;
     DevBuf<double> floor_d2;
     DevBuf<uint32_t> floor_idx;
+    DevBuf<double> bound;          // per-query upper bound of the NN distance (filtered scan)
+    int fs_blocks_per_cu[2] = {0, 0};   // occupancy of k_knn1_fscan<128>, <256>
+    int knn1_mode = 0;             // SICP_KNN1 = exact | filter: force one scan flavour (A/B + tests); 0 = auto
+    bool have_prev_match = false;  // m_p2 holds last iteration's winners (bound source)
     // ICP state (selected fixed points and per-iteration products)
     int64_t Q = 0, qpad = 0;
     DevBuf<double> q;              // qx|qy|qz [qpad]
@@ -247,23 +253,98 @@ int check_slot(sicp_ctx *c, int slot, bool need_data)
 
 void H16_to_Xf(const double H[16], Xf *o) { for (int i = 0; i < 12; ++i) o->m[i] = H[i]; }
 
-// 1-NN of SoA queries (qx|qy|qz with stride qpad) in a slot; results in device buffers
+// largest singular value of the 3x3 part of H (so |Hp| <= smax*|p| + |t| for ANY affine H)
+double smax3(const Xf &H)
+{
+    double A[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        A[i][j] = 0; for (int k = 0; k < 3; ++k) A[i][j] += H.m[4 * k + i] * H.m[4 * k + j];   // A = M^T M
+    }
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        const double off = std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
+            if (A[p][q] == 0.0) continue;
+            const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
+            const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c, apq = A[p][q];
+            A[p][p] -= t * apq; A[q][q] += t * apq; A[p][q] = A[q][p] = 0.0;
+            const int r = 3 - p - q;
+            const double arp = A[r][p], arq = A[r][q];
+            A[r][p] = A[p][r] = c * arp - sn * arq;
+            A[r][q] = A[q][r] = sn * arp + c * arq;
+        }
+    }
+    const double l = std::max(A[0][0], std::max(A[1][1], A[2][2]));
+    return std::sqrt(std::max(l, 0.0)) * (1.0 + 1e-9);
+}
+
+// 1-NN of SoA queries (qx|qy|qz with stride qpad) in a slot; results in device buffers.
+//   prev_p2 : optional (Q,3) coordinates of a cloud point per query (last iteration's match): its
+//             exact distance under H is the filter bound; otherwise a strided-subsample exact
+//             pre-pass provides one.  Either way the answer equals the plain brute-force scan's.
 int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, const Xf *H, double max_dist,
-                double *d2_out, int64_t *idx_out, double *p2_out)
+                const double *prev_p2, double *d2_out, int64_t *idx_out, double *p2_out)
 {
     Cloud &cl = c->cloud[slot];
-    int chunk_pts, nchunks;
-    const long qblocks = qpad / QPAD;
-    plan_chunks(c, cl.npad, qblocks, (size_t)qpad * 12, &chunk_pts, &nchunks);
-    CHK(c->part_d2.reserve((size_t)nchunks * qpad));
-    CHK(c->part_idx.reserve((size_t)nchunks * qpad));
+    const double max_d2 = max_dist * max_dist;
+    const long tiles = cl.npad / TILE_PTS;
+    const int cus = c->prop.multiProcessorCount;
+    double rmax_t = cl.rmax;
+    if (H) rmax_t = smax3(*H) * cl.rmax + std::sqrt(H->m[3] * H->m[3] + H->m[7] * H->m[7] + H->m[11] * H->m[11]);
+    rmax_t *= (1.0 + 1e-9);
+    const bool small = cl.n <= 262144;                       // launch-bound anyway: one exact pass
+    const bool filter_ok = std::isfinite(rmax_t) && rmax_t < 1e18;   // squares must fit float32
+    if (c->knn1_mode == 1 || (small && c->knn1_mode != 2) || !filter_ok) {
+        const long qblocks = (Q + KNN_BLOCK * KNN1_R - 1) / (KNN_BLOCK * KNN1_R);
+        long want = std::max<long>(1, (8L * cus + qblocks - 1) / qblocks);
+        want = std::min(want, tiles);
+        const int tpc = (int)((tiles + want - 1) / want);
+        const int nchunks = (int)((tiles + tpc - 1) / tpc);
+        CHK(c->part_d2.reserve((size_t)nchunks * qpad));
+        CHK(c->part_idx.reserve((size_t)nchunks * qpad));
+        {
+            Timed t(c, SICP_K_KNN1);
+            launch_knn1_scan(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, (int)qpad, (int)qblocks, cl.x(), cl.y(),
+                             cl.z(), cl.npad, tpc, tpc, nchunks, H, c->part_d2.p, c->part_idx.p);
+        }
+        launch_knn1_reduce(c->stream, c->part_d2.p, c->part_idx.p, nchunks, (int)qpad, Q, max_d2, cl.idx_base, cl.x(),
+                           cl.y(), cl.z(), d2_out, idx_out, p2_out);
+        HIPCHK(hipGetLastError());
+        return SICP_OK;
+    }
+
+    // ---- bound ----
+    CHK(c->bound.reserve(qpad));
+    if (prev_p2) {
+        launch_bound_prev(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, prev_p2, Q, qpad, *H, c->bound.p);
+    } else {
+        const int step = 64;                                  // every 64th 1024-point tile: 1.6 % of the cloud
+        const long qblocks = (Q + KNN_BLOCK * KNN1_R - 1) / (KNN_BLOCK * KNN1_R);
+        const int nsub = (int)((tiles + step - 1) / step);
+        CHK(c->part_d2.reserve((size_t)nsub * qpad));
+        CHK(c->part_idx.reserve((size_t)nsub * qpad));
+        launch_knn1_scan(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, (int)qpad, (int)qblocks, cl.x(), cl.y(), cl.z(),
+                         cl.npad, step, 1, nsub, H, c->part_d2.p, c->part_idx.p);
+        launch_knn1_reduce(c->stream, c->part_d2.p, c->part_idx.p, nsub, (int)qpad, Q,
+                           std::numeric_limits<double>::infinity(), 0, cl.x(), cl.y(), cl.z(), c->bound.p, nullptr, nullptr);
+    }
+    // ---- filtered scan: fill the chip exactly once with resident blocks ----
+    const int blk = (Q > 1024) ? 256 : 128;                  // 8 queries per lane either way
+    int &bpc = c->fs_blocks_per_cu[blk == 256];
+    if (bpc == 0) bpc = fscan_blocks_per_cu(blk);
+    const long qblocks = (Q + blk * FS_R - 1) / (blk * FS_R);
+    const int ftiles = (int)(cl.npad / FS_TILE);
+    long nparts = std::max<long>(1, ((long)cus * bpc) / qblocks);
+    nparts = std::min<long>(nparts, ftiles);
+    CHK(c->part_d2.reserve((size_t)nparts * qpad));
+    CHK(c->part_idx.reserve((size_t)nparts * qpad));
     {
         Timed t(c, SICP_K_KNN1);
-        launch_knn1_scan(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, (int)qpad, cl.x(), cl.y(), cl.z(), cl.npad,
-                         chunk_pts, nchunks, H, c->part_d2.p, c->part_idx.p);
+        launch_knn1_fscan(c->stream, blk, qsoa, qsoa + qpad, qsoa + 2 * qpad, (int)qpad, (int)qblocks, c->bound.p, cl.x(),
+                          cl.y(), cl.z(), ftiles, (int)nparts, H, rmax_t, c->part_d2.p, c->part_idx.p);
     }
-    const double max_d2 = max_dist * max_dist;
-    launch_knn1_reduce(c->stream, c->part_d2.p, c->part_idx.p, nchunks, (int)qpad, Q, max_d2, cl.idx_base, cl.x(),
+    launch_knn1_reduce(c->stream, c->part_d2.p, c->part_idx.p, (int)nparts, (int)qpad, Q, max_d2, cl.idx_base, cl.x(),
                        cl.y(), cl.z(), d2_out, idx_out, p2_out);
     HIPCHK(hipGetLastError());
     return SICP_OK;
@@ -280,7 +361,7 @@ int knnk_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, in
         const int K = rem <= 8 ? 8 : rem <= 16 ? 16 : rem <= 32 ? 32 : 64;
         const int kout = rem < K ? rem : K;
         int chunk_pts, nchunks;
-        plan_chunks(c, cl.npad, qpad / KNN_BLOCK, (size_t)qpad * K * 12, &chunk_pts, &nchunks);
+        plan_chunks(c, cl.npad, (Q + KNN_BLOCK - 1) / KNN_BLOCK, (size_t)qpad * K * 12, &chunk_pts, &nchunks);
         CHK(c->part_d2.reserve((size_t)nchunks * qpad * K));
         CHK(c->part_idx.reserve((size_t)nchunks * qpad * K));
         const bool more = done + kout < k;
@@ -378,6 +459,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (rc == SICP_OK) rc = c->ticket.reserve(4);
     if (rc == SICP_OK && hipMemsetAsync(c->ticket.p, 0, 4 * sizeof(unsigned), c->stream) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
+    if (const char *e = std::getenv("SICP_KNN1")) c->knn1_mode = !std::strcmp(e, "exact") ? 1 : !std::strcmp(e, "filter") ? 2 : 0;
     *ctx_out = c;
     return SICP_OK;
 }
@@ -391,7 +473,7 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     for (auto &p : c->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &cl : c->cloud) cl.xyz.release();
     c->stage.release(); c->part_d2.release(); c->part_idx.release(); c->kq.release(); c->k_d2.release();
-    c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->q.release(); c->normals.release();
+    c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
     c->resid.release(); c->flag.release(); c->keep.release(); c->small.release(); c->ne_partial.release();
     c->ticket.release();
@@ -422,7 +504,16 @@ SICP_EXPORT int sicp_cloud_upload(sicp_ctx *c, int slot, const double *xyz, int6
     HIPCHK(hipMemcpyAsync(c->stage.p, xyz, (size_t)3 * n * sizeof(double), hipMemcpyDefault, c->stream));
     launch_aos_to_soa(c->stream, c->stage.p, n, cl.npad, cl.x(), cl.y(), cl.z());
     HIPCHK(hipGetLastError());
-    return sync(c);
+    // largest norm, for the filtered scan's rounding-error bound
+    unsigned long long *d_bits = (unsigned long long *)(c->small.p + 40);
+    HIPCHK(hipMemsetAsync(d_bits, 0, sizeof(unsigned long long), c->stream));
+    launch_max_norm2(c->stream, cl.x(), cl.y(), cl.z(), n, d_bits);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_small + 40, d_bits, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CHK(sync(c));
+    cl.rmax = std::sqrt(c->h_small[40]) * (1.0 + 1e-12);
+    if (slot == SICP_MOV) c->have_prev_match = false;
+    return SICP_OK;
 }
 
 SICP_EXPORT int sicp_cloud_size(sicp_ctx *c, int slot, int64_t *n_out)
@@ -442,6 +533,8 @@ SICP_EXPORT int sicp_cloud_transform(sicp_ctx *c, int slot, const double H[16])
     Cloud &cl = c->cloud[slot];
     launch_transform(c->stream, cl.x(), cl.y(), cl.z(), cl.n, X);
     HIPCHK(hipGetLastError());
+    cl.rmax = (smax3(X) * cl.rmax + std::sqrt(X.m[3] * X.m[3] + X.m[7] * X.m[7] + X.m[11] * X.m[11])) * (1.0 + 1e-9);
+    if (slot == SICP_MOV) c->have_prev_match = false;
     return sync(c);
 }
 
@@ -480,7 +573,7 @@ SICP_EXPORT int sicp_knn(sicp_ctx *c, int slot, const double *q_xyz, int64_t Q, 
     if (k == 1) {
         Xf X;
         if (H) H16_to_Xf(H, &X);
-        CHK(knn1_device(c, slot, c->kq.p, Q, qpad, H ? &X : nullptr, max_dist, c->k_d2.p, c->k_idx.p, nullptr));
+        CHK(knn1_device(c, slot, c->kq.p, Q, qpad, H ? &X : nullptr, max_dist, nullptr, c->k_d2.p, c->k_idx.p, nullptr));
     } else {
         CHK(knnk_device(c, slot, c->kq.p, Q, qpad, k, c->k_d2.p, c->k_idx.p));
     }
@@ -544,6 +637,7 @@ SICP_EXPORT int sicp_icp_setup(sicp_ctx *c, const int64_t *sel_idx, int64_t Q, c
     HIPCHK(hipMemcpyAsync(c->normals.p, normals, (size_t)3 * Q * sizeof(float), hipMemcpyDefault, c->stream));
     HIPCHK(hipMemcpyAsync(c->planarity.p, planarity, (size_t)Q * sizeof(float), hipMemcpyDefault, c->stream));
     c->have_iter = false;
+    c->have_prev_match = false;
     return sync(c);
 }
 
@@ -565,7 +659,9 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
     double H12[12];
     params_to_H12(P->x, H12);
     Xf X; for (int i = 0; i < 12; ++i) X.m[i] = H12[i];
-    CHK(knn1_device(c, SICP_MOV, c->q.p, Q, c->qpad, &X, std::numeric_limits<double>::infinity(), c->m_d2.p, c->m_idx.p, c->m_p2.p));
+    CHK(knn1_device(c, SICP_MOV, c->q.p, Q, c->qpad, &X, std::numeric_limits<double>::infinity(),
+                    c->have_prev_match ? c->m_p2.p : nullptr, c->m_d2.p, c->m_idx.p, c->m_p2.p));
+    c->have_prev_match = (c->world == 1);   // after an exchange idx -1 rows would carry zeros: keep it simple
     if (c->world > 1 && c->xfn) {
         CHK(sync(c));
         if (c->xfn(c->xuser, SICP_XCHG_BEST_MATCH, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q) != 0)

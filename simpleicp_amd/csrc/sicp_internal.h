@@ -11,7 +11,10 @@ struct Xf { double m[12]; };
 constexpr int    KNN_BLOCK = 256;     // lanes per workgroup of the scan kernels (4 waves, 1 per SIMD)
 constexpr int    KNN1_R    = 4;       // queries per lane in the 1-NN scan
 constexpr int    TILE_PTS  = 1024;    // cloud points staged in LDS per step (24 KiB)
-constexpr int    QPAD      = KNN_BLOCK * KNN1_R;   // query padding granule
+constexpr int    FS_TILE   = 512;     // points per LDS tile of the filtered scan (float4: 8 KiB, x2 buffers)
+constexpr int    FS_R      = 8;       // queries per lane of the filtered scan
+constexpr int    FS_G      = 8;       // points between two slow-path checks of the filtered scan
+constexpr int    QPAD      = 2048;    // query padding granule (covers R = 4 and R = 8 scan blocks)
 constexpr int    NE_BLOCK  = 256;
 constexpr int    NE_MAX_GRID = 1024;
 constexpr double SICP_PAD_COORD_V = 1.0e300;
@@ -23,10 +26,17 @@ void launch_transform(hipStream_t s, double *x, double *y, double *z, long n, co
 void launch_gather_queries(hipStream_t s, const double *x, const double *y, const double *z, const int64_t *sel,
                            long Q, long qpad, double *qx, double *qy, double *qz);
 void launch_aos_queries(hipStream_t s, const double *aos, long Q, long qpad, double *qx, double *qy, double *qz);
-void launch_knn1_scan(hipStream_t s, const double *qx, const double *qy, const double *qz, int qpad,
-                      const double *px, const double *py, const double *pz, long npad, int chunk_pts, int nchunks,
-                      const Xf *H, double *part_d2, uint32_t *part_idx);
-void launch_knn1_reduce(hipStream_t s, const double *part_d2, const uint32_t *part_idx, int nchunks, int qpad, long Q,
+void launch_knn1_scan(hipStream_t s, const double *qx, const double *qy, const double *qz, int qpad, int qblocks,
+                      const double *px, const double *py, const double *pz, long npad, int tile_step,
+                      int tiles_per_chunk, int nchunks, const Xf *H, double *part_d2, uint32_t *part_idx);
+void launch_knn1_fscan(hipStream_t s, int block, const double *qx, const double *qy, const double *qz, int qpad,
+                       int qblocks, const double *bound, const double *px, const double *py, const double *pz,
+                       int ntiles, int nparts, const Xf *H, double rmax, double *part_d2, uint32_t *part_idx);
+int  fscan_blocks_per_cu(int block);
+void launch_bound_prev(hipStream_t s, const double *qx, const double *qy, const double *qz, const double *p2, long Q,
+                       long qpad, const Xf &H, double *bound);
+void launch_max_norm2(hipStream_t s, const double *x, const double *y, const double *z, long n, unsigned long long *out);
+void launch_knn1_reduce(hipStream_t s, const double *part_d2, const uint32_t *part_idx, int nparts, int qpad, long Q,
                         double max_d2, int64_t idx_base, const double *px, const double *py, const double *pz,
                         double *d2_out, int64_t *idx_out, double *p2_out);
 void launch_knnk_pass(hipStream_t s, int K, const double *qx, const double *qy, const double *qz, int qpad, long Q,

@@ -109,7 +109,8 @@ template <int R, bool XFORM>
 __global__ __launch_bounds__(KNN_BLOCK) void k_knn1_scan(
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, int qpad,
     const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
-    long npad, int chunk_pts, Xf H, double *__restrict__ part_d2, uint32_t *__restrict__ part_idx)
+    long npad, int tile_step, int tiles_per_chunk, Xf H, double *__restrict__ part_d2,
+    uint32_t *__restrict__ part_idx)
 {
     __shared__ double sx[TILE_PTS], sy[TILE_PTS], sz[TILE_PTS];
     const int tid = threadIdx.x;
@@ -124,8 +125,10 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn1_scan(
         best[r] = __builtin_inf(); bidx[r] = 0xffffffffu;
     }
 
-    const long c0 = (long)blockIdx.y * chunk_pts;
-    long c1 = c0 + chunk_pts;
+    // chunk = tiles [y*tile_step, y*tile_step + tiles_per_chunk): contiguous cover when the two are
+    // equal, a strided subsample (bound pre-pass of the filtered scan) when tile_step is larger
+    const long c0 = (long)blockIdx.y * tile_step * TILE_PTS;
+    long c1 = c0 + (long)tiles_per_chunk * TILE_PTS;
     if (c1 > npad) c1 = npad;
 
     for (long t0 = c0; t0 < c1; t0 += TILE_PTS) {
@@ -158,27 +161,205 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn1_scan(
     }
 }
 
+// ------------------------------------------------------------------------------------
+// K1f: FILTERED brute-force 1-NN scan -- same result as K1, ~4x fewer VALU cycles per pair.
+//
+// The exact test costs 6 FP64 ops + compare/select per pair (FP64 VALU runs at 16 lanes/clk).
+// Here every pair first goes through a conservative FP32 filter in expanded form
+//        s = |p|^2 - 2 q.p          (3 v_fma_f32 + 1 v_cmp_f32, 32 lanes/clk)
+// against a per-query threshold  thr >= bound - |q|^2 + M,  where `bound` is the exact squared
+// distance to SOME cloud point (previous iteration's match, or a strided-subsample pre-pass)
+// and M = 6 * 2^-24 * (rmax + |q|)^2 bounds the FP32 rounding error of s rigorously
+// (inputs rounded to f32: u(|p|^2 + 4|q||p|); 3 fma roundings: 3u(|p|^2 + 2|q||p|);
+// sum <= 5u(|p|+|q|)^2, u = 2^-24).  Any point whose exact d2 is <= bound therefore passes, and
+// only passing pairs (a few dozen per query for the whole scan) are re-evaluated with the exact
+// FP64 contract (T)+(D) from the original coordinates.  The final answer is the lexicographic
+// (d2, idx) minimum over exactly-evaluated candidates == the plain brute-force answer, bit for bit.
+// Predicates are OR-ed in scalar registers over a group of FS_G points, so the hot loop has no
+// per-pair branch or select.  Tiles are double-buffered in LDS as float4 (x, y, z, |p|^2).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float filter_threshold(double bound, double qq, double rmax)
+{
+    if (!(bound < __builtin_inf())) return __builtin_inff();
+    const double sN = rmax + sqrt(qq);
+    const double M = (6.0 * 5.9604644775390625e-08 * 1.0001) * sN * sN;
+    const float f = (float)((bound - qq) + M);
+    return f + fabsf(f) * 1.1920929e-07f + 1.0e-37f;      // round up past the f64->f32 conversion
+}
+
+template <int BLOCK, bool XFORM>
+__global__ __launch_bounds__(BLOCK) void k_knn1_fscan(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, int qpad,
+    const double *__restrict__ bound,
+    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
+    int ntiles, Xf H, double rmax, double *__restrict__ part_d2, uint32_t *__restrict__ part_idx)
+{
+    constexpr int R = FS_R;
+    __shared__ float4 tile[2][FS_TILE];
+    const int tid = threadIdx.x;
+    const long q0 = (long)blockIdx.x * (BLOCK * R);
+
+    float m2x[R], m2y[R], m2z[R], thr[R];
+    double best[R];
+    uint32_t bidx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long q = q0 + r * BLOCK + tid;
+        const double x = qx[q], y = qy[q], z = qz[q];
+        const double qq = fma(z, z, fma(y, y, x * x));
+        m2x[r] = (float)(-2.0 * x); m2y[r] = (float)(-2.0 * y); m2z[r] = (float)(-2.0 * z);
+        thr[r] = filter_threshold(bound[q], qq, rmax);
+        best[r] = __builtin_inf(); bidx[r] = 0xffffffffu;
+    }
+
+    const int t_lo = (int)((long)blockIdx.y * ntiles / gridDim.y);
+    const int t_hi = (int)((long)(blockIdx.y + 1) * ntiles / gridDim.y);
+
+    constexpr int PER = FS_TILE / BLOCK;
+    double lx[PER], ly[PER], lz[PER];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const long g = (long)t * FS_TILE + u * BLOCK + tid;
+            lx[u] = px[g]; ly[u] = py[g]; lz[u] = pz[g];
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            double X = lx[u], Y = ly[u], Z = lz[u];
+            if (XFORM) { double a, b, c; xform(H, X, Y, Z, a, b, c); X = a; Y = b; Z = c; }
+            const double pp = fma(Z, Z, fma(Y, Y, X * X));
+            tile[buf][u * BLOCK + tid] = make_float4((float)X, (float)Y, (float)Z, (float)pp);
+        }
+    };
+    if (t_lo < t_hi) { gload(t_lo); lstore(0); }
+    int cur = 0;
+    for (int t = t_lo; t < t_hi; ++t) {
+        __syncthreads();                     // tile[cur] complete; nobody still reads tile[cur^1]
+        const bool more = (t + 1 < t_hi);
+        if (more) gload(t + 1);              // HBM latency hides under this tile's compute
+        const uint32_t tbase = (uint32_t)t * FS_TILE;
+        for (int g0 = 0; g0 < FS_TILE; g0 += FS_G) {
+            // group minimum of s per query, then ONE compare per query: the per-pair cost is
+            // 3 fma + 1/2 min3; the lane masks are OR-ed in scalar registers
+            float gm[R];
+            {
+                const float4 P = tile[cur][g0];
+#pragma unroll
+                for (int r = 0; r < R; ++r) gm[r] = fmaf(m2x[r], P.x, fmaf(m2y[r], P.y, fmaf(m2z[r], P.z, P.w)));
+            }
+#pragma unroll
+            for (int g = 1; g < FS_G; ++g) {
+                const float4 P = tile[cur][g0 + g];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    gm[r] = fminf(gm[r], fmaf(m2x[r], P.x, fmaf(m2y[r], P.y, fmaf(m2z[r], P.z, P.w))));
+            }
+            unsigned long long hit = 0ull;
+#pragma unroll
+            for (int r = 0; r < R; ++r) hit |= __builtin_amdgcn_ballot_w64(gm[r] < thr[r]);
+            if (hit != 0ull) {
+                // rare: re-run the group, evaluate passing pairs exactly from the original coordinates
+#pragma unroll 1
+                for (int g = 0; g < FS_G; ++g) {
+                    const float4 P = tile[cur][g0 + g];
+                    const uint32_t id = tbase + (uint32_t)(g0 + g);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float s = fmaf(m2x[r], P.x, fmaf(m2y[r], P.y, fmaf(m2z[r], P.z, P.w)));
+                        if (s < thr[r]) {
+                            double X = px[id], Y = py[id], Z = pz[id];
+                            if (XFORM) { double a, b, c; xform(H, X, Y, Z, a, b, c); X = a; Y = b; Z = c; }
+                            const long q = q0 + r * BLOCK + tid;
+                            const double ax = qx[q], ay = qy[q], az = qz[q];
+                            const double dx = X - ax, dy = Y - ay, dz = Z - az;
+                            const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                            if (d2 < best[r]) {          // ascending scan: ties keep the lower index
+                                best[r] = d2; bidx[r] = id;
+                                const double qq = fma(az, az, fma(ay, ay, ax * ax));
+                                thr[r] = fminf(thr[r], filter_threshold(d2, qq, rmax));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (more) lstore(cur ^ 1);
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long q = q0 + r * BLOCK + tid;
+        part_d2[(long)blockIdx.y * qpad + q] = best[r];
+        part_idx[(long)blockIdx.y * qpad + q] = bidx[r];
+    }
+}
+
+// exact squared distance to the previous iteration's match under the NEW transform: an upper
+// bound of the new nearest-neighbour distance that costs nothing (the point is in the cloud).
+__global__ void k_bound_prev(const double *__restrict__ qx, const double *__restrict__ qy,
+                             const double *__restrict__ qz, const double *__restrict__ p2, long Q, long qpad, Xf H,
+                             double *__restrict__ bound)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= qpad) return;
+    if (q >= Q) { bound[q] = __builtin_inf(); return; }
+    double X, Y, Z;
+    xform(H, p2[3 * q], p2[3 * q + 1], p2[3 * q + 2], X, Y, Z);
+    const double dx = X - qx[q], dy = Y - qy[q], dz = Z - qz[q];
+    bound[q] = fma(dz, dz, fma(dy, dy, dx * dx));
+}
+
+// largest squared norm of a cloud (for the filter's error bound); out = bits of a non-negative double
+__global__ void k_max_norm2(const double *__restrict__ x, const double *__restrict__ y,
+                            const double *__restrict__ z, long n, unsigned long long *__restrict__ out)
+{
+    double m = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double v = fma(z[i], z[i], fma(y[i], y[i], x[i] * x[i]));
+        m = v > m ? v : m;                                  // NaN never wins
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(m, off, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
 // chunk partials -> per-query winner (ascending chunk order + strict `<` keeps the lowest
 // index on ties), strict upper bound (pointcloud.py:163-167), gather of the winner's
 // ORIGINAL coordinates (what the optimiser consumes, optimization.py:172-211).
-__global__ void k_knn1_reduce(const double *__restrict__ part_d2, const uint32_t *__restrict__ part_idx,
-                              int nchunks, int qpad, long Q, double max_d2, int64_t idx_base,
-                              const double *__restrict__ px, const double *__restrict__ py,
-                              const double *__restrict__ pz,
-                              double *__restrict__ d2_out, int64_t *__restrict__ idx_out,
-                              double *__restrict__ p2_out /* (Q,3) row-major, may be null */)
+__global__ __launch_bounds__(1024) void k_knn1_reduce(
+    const double *__restrict__ part_d2, const uint32_t *__restrict__ part_idx, int nparts, int qpad, long Q,
+    double max_d2, int64_t idx_base, const double *__restrict__ px, const double *__restrict__ py,
+    const double *__restrict__ pz, double *__restrict__ d2_out, int64_t *__restrict__ idx_out,
+    double *__restrict__ p2_out /* (Q,3) row-major, may be null */)
 {
-    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q) return;
+    // wave w of the block reads partial rows w, w+16, ... for 64 consecutive queries (coalesced),
+    // then the 16 waves combine through LDS; all comparisons lexicographic on (d2, idx)
+    __shared__ double sd[16][64];
+    __shared__ uint32_t si[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long q = (long)blockIdx.x * 64 + tx;
     double best = __builtin_inf();
     uint32_t bi = 0xffffffffu;
-    for (int c = 0; c < nchunks; ++c) {
-        const double d = part_d2[(long)c * qpad + q];
-        if (d < best) { best = d; bi = part_idx[(long)c * qpad + q]; }
+    if (q < Q) {
+        for (int c = ty; c < nparts; c += 16) {
+            const double d = part_d2[(long)c * qpad + q];
+            const uint32_t i = part_idx[(long)c * qpad + q];
+            if (d < best || (d == best && i < bi)) { best = d; bi = i; }
+        }
+    }
+    sd[ty][tx] = best; si[ty][tx] = bi;
+    __syncthreads();
+    if (ty != 0 || q >= Q) return;
+    for (int w = 1; w < 16; ++w) {
+        const double d = sd[w][tx];
+        const uint32_t i = si[w][tx];
+        if (d < best || (d == best && i < bi)) { best = d; bi = i; }
     }
     const bool ok = (bi != 0xffffffffu) && (best < max_d2);
-    d2_out[q] = ok ? best : __builtin_inf();
-    idx_out[q] = ok ? (idx_base + (int64_t)bi) : (int64_t)-1;
+    if (d2_out) d2_out[q] = ok ? best : __builtin_inf();
+    if (idx_out) idx_out[q] = ok ? (idx_base + (int64_t)bi) : (int64_t)-1;
     if (p2_out) {
         p2_out[3 * q]     = ok ? px[bi] : 0.0;
         p2_out[3 * q + 1] = ok ? py[bi] : 0.0;
@@ -664,25 +845,72 @@ void launch_aos_queries(hipStream_t s, const double *aos, long Q, long qpad, dou
     hipLaunchKernelGGL(k_aos_queries, dim3(cdiv(qpad, 256)), dim3(256), 0, s, aos, Q, qpad, qx, qy, qz);
 }
 
-void launch_knn1_scan(hipStream_t s, const double *qx, const double *qy, const double *qz, int qpad,
-                      const double *px, const double *py, const double *pz, long npad, int chunk_pts, int nchunks,
-                      const Xf *H, double *part_d2, uint32_t *part_idx)
+void launch_knn1_scan(hipStream_t s, const double *qx, const double *qy, const double *qz, int qpad, int qblocks,
+                      const double *px, const double *py, const double *pz, long npad, int tile_step,
+                      int tiles_per_chunk, int nchunks, const Xf *H, double *part_d2, uint32_t *part_idx)
 {
-    const dim3 grid(qpad / (KNN_BLOCK * KNN1_R), nchunks), block(KNN_BLOCK);
+    const dim3 grid(qblocks, nchunks), block(KNN_BLOCK);
     Xf id = {};
     if (H)
         hipLaunchKernelGGL((k_knn1_scan<KNN1_R, true>), grid, block, 0, s, qx, qy, qz, qpad, px, py, pz, npad,
-                           chunk_pts, *H, part_d2, part_idx);
+                           tile_step, tiles_per_chunk, *H, part_d2, part_idx);
     else
         hipLaunchKernelGGL((k_knn1_scan<KNN1_R, false>), grid, block, 0, s, qx, qy, qz, qpad, px, py, pz, npad,
-                           chunk_pts, id, part_d2, part_idx);
+                           tile_step, tiles_per_chunk, id, part_d2, part_idx);
 }
 
-void launch_knn1_reduce(hipStream_t s, const double *part_d2, const uint32_t *part_idx, int nchunks, int qpad, long Q,
+template <int BLOCK>
+static void fscan_launch(hipStream_t s, const double *qx, const double *qy, const double *qz, int qpad, int qblocks,
+                         const double *bound, const double *px, const double *py, const double *pz, int ntiles,
+                         int nparts, const Xf *H, double rmax, double *part_d2, uint32_t *part_idx)
+{
+    const dim3 grid(qblocks, nparts), block(BLOCK);
+    Xf id = {};
+    if (H)
+        hipLaunchKernelGGL((k_knn1_fscan<BLOCK, true>), grid, block, 0, s, qx, qy, qz, qpad, bound, px, py, pz, ntiles,
+                           *H, rmax, part_d2, part_idx);
+    else
+        hipLaunchKernelGGL((k_knn1_fscan<BLOCK, false>), grid, block, 0, s, qx, qy, qz, qpad, bound, px, py, pz, ntiles,
+                           id, rmax, part_d2, part_idx);
+}
+
+// BLOCK = 128 (1024 queries per block) or 256 (2048 queries per block)
+void launch_knn1_fscan(hipStream_t s, int block, const double *qx, const double *qy, const double *qz, int qpad,
+                       int qblocks, const double *bound, const double *px, const double *py, const double *pz,
+                       int ntiles, int nparts, const Xf *H, double rmax, double *part_d2, uint32_t *part_idx)
+{
+    if (block == 256) fscan_launch<256>(s, qx, qy, qz, qpad, qblocks, bound, px, py, pz, ntiles, nparts, H, rmax, part_d2, part_idx);
+    else              fscan_launch<128>(s, qx, qy, qz, qpad, qblocks, bound, px, py, pz, ntiles, nparts, H, rmax, part_d2, part_idx);
+}
+
+int fscan_blocks_per_cu(int block)
+{
+    int nb = 0;
+    hipError_t e = (block == 256)
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_knn1_fscan<256, true>, 256, 0)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_knn1_fscan<128, true>, 128, 0);
+    if (e != hipSuccess || nb < 1) nb = 2;
+    return nb > 16 ? 16 : nb;
+}
+
+void launch_bound_prev(hipStream_t s, const double *qx, const double *qy, const double *qz, const double *p2, long Q,
+                       long qpad, const Xf &H, double *bound)
+{
+    hipLaunchKernelGGL(k_bound_prev, dim3(cdiv(qpad, 256)), dim3(256), 0, s, qx, qy, qz, p2, Q, qpad, H, bound);
+}
+
+void launch_max_norm2(hipStream_t s, const double *x, const double *y, const double *z, long n, unsigned long long *out)
+{
+    long g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)g), dim3(256), 0, s, x, y, z, n, out);
+}
+
+void launch_knn1_reduce(hipStream_t s, const double *part_d2, const uint32_t *part_idx, int nparts, int qpad, long Q,
                         double max_d2, int64_t idx_base, const double *px, const double *py, const double *pz,
                         double *d2_out, int64_t *idx_out, double *p2_out)
 {
-    hipLaunchKernelGGL(k_knn1_reduce, dim3(cdiv(Q, 256)), dim3(256), 0, s, part_d2, part_idx, nchunks, qpad, Q, max_d2,
+    hipLaunchKernelGGL(k_knn1_reduce, dim3(cdiv(Q, 64)), dim3(1024), 0, s, part_d2, part_idx, nparts, qpad, Q, max_d2,
                        idx_base, px, py, pz, d2_out, idx_out, p2_out);
 }
 
@@ -693,7 +921,7 @@ static void knnk_pass(hipStream_t s, const double *qx, const double *qy, const d
                       int kout, int col0, int kstride, int64_t idx_base, double *d2_out, int64_t *idx_out,
                       double *floor_d2_out, uint32_t *floor_idx_out)
 {
-    hipLaunchKernelGGL((k_knnk_scan<K>), dim3(qpad / KNN_BLOCK, nchunks), dim3(KNN_BLOCK), 0, s, qx, qy, qz, qpad, px,
+    hipLaunchKernelGGL((k_knnk_scan<K>), dim3(cdiv(Q, KNN_BLOCK), nchunks), dim3(KNN_BLOCK), 0, s, qx, qy, qz, qpad, px,
                        py, pz, npad, chunk_pts, floor_d2_in, floor_idx_in, part_d2, part_idx);
     hipLaunchKernelGGL((k_knnk_merge<K>), dim3(cdiv(Q, 64)), dim3(64), 0, s, part_d2, part_idx, nchunks, qpad, Q, kout,
                        col0, kstride, idx_base, d2_out, idx_out, floor_d2_out, floor_idx_out);

@@ -165,3 +165,76 @@ def test_too_few_correspondences(ctx):
     with pytest.raises(_lib.BackendError) as e:
         ctx.icp_iterate(np.zeros(6), np.zeros(6), np.zeros(6))
     assert e.value.code == _lib.ERR_TOO_FEW and "Too few correspondences" in str(e.value)
+
+
+# ---- filtered scan (FP32 conservative filter + exact FP64 verification) == plain brute force ----
+@pytest.fixture(scope="module")
+def ctx_filter():
+    import os
+    from simpleicp_amd import _lib
+    os.environ["SICP_KNN1"] = "filter"          # force the filtered path even for small clouds
+    try:
+        c = _lib.Context(0)
+    finally:
+        del os.environ["SICP_KNN1"]
+    yield c
+    c.close()
+
+
+def _surface(n, seed, L=None):
+    rng = np.random.default_rng(seed)
+    L = L or np.sqrt(n / 10.0)
+    x, y = rng.uniform(0, L, n), rng.uniform(0, L, n)
+    z = 20 * np.sin(2 * np.pi * x / 200) * np.cos(2 * np.pi * y / 300) + rng.normal(0, 0.02, n)
+    return np.column_stack((x, y, z))
+
+
+@pytest.mark.parametrize("case", ["uniform_small", "surface_1m", "offset_utm", "quantised_ties", "tiny_coords",
+                                  "clustered", "q_gt_1024"])
+def test_filtered_scan_equals_brute_force(ctx_filter, case):
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(11)
+    H = _H(4)
+    if case == "uniform_small":
+        P, Qp = rng.uniform(-50, 50, (5000, 3)), rng.uniform(-50, 50, (300, 3))
+    elif case == "surface_1m":
+        P = _surface(1_000_000, 1); P -= P.mean(0)
+        Qp = _surface(1_000_000, 2)[::1000] - _surface(1_000_000, 1).mean(0)
+    elif case == "offset_utm":       # large common offset: the FP32 filter is nearly blind, still exact
+        P = _surface(300_000, 3) + np.array([4.5e5, 5.2e6, 300.0])
+        Qp = P[::300] + rng.normal(0, 0.05, (1000, 3))
+    elif case == "quantised_ties":
+        P = np.round(rng.uniform(-20, 20, (400_000, 3)), 1); P[200_000:] = P[:200_000]
+        Qp = np.round(rng.uniform(-20, 20, (1000, 3)), 1)
+    elif case == "tiny_coords":
+        P, Qp = rng.uniform(-1e-6, 1e-6, (300_000, 3)), rng.uniform(-1e-6, 1e-6, (500, 3))
+    elif case == "clustered":
+        P = np.concatenate([rng.normal(c, 0.01, (100_000, 3)) for c in ((0, 0, 0), (100, 0, 0), (0, 1000, 5))])
+        Qp = np.concatenate([rng.normal(c, 0.02, (300, 3)) for c in ((0, 0, 0), (100, 0, 0), (50, 500, 0))])
+    else:
+        P, Qp = _surface(500_000, 5), _surface(500_000, 6)[::100]      # 5000 queries -> R = 8 blocks
+    ctx_filter.upload(_lib.MOV, P)
+    for Hm, md in ((None, np.inf), (H, np.inf), (None, 0.5)):
+        idx, d2 = ctx_filter.knn(_lib.MOV, Qp, k=1, H=Hm, max_dist=md)
+        ridx, rd2 = orc.knn(P, Qp, k=1, H=Hm, max_dist=md)
+        assert np.array_equal(idx, ridx)
+        assert np.array_equal(d2, rd2)
+
+
+def test_filtered_iteration_uses_previous_match_bound(ctx_filter, clouds):
+    """Iterations 2+ take the filter bound from the previous match; all of it must stay bit-exact."""
+    from simpleicp_amd import _lib
+    g, files, kw = load_golden("dragon")
+    Xf, Xm = clouds(files[0]), clouds(files[1])
+    sel = g["sel_idx"]
+    ctx_filter.upload(_lib.FIX, Xf)
+    ctx_filter.upload(_lib.MOV, Xm)
+    ctx_filter.icp_setup(sel, g["normals"], g["planarity"])
+    x = np.zeros(6)
+    for it in range(5):
+        R = ctx_filter.icp_iterate(x, np.zeros(6), np.zeros(6), 0.3, 1.0)
+        o = orc.icp_iteration(Xm, Xf[sel], g["normals"], g["planarity"], x, x, 1.0, np.zeros(6), np.zeros(6), 0.3)
+        idx, dist, keep, _ = ctx_filter.icp_state()
+        assert np.array_equal(idx, o["nn"]) and np.array_equal(dist, o["dist"]) and np.array_equal(keep, o["keep"])
+        x = np.array(R.x[:])
+        assert np.abs(x - o["x"]).max() < 1e-11
