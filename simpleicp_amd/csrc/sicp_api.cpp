@@ -65,9 +65,20 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct Grid {
+    bool valid = false;
+    GridGeom g;
+    long ncells = 0;
+    double avg_per_cell = 0;
+    DevBuf<uint32_t> cell_start;     // ncells + 1
+    DevBuf<uint32_t> sidx;           // sorted position -> local row
+    DevBuf<double> sxyz;             // sx[n] | sy[n] | sz[n] in cell order
+};
+
 struct Cloud {
     int64_t n = 0, npad = 0, idx_base = 0;
-    double rmax = 0.0;    // largest point norm (error bound of the filtered scan)
+    double rmax = 0.0;    // largest point norm (error bounds of the filtered / grid searches)
+    Grid grid;
     DevBuf<double> xyz;   // x[npad] | y[npad] | z[npad]
     const double *x() const { return xyz.p; }
     const double *y() const { return xyz.p + npad; }
@@ -168,7 +179,9 @@ struct sicp_ctx {
     DevBuf<uint32_t> floor_idx;
     DevBuf<double> bound;          // per-query upper bound of the NN distance (filtered scan)
     int fs_blocks_per_cu[2] = {0, 0};   // occupancy of k_knn1_fscan<128>, <256>
-    int knn1_mode = 0;             // SICP_KNN1 = exact | filter: force one scan flavour (A/B + tests); 0 = auto
+    int knn1_mode = 0;             // SICP_KNN1 = exact | filter | grid: force one 1-NN flavour (A/B + tests); 0 = auto
+    DevBuf<uint32_t> g_keys, g_vals, g_keys2, g_counts;   // grid build scratch
+    DevBuf<unsigned char> g_tmp;
     bool have_prev_match = false;  // m_p2 holds last iteration's winners (bound source)
     // ICP state (selected fixed points and per-iteration products)
     int64_t Q = 0, qpad = 0;
@@ -253,6 +266,105 @@ int check_slot(sicp_ctx *c, int slot, bool need_data)
 
 void H16_to_Xf(const double H[16], Xf *o) { for (int i = 0; i < 12; ++i) o->m[i] = H[i]; }
 
+double key_to_double(unsigned long long k)
+{
+    const unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    double v; std::memcpy(&v, &b, sizeof v); return v;
+}
+
+// bins the cloud of `slot` once (own frame); see sicp_grid.hip
+int grid_build(sicp_ctx *c, int slot)
+{
+    Cloud &cl = c->cloud[slot];
+    Grid &gr = cl.grid;
+    if (gr.valid) return SICP_OK;
+    const long n = cl.n;
+    unsigned long long *d_keys = (unsigned long long *)(c->small.p + 48);     // 6 u64
+    unsigned long long h_init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
+    HIPCHK(hipMemcpyAsync(d_keys, h_init, sizeof h_init, hipMemcpyHostToDevice, c->stream));
+    launch_bbox(c->stream, cl.x(), cl.y(), cl.z(), n, d_keys);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_small + 48, d_keys, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CHK(sync(c));
+    unsigned long long hk[6]; std::memcpy(hk, c->h_small + 48, sizeof hk);
+    double mn[3], ex[3], vol = 1.0; int deff = 0;
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = key_to_double(hk[a]);
+        ex[a] = key_to_double(hk[3 + a]) - mn[a];
+        if (!(ex[a] >= 0) || !std::isfinite(ex[a])) return fail(SICP_ERR_INVALID, "cloud has non-finite coordinates");
+        if (ex[a] > 0) { vol *= ex[a]; ++deff; }
+    }
+    const double target = 8.0;                       // points per occupied cell
+    const long cap = 1L << 27;                       // dense cell array cap (512 MiB of offsets)
+    double h = deff ? std::pow(vol * target / (double)n, 1.0 / deff) : 1.0;
+    if (!(h > 0) || !std::isfinite(h)) h = 1.0;
+    CHK(c->g_keys.reserve(n)); CHK(c->g_vals.reserve(n)); CHK(c->g_keys2.reserve(n)); CHK(gr.sidx.reserve(n));
+    GridGeom G;
+    long ncells = 1;
+    for (int attempt = 0;; ++attempt) {
+        for (;;) {
+            ncells = 1;
+            for (int a = 0; a < 3; ++a) {
+                double d = std::floor(ex[a] / h) + 1.0;
+                if (d > 2.0e9) d = 2.0e9;
+                G.dim[a] = (int)d; ncells *= (long)G.dim[a];
+                if (ncells > (1L << 40)) ncells = 1L << 40;
+            }
+            if (ncells <= cap) break;
+            h *= std::cbrt((double)ncells / (double)cap) * 1.02;
+        }
+        for (int a = 0; a < 3; ++a) G.mn[a] = mn[a];
+        G.h = h; G.inv_h = 1.0 / h;
+        CHK(c->g_counts.reserve((size_t)ncells + 1));
+        HIPCHK(hipMemsetAsync(c->g_counts.p, 0, ((size_t)ncells + 1) * sizeof(uint32_t), c->stream));
+        launch_cell_ids(c->stream, cl.x(), cl.y(), cl.z(), n, G, c->g_keys.p, c->g_vals.p, c->g_counts.p);
+        unsigned long long *d_cnt = (unsigned long long *)(c->small.p + 54);
+        HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), c->stream));
+        launch_count_nonempty(c->stream, c->g_counts.p, ncells, d_cnt);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->h_small + 54, d_cnt, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        CHK(sync(c));
+        unsigned long long occ; std::memcpy(&occ, c->h_small + 54, sizeof occ);
+        gr.avg_per_cell = (double)n / (double)std::max<unsigned long long>(occ, 1);
+        // data on a surface / curve fills far fewer cells than the volume estimate assumes: shrink
+        if (gr.avg_per_cell > 3 * target && attempt < 4 && ncells < cap / 2) { h *= std::sqrt(target / gr.avg_per_cell); continue; }
+        break;
+    }
+    gr.g = G; gr.ncells = ncells;
+    // offsets = exclusive scan of the histogram (entry ncells = n)
+    CHK(gr.cell_start.reserve((size_t)ncells + 1));
+    int bits = 1; while ((1L << bits) < ncells && bits < 32) ++bits;
+    const size_t tmp_bytes = std::max(grid_scan_temp_bytes(ncells + 1), grid_sort_temp_bytes(n, bits));
+    CHK(c->g_tmp.reserve(tmp_bytes + 256));
+    if (grid_scan(c->stream, c->g_tmp.p, tmp_bytes, c->g_counts.p, gr.cell_start.p, ncells + 1) != hipSuccess)
+        return fail(SICP_ERR_HIP, "grid: exclusive scan failed");
+    // stable sort by cell id: rows of a cell stay in ascending original order
+    if (grid_sort(c->stream, c->g_tmp.p, tmp_bytes, c->g_keys.p, c->g_keys2.p, c->g_vals.p, gr.sidx.p, n, bits) != hipSuccess)
+        return fail(SICP_ERR_HIP, "grid: radix sort failed");
+    CHK(gr.sxyz.reserve((size_t)3 * n));
+    launch_gather_sorted(c->stream, cl.x(), cl.y(), cl.z(), gr.sidx.p, n, gr.sxyz.p, gr.sxyz.p + n, gr.sxyz.p + 2 * n);
+    HIPCHK(hipGetLastError());
+    CHK(sync(c));
+    gr.valid = true;
+    return SICP_OK;
+}
+
+// H (rows 0..2) rigid to working precision?  Then Hinv = [R^T | -R^T t].
+bool rigid_inverse(const Xf &H, Xf *inv)
+{
+    double e = 0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        double s = 0; for (int k = 0; k < 3; ++k) s += H.m[4 * k + i] * H.m[4 * k + j];
+        e = std::max(e, std::fabs(s - (i == j ? 1.0 : 0.0)));
+    }
+    if (!(e < 1e-13)) return false;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) inv->m[4 * i + j] = H.m[4 * j + i];
+        inv->m[4 * i + 3] = -(H.m[i] * H.m[3] + H.m[4 + i] * H.m[7] + H.m[8 + i] * H.m[11]);
+    }
+    return true;
+}
+
 // largest singular value of the 3x3 part of H (so |Hp| <= smax*|p| + |t| for ANY affine H)
 double smax3(const Xf &H)
 {
@@ -293,6 +405,28 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
     double rmax_t = cl.rmax;
     if (H) rmax_t = smax3(*H) * cl.rmax + std::sqrt(H->m[3] * H->m[3] + H->m[7] * H->m[7] + H->m[11] * H->m[11]);
     rmax_t *= (1.0 + 1e-9);
+    // ---- pruned exact search on the static grid (rigid H only) ----
+    Xf Hinv;
+    const bool rigid = !H || rigid_inverse(*H, &Hinv);
+    const bool big = cl.n > 65536 || (double)cl.n * (double)Q > 1.0e9;
+    if (rigid && (c->knn1_mode == 3 || (c->knn1_mode == 0 && big))) {
+        CHK(grid_build(c, slot));
+        Grid &gr = cl.grid;
+        const double *bnd = nullptr;
+        if (prev_p2) {
+            CHK(c->bound.reserve(qpad));
+            launch_bound_prev(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, prev_p2, Q, qpad, *H, c->bound.p);
+            bnd = c->bound.p;
+        }
+        {
+            Timed t(c, SICP_K_KNN1);
+            launch_grid_nn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, bnd, gr.g, gr.cell_start.p, gr.sxyz.p,
+                           gr.sxyz.p + cl.n, gr.sxyz.p + 2 * cl.n, gr.sidx.p, H, H ? &Hinv : nullptr, cl.rmax, max_d2,
+                           cl.idx_base, d2_out, idx_out, p2_out);
+        }
+        HIPCHK(hipGetLastError());
+        return SICP_OK;
+    }
     const bool small = cl.n <= 262144;                       // launch-bound anyway: one exact pass
     const bool filter_ok = std::isfinite(rmax_t) && rmax_t < 1e18;   // squares must fit float32
     if (c->knn1_mode == 1 || (small && c->knn1_mode != 2) || !filter_ok) {
@@ -459,7 +593,8 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (rc == SICP_OK) rc = c->ticket.reserve(4);
     if (rc == SICP_OK && hipMemsetAsync(c->ticket.p, 0, 4 * sizeof(unsigned), c->stream) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
-    if (const char *e = std::getenv("SICP_KNN1")) c->knn1_mode = !std::strcmp(e, "exact") ? 1 : !std::strcmp(e, "filter") ? 2 : 0;
+    if (const char *e = std::getenv("SICP_KNN1"))
+        c->knn1_mode = !std::strcmp(e, "exact") ? 1 : !std::strcmp(e, "filter") ? 2 : !std::strcmp(e, "grid") ? 3 : 0;
     *ctx_out = c;
     return SICP_OK;
 }
@@ -471,7 +606,8 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    for (auto &cl : c->cloud) cl.xyz.release();
+    for (auto &cl : c->cloud) { cl.xyz.release(); cl.grid.cell_start.release(); cl.grid.sidx.release(); cl.grid.sxyz.release(); }
+    c->g_keys.release(); c->g_vals.release(); c->g_keys2.release(); c->g_counts.release(); c->g_tmp.release();
     c->stage.release(); c->part_d2.release(); c->part_idx.release(); c->kq.release(); c->k_d2.release();
     c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
@@ -499,6 +635,7 @@ SICP_EXPORT int sicp_cloud_upload(sicp_ctx *c, int slot, const double *xyz, int6
     HIPCHK(hipSetDevice(c->device));
     Cloud &cl = c->cloud[slot];
     cl.n = n; cl.npad = round_up(n, TILE_PTS); cl.idx_base = index_base;
+    cl.grid.valid = false;
     CHK(cl.xyz.reserve((size_t)3 * cl.npad));
     CHK(c->stage.reserve((size_t)3 * n));
     HIPCHK(hipMemcpyAsync(c->stage.p, xyz, (size_t)3 * n * sizeof(double), hipMemcpyDefault, c->stream));
@@ -533,6 +670,7 @@ SICP_EXPORT int sicp_cloud_transform(sicp_ctx *c, int slot, const double H[16])
     Cloud &cl = c->cloud[slot];
     launch_transform(c->stream, cl.x(), cl.y(), cl.z(), cl.n, X);
     HIPCHK(hipGetLastError());
+    cl.grid.valid = false;
     cl.rmax = (smax3(X) * cl.rmax + std::sqrt(X.m[3] * X.m[3] + X.m[7] * X.m[7] + X.m[11] * X.m[11])) * (1.0 + 1e-9);
     if (slot == SICP_MOV) c->have_prev_match = false;
     return sync(c);

@@ -1,0 +1,254 @@
+// sicp_grid.hip -- pruned EXACT 1-NN on a static uniform grid.
+//
+// The searched (movable) cloud never moves in its own frame, so it is binned ONCE per upload:
+// cell id per point -> stable radix sort (hipCUB; a library primitive used only in this one-off
+// build) -> cell offsets by histogram + exclusive scan -> coordinates gathered into cell order.
+// Per iteration each query is pulled back into the cloud's frame with the rigid inverse of H and
+// ONE WAVE enumerates the cells that intersect a ball around it; every candidate is evaluated with
+// the exact arithmetic contract (T)+(D) from its original coordinates and compared
+// lexicographically on (d2, original index).  The ball radius comes from an exact upper bound of
+// the answer (previous iteration's match re-evaluated under the new H) or from an expanding search;
+// termination needs best <= radius minus a slack that covers the rounding of H^-1 q and the
+// non-orthogonality of the floating-point R, so the result equals the brute-force scan's, bit for
+// bit (tests compare the two on full-size inputs).  The reference instead rebuilds a cKDTree on
+// the transformed cloud every iteration (corrpts.py:131, simpleicp.py:188-202).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include "sicp_internal.h"
+
+namespace sicp {
+
+__device__ __forceinline__ unsigned long long okey(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// out[0..2] = min keys, out[3..5] = max keys (ordered-uint64 image of the doubles)
+__global__ void k_bbox(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z, long n,
+                       unsigned long long *__restrict__ out)
+{
+    double lo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
+    double hi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double v[3] = {x[i], y[i], z[i]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = v[a] < lo[a] ? v[a] : lo[a]; hi[a] = v[a] > hi[a] ? v[a] : hi[a]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double l = __shfl_down(lo[a], off, 64), h = __shfl_down(hi[a], off, 64);
+            lo[a] = l < lo[a] ? l : lo[a]; hi[a] = h > hi[a] ? h : hi[a];
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(out + a, okey(lo[a])); atomicMax(out + 3 + a, okey(hi[a])); }
+    }
+}
+
+__device__ __forceinline__ int cell_coord(double v, double mn, double inv_h, int dim)
+{
+    int c = (int)floor((v - mn) * inv_h);
+    return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
+}
+
+__global__ void k_cell_ids(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                           long n, GridGeom G, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                           uint32_t *__restrict__ counts)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cx = cell_coord(x[i], G.mn[0], G.inv_h, G.dim[0]);
+    const int cy = cell_coord(y[i], G.mn[1], G.inv_h, G.dim[1]);
+    const int cz = cell_coord(z[i], G.mn[2], G.inv_h, G.dim[2]);
+    const uint32_t id = ((uint32_t)cz * G.dim[1] + cy) * G.dim[0] + cx;
+    keys[i] = id; vals[i] = (uint32_t)i;
+    atomicAdd(counts + id, 1u);
+}
+
+__global__ void k_gather_sorted(const double *__restrict__ x, const double *__restrict__ y,
+                                const double *__restrict__ z, const uint32_t *__restrict__ sidx, long n,
+                                double *__restrict__ sx, double *__restrict__ sy, double *__restrict__ sz)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = sidx[i];
+    sx[i] = x[s]; sy[i] = y[s]; sz[i] = z[s];
+}
+
+// number of non-empty cells (to judge the cell size)
+__global__ void k_count_nonempty(const uint32_t *__restrict__ counts, long ncells, unsigned long long *out)
+{
+    unsigned long long c = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ncells; i += (long)gridDim.x * blockDim.x)
+        c += counts[i] ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// ------------------------------------------------------------------------------------
+// one wave per query
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void xf(const Xf &H, double x, double y, double z, double &ox, double &oy, double &oz)
+{
+    double t;
+    t = H.m[0] * x;  t = fma(H.m[1], y, t);  t = fma(H.m[2], z, t);   ox = t + H.m[3];
+    t = H.m[4] * x;  t = fma(H.m[5], y, t);  t = fma(H.m[6], z, t);   oy = t + H.m[7];
+    t = H.m[8] * x;  t = fma(H.m[9], y, t);  t = fma(H.m[10], z, t);  oz = t + H.m[11];
+}
+
+template <bool XFORM>
+__global__ __launch_bounds__(256) void k_grid_nn(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, long Q,
+    const double *__restrict__ bound /* nullable: exact upper bound of the NN d2 per query */,
+    GridGeom G, const uint32_t *__restrict__ cell_start, const double *__restrict__ sx,
+    const double *__restrict__ sy, const double *__restrict__ sz, const uint32_t *__restrict__ sidx,
+    Xf H, Xf Hinv, double rmax, double max_d2, int64_t idx_base,
+    double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out)
+{
+    const int lane = threadIdx.x & 63;
+    const long q = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= Q) return;                                   // whole wave leaves together
+    const double ax = qx[q], ay = qy[q], az = qz[q];
+    double cxq = ax, cyq = ay, czq = az;                  // query in the cloud's own frame
+    if (XFORM) xf(Hinv, ax, ay, az, cxq, cyq, czq);
+    // covers rounding of H^-1 q and |R^T R - I| ~ 1e-16: distances in the two frames agree to
+    // ~1e-15 * scale; 1e-12 * scale leaves three orders of magnitude
+    const double scale = rmax + sqrt(fma(czq, czq, fma(cyq, cyq, cxq * cxq))) + 1.0;
+    const double slack = 1e-12 * scale;
+    const double r_cap = (max_d2 < __builtin_inf()) ? sqrt(max_d2) * (1.0 + 1e-12) + slack : __builtin_inf();
+    const bool has_bound = bound && (bound[q] < __builtin_inf());
+    double r = has_bound ? sqrt(bound[q]) * (1.0 + 1e-12) + slack : 0.5 * G.h;
+    if (r > r_cap) r = r_cap;
+
+    double best = __builtin_inf();
+    uint32_t bidx = 0xffffffffu, bpos = 0;
+    for (int pass = 0; pass < 64; ++pass) {
+        int lo[3], hi[3];
+        const double c3[3] = {cxq, cyq, czq};
+        bool all = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double fl = floor((c3[a] - r - G.mn[a]) * G.inv_h - 1e-6);
+            const double fh = floor((c3[a] + r - G.mn[a]) * G.inv_h + 1e-6);
+            lo[a] = fl < 0.0 ? 0 : (fl > (double)(G.dim[a] - 1) ? G.dim[a] - 1 : (int)fl);
+            hi[a] = fh < 0.0 ? 0 : (fh > (double)(G.dim[a] - 1) ? G.dim[a] - 1 : (int)fh);
+            // whole axis covered <=> the ball reaches past both faces of the box
+            all = all && (fl <= 0.0) && (fh >= (double)(G.dim[a] - 1));
+        }
+        best = __builtin_inf(); bidx = 0xffffffffu; bpos = 0;
+        for (int cz = lo[2]; cz <= hi[2]; ++cz)
+            for (int cy = lo[1]; cy <= hi[1]; ++cy) {
+                const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
+                const uint32_t b = cell_start[row + lo[0]], e = cell_start[row + hi[0] + 1];
+                for (uint32_t i = b + lane; i < e; i += 64) {
+                    double X = sx[i], Y = sy[i], Z = sz[i];
+                    if (XFORM) { double u, v, w; xf(H, X, Y, Z, u, v, w); X = u; Y = v; Z = w; }
+                    const double dx = X - ax, dy = Y - ay, dz = Z - az;
+                    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                    if (d2 <= best) {
+                        const uint32_t oi = sidx[i];
+                        if (d2 < best || oi < bidx) { best = d2; bidx = oi; bpos = i; }
+                    }
+                }
+            }
+        // wave-wide lexicographic (d2, original index) minimum
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double od = __shfl_xor(best, off, 64);
+            const uint32_t oi = __shfl_xor(bidx, off, 64), op = __shfl_xor(bpos, off, 64);
+            if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; bpos = op; }
+        }
+        const bool found = bidx != 0xffffffffu;
+        const double r_eff = (r - slack) / (1.0 + 1e-12);
+        if (found && sqrt(best) <= r_eff) break;          // nothing outside the ball can beat or tie it
+        if (all || r >= r_cap || has_bound) break;        // searched everything that may qualify
+        r = found ? sqrt(best) * (1.0 + 1e-12) + slack : 2.0 * r;
+        if (r > r_cap) r = r_cap;
+    }
+    if (lane == 0) {
+        const bool ok = (bidx != 0xffffffffu) && (best < max_d2);
+        d2_out[q] = ok ? best : __builtin_inf();
+        idx_out[q] = ok ? idx_base + (int64_t)bidx : (int64_t)-1;
+        if (p2_out) {
+            p2_out[3 * q]     = ok ? sx[bpos] : 0.0;
+            p2_out[3 * q + 1] = ok ? sy[bpos] : 0.0;
+            p2_out[3 * q + 2] = ok ? sz[bpos] : 0.0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------
+static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
+void launch_bbox(hipStream_t s, const double *x, const double *y, const double *z, long n, unsigned long long *out6)
+{
+    long g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_bbox, dim3((unsigned)g), dim3(256), 0, s, x, y, z, n, out6);
+}
+
+void launch_cell_ids(hipStream_t s, const double *x, const double *y, const double *z, long n, const GridGeom &G,
+                     uint32_t *keys, uint32_t *vals, uint32_t *counts)
+{
+    hipLaunchKernelGGL(k_cell_ids, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, n, G, keys, vals, counts);
+}
+
+void launch_count_nonempty(hipStream_t s, const uint32_t *counts, long ncells, unsigned long long *out)
+{
+    long g = (ncells + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_count_nonempty, dim3((unsigned)g), dim3(256), 0, s, counts, ncells, out);
+}
+
+size_t grid_sort_temp_bytes(long n, int bits)
+{
+    size_t t = 0;
+    uint32_t *p = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t, p, p, p, p, (int)n, 0, bits, (hipStream_t)0);
+    return t;
+}
+size_t grid_scan_temp_bytes(long ncells)
+{
+    size_t t = 0;
+    uint32_t *p = nullptr;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t, p, p, (int)ncells, (hipStream_t)0);
+    return t;
+}
+hipError_t grid_sort(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *k_in, uint32_t *k_out,
+                     const uint32_t *v_in, uint32_t *v_out, long n, int bits)
+{
+    return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (int)n, 0, bits, s);
+}
+hipError_t grid_scan(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, long ncells)
+{
+    return hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, in, out, (int)ncells, s);
+}
+
+void launch_gather_sorted(hipStream_t s, const double *x, const double *y, const double *z, const uint32_t *sidx, long n,
+                          double *sx, double *sy, double *sz)
+{
+    hipLaunchKernelGGL(k_gather_sorted, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, sidx, n, sx, sy, sz);
+}
+
+void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *bound,
+                    const GridGeom &G, const uint32_t *cell_start, const double *sx, const double *sy, const double *sz,
+                    const uint32_t *sidx, const Xf *H, const Xf *Hinv, double rmax, double max_d2, int64_t idx_base,
+                    double *d2_out, int64_t *idx_out, double *p2_out)
+{
+    const dim3 grid(cdiv(Q, 4)), block(256);
+    Xf id = {};
+    if (H)
+        hipLaunchKernelGGL((k_grid_nn<true>), grid, block, 0, s, qx, qy, qz, Q, bound, G, cell_start, sx, sy, sz, sidx, *H,
+                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out);
+    else
+        hipLaunchKernelGGL((k_grid_nn<false>), grid, block, 0, s, qx, qy, qz, Q, bound, G, cell_start, sx, sy, sz, sidx, id,
+                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out);
+}
+
+}  // namespace sicp

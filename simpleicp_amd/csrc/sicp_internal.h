@@ -20,6 +20,25 @@ constexpr int    NE_MAX_GRID = 1024;
 constexpr double SICP_PAD_COORD_V = 1.0e300;
 #define SICP_PAD_COORD 1.0e300
 
+// uniform grid over a cloud in its own frame (sicp_grid.hip)
+struct GridGeom { double mn[3]; double h, inv_h; int dim[3]; };
+
+void launch_bbox(hipStream_t s, const double *x, const double *y, const double *z, long n, unsigned long long *out6);
+void launch_cell_ids(hipStream_t s, const double *x, const double *y, const double *z, long n, const GridGeom &G,
+                     uint32_t *keys, uint32_t *vals, uint32_t *counts);
+void launch_count_nonempty(hipStream_t s, const uint32_t *counts, long ncells, unsigned long long *out);
+size_t grid_sort_temp_bytes(long n, int bits);
+size_t grid_scan_temp_bytes(long ncells);
+hipError_t grid_sort(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *k_in, uint32_t *k_out,
+                     const uint32_t *v_in, uint32_t *v_out, long n, int bits);
+hipError_t grid_scan(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, long ncells);
+void launch_gather_sorted(hipStream_t s, const double *x, const double *y, const double *z, const uint32_t *sidx, long n,
+                          double *sx, double *sy, double *sz);
+void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *bound,
+                    const GridGeom &G, const uint32_t *cell_start, const double *sx, const double *sy, const double *sz,
+                    const uint32_t *sidx, const Xf *H, const Xf *Hinv, double rmax, double max_d2, int64_t idx_base,
+                    double *d2_out, int64_t *idx_out, double *p2_out);
+
 void launch_aos_to_soa(hipStream_t s, const double *aos, long n, long npad, double *x, double *y, double *z);
 void launch_soa_to_aos(hipStream_t s, const double *x, const double *y, const double *z, long n, double *aos);
 void launch_transform(hipStream_t s, double *x, double *y, double *z, long n, const Xf &H);

@@ -168,15 +168,17 @@ def test_too_few_correspondences(ctx):
 
 
 # ---- filtered scan (FP32 conservative filter + exact FP64 verification) == plain brute force ----
-@pytest.fixture(scope="module")
-def ctx_filter():
+@pytest.fixture(scope="module", params=["filter", "grid"])
+def ctx_filter(request):
+    """Contexts that FORCE the filtered brute-force scan / the grid search even for small clouds."""
     import os
     from simpleicp_amd import _lib
-    os.environ["SICP_KNN1"] = "filter"          # force the filtered path even for small clouds
+    os.environ["SICP_KNN1"] = request.param
     try:
         c = _lib.Context(0)
     finally:
         del os.environ["SICP_KNN1"]
+    c.mode = request.param
     yield c
     c.close()
 
@@ -190,7 +192,8 @@ def _surface(n, seed, L=None):
 
 
 @pytest.mark.parametrize("case", ["uniform_small", "surface_1m", "offset_utm", "quantised_ties", "tiny_coords",
-                                  "clustered", "q_gt_1024"])
+                                  "clustered", "q_gt_1024", "far_queries", "degenerate_line", "identical_points",
+                                  "single_point"])
 def test_filtered_scan_equals_brute_force(ctx_filter, case):
     from simpleicp_amd import _lib
     rng = np.random.default_rng(11)
@@ -211,10 +214,21 @@ def test_filtered_scan_equals_brute_force(ctx_filter, case):
     elif case == "clustered":
         P = np.concatenate([rng.normal(c, 0.01, (100_000, 3)) for c in ((0, 0, 0), (100, 0, 0), (0, 1000, 5))])
         Qp = np.concatenate([rng.normal(c, 0.02, (300, 3)) for c in ((0, 0, 0), (100, 0, 0), (50, 500, 0))])
+    elif case == "far_queries":      # queries far outside the cloud's box: expanding search / huge radii
+        P = rng.uniform(-1, 1, (100_000, 3))
+        Qp = np.concatenate((rng.uniform(-1, 1, (50, 3)), rng.uniform(500, 600, (50, 3)), [[1e6, -1e6, 3.0]]))
+    elif case == "degenerate_line":  # zero extent on two axes
+        P = np.zeros((70_000, 3)); P[:, 0] = np.round(rng.uniform(0, 100, 70_000), 2)
+        Qp = np.column_stack((rng.uniform(-10, 110, 400), rng.normal(0, 1, 400), rng.normal(0, 1, 400)))
+    elif case == "identical_points":
+        P = np.tile([[1.5, -2.5, 3.25]], (5000, 1)); Qp = rng.uniform(-5, 5, (100, 3))
+    elif case == "single_point":
+        P = np.array([[1.0, 2.0, 3.0]]); Qp = rng.uniform(-5, 5, (10, 3))
     else:
         P, Qp = _surface(500_000, 5), _surface(500_000, 6)[::100]      # 5000 queries -> R = 8 blocks
     ctx_filter.upload(_lib.MOV, P)
-    for Hm, md in ((None, np.inf), (H, np.inf), (None, 0.5)):
+    A = H.copy(); A[:3, :3] = A[:3, :3] @ np.diag([1.5, 0.7, 1.0]) + 0.01     # NOT rigid: must still be exact
+    for Hm, md in ((None, np.inf), (H, np.inf), (None, 0.5), (H, 2.0), (A, np.inf)):
         idx, d2 = ctx_filter.knn(_lib.MOV, Qp, k=1, H=Hm, max_dist=md)
         ridx, rd2 = orc.knn(P, Qp, k=1, H=Hm, max_dist=md)
         assert np.array_equal(idx, ridx)
