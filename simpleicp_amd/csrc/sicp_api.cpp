@@ -196,6 +196,9 @@ struct sicp_ctx {
     double *h_small = nullptr;     // pinned mirror of `small`
     bool have_iter = false;
     double last_x[6] = {0}, last_w = 1.0, last_obs[6] = {0}, last_ow[6] = {0};
+    double last_ne[30] = {0};      // normal equations at last_x (fused path caches them)
+    bool have_last_ne = false;
+    int solve_mode = 0;            // SICP_SOLVE = fused | host (A/B + tests); 0 = auto
     // exchange
     sicp_exchange_fn xfn = nullptr;
     void *xuser = nullptr;
@@ -587,12 +590,13 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
         return fail(SICP_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, arch.c_str());
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipStreamCreate failed"); }
-    if (hipHostMalloc((void **)&c->h_small, 64 * sizeof(double)) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipHostMalloc failed"); }
-    int rc = c->small.reserve(64);
+    if (hipHostMalloc((void **)&c->h_small, 128 * sizeof(double)) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipHostMalloc failed"); }
+    int rc = c->small.reserve(128);
     if (rc == SICP_OK) rc = c->ne_partial.reserve((size_t)NE_MAX_GRID * 32);
     if (rc == SICP_OK) rc = c->ticket.reserve(4);
     if (rc == SICP_OK && hipMemsetAsync(c->ticket.p, 0, 4 * sizeof(unsigned), c->stream) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
+    if (const char *e = std::getenv("SICP_SOLVE")) c->solve_mode = !std::strcmp(e, "fused") ? 1 : !std::strcmp(e, "host") ? 2 : 0;
     if (const char *e = std::getenv("SICP_KNN1"))
         c->knn1_mode = !std::strcmp(e, "exact") ? 1 : !std::strcmp(e, "filter") ? 2 : !std::strcmp(e, "grid") ? 3 : 0;
     *ctx_out = c;
@@ -805,6 +809,55 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
         if (c->xfn(c->xuser, SICP_XCHG_BEST_MATCH, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q) != 0)
             return fail(SICP_ERR_EXCHANGE, "exchange callback (BEST_MATCH) failed");
     }
+    // ---- small Q: the whole tail of the iteration is ONE single-workgroup launch (sicp_solve.hip) ----
+    const bool sharded_gn = c->world > 1 && c->gn_shard && c->xfn;
+    if (Q <= SOLVE_MAX_Q && !sharded_gn && c->solve_mode != 2) {
+        SolveArgs A;
+        A.H = X;
+        for (int j = 0; j < 6; ++j) { A.x0[j] = P->x[j]; A.obs[j] = P->obs[j]; A.ow[j] = P->obs_weight[j]; }
+        A.w = (P->distance_weight > 0) ? P->distance_weight : -1.0;
+        A.min_planarity = (float)P->min_planarity;
+        A.max_steps = P->max_lm_steps > 0 ? (int)P->max_lm_steps : 100;
+        A.Q = Q;
+        double *d_out = c->small.p + 64;
+        {
+            Timed t(c, SICP_K_NORMALEQ);
+            launch_icp_solve(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p,
+                             c->m_p2.p, c->m_idx.p, A, c->dist.p, c->flag.p, c->keep.p, c->resid.p, d_out);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->h_small + 64, d_out, 56 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        CHK(sync(c));
+        const double *o = c->h_small + 64;
+        R->n_queries = Q; R->n_planar = (int64_t)o[0]; R->median = o[1]; R->mad = o[2]; R->n_kept = (int64_t)o[3];
+        R->dist_mean = o[4]; R->dist_std = o[5];
+        c->have_iter = true;
+        std::memcpy(c->last_x, P->x, sizeof c->last_x);
+        c->have_last_ne = false;
+        if (o[18] == 1.0 || R->n_kept < 6) {
+            std::memcpy(R->x, P->x, sizeof R->x);
+            return fail(SICP_ERR_TOO_FEW, "Too few correspondences! At least 6 correspondences are needed to estimate the 6 "
+                                          "rigid body transformation parameters. The current number of correspondences is %lld.",
+                        (long long)R->n_kept);
+        }
+        if (o[18] != 0.0) return fail(SICP_ERR_NUMERIC, "objective is not finite");
+        R->weight_used = o[6]; R->cost = o[7]; R->lm_steps = (int64_t)o[8]; R->ne_evals = (int64_t)o[9];
+        for (int j = 0; j < 6; ++j) R->x[j] = o[10 + j];
+        R->res_mean = o[16]; R->res_std = o[17];
+        params_to_H12(R->x, R->H);
+        R->H[12] = 0; R->H[13] = 0; R->H[14] = 0; R->H[15] = 1;
+        std::memcpy(c->last_x, R->x, sizeof c->last_x);
+        c->last_w = R->weight_used;
+        std::memcpy(c->last_obs, P->obs, sizeof c->last_obs);
+        std::memcpy(c->last_ow, P->obs_weight, sizeof c->last_ow);
+        std::memcpy(c->last_ne, o + 20, sizeof c->last_ne);
+        c->have_last_ne = true;
+        if (std::getenv("SICP_SOLVE_TRACE"))
+            std::fprintf(stderr, "[solve] cycles: dist %.0f sort %.0f stats %.0f lm %.0f (%lld evals, %lld steps) final %.0f\n",
+                         o[50], o[51], o[52], o[53], (long long)R->ne_evals, (long long)R->lm_steps, o[54]);
+        return SICP_OK;
+    }
+    c->have_last_ne = false;
     // ---- distances + rejections: corrpts.py:139-211 ----
     launch_postmatch(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, c->m_p2.p,
                      c->m_idx.p, Q, X, (float)P->min_planarity, c->dist.p, c->flag.p);
@@ -863,7 +916,7 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
             for (int u = 0; u < nfree; ++u) { xn[freeidx[u]] += b[u]; dxmax = std::max(dxmax, std::fabs(b[u])); }
             CHK(normal_eq_host(c, xn, false, true, nen)); R->ne_evals++;
             costn = objective(nen, w, xn, obs, ow);
-            if (costn <= cost * (1 + 1e-14) || dxmax < 1e-15) { accepted = true; break; }
+            if (costn <= cost * (1 + 1e-12) || dxmax < 1e-15) { accepted = true; break; }
             lambda = lambda > 0 ? lambda * 10 : 1e-6;
         }
         if (!accepted) break;
@@ -922,7 +975,8 @@ SICP_EXPORT int sicp_icp_uncertainties(sicp_ctx *c, double sigma_out[6])
     if (!c->have_iter) return fail(SICP_ERR_INVALID, "no iteration has run yet");
     HIPCHK(hipSetDevice(c->device));
     double ne[30];
-    CHK(normal_eq_host(c, c->last_x, false, false, ne));
+    if (c->have_last_ne) std::memcpy(ne, c->last_ne, sizeof ne);
+    else CHK(normal_eq_host(c, c->last_x, false, false, ne));
     const double w = c->last_w, *ow = c->last_ow, *obs = c->last_obs, *x = c->last_x;
     int freeidx[6], m = 0, nobs = 0;
     for (int j = 0; j < 6; ++j) { sigma_out[j] = std::numeric_limits<double>::quiet_NaN(); if (std::isfinite(ow[j])) freeidx[m++] = j; }

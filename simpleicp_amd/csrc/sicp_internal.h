@@ -20,6 +20,21 @@ constexpr int    NE_MAX_GRID = 1024;
 constexpr double SICP_PAD_COORD_V = 1.0e300;
 #define SICP_PAD_COORD 1.0e300
 
+// fused single-workgroup tail of the iteration (sicp_solve.hip)
+constexpr int SOLVE_MAX_Q = 2048;   // 7 staged Jacobian columns x 2048 x 8 B = 112 KiB of LDS
+constexpr int SOLVE_BLOCK = 512;   // 8 waves: 256-VGPR budget (30 fp64 accumulators + Jacobian rows, no spills)
+struct SolveArgs {
+    Xf H;                       // transform of the match (H(x0))
+    double x0[6], obs[6], ow[6];
+    double w;                   // distance weight; <= 0 = automatic
+    float min_planarity;
+    int max_steps;
+    long Q;
+};
+void launch_icp_solve(hipStream_t st, const double *qx, const double *qy, const double *qz, const float *normals,
+                      const float *planarity, const double *p2, const int64_t *idx, const SolveArgs &A, double *dist,
+                      uint8_t *flag, uint8_t *keep, double *resid, double *out);
+
 // uniform grid over a cloud in its own frame (sicp_grid.hip)
 struct GridGeom { double mn[3]; double h, inv_h; int dim[3]; };
 

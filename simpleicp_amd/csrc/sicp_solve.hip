@@ -1,0 +1,384 @@
+// sicp_solve.hip -- everything after the match of one ICP iteration in ONE launch of ONE workgroup
+// (Q <= SOLVE_MAX_Q): point-to-plane distances + planarity flag (corrpts.py:139-163,195-211),
+// median / raw-MAD rejection (corrpts.py:165-188), kept-distance statistics (simpleicp.py:233-234),
+// the Levenberg-Marquardt minimisation of optimization.py:65-124 on fused 6x6 normal-equation
+// reductions -- including the 6x6 solves, done wave-parallel on the device -- and the residual
+// statistics of simpleicp.py:356-379.  At Q ~ 1000 the whole tail of the iteration is latency, not
+// bandwidth: one launch + one 512-byte read-back replaces ~15 launches and ~12 host round trips.
+// (Large Q keeps the multi-block path: k_reject / k_stats / k_normal_eq + host solve.)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sicp_internal.h"
+
+namespace sicp {
+
+namespace {
+
+__device__ __forceinline__ void xfm(const Xf &H, double x, double y, double z, double &ox, double &oy, double &oz)
+{
+    double t;
+    t = H.m[0] * x;  t = fma(H.m[1], y, t);  t = fma(H.m[2], z, t);   ox = t + H.m[3];
+    t = H.m[4] * x;  t = fma(H.m[5], y, t);  t = fma(H.m[6], z, t);   oy = t + H.m[7];
+    t = H.m[8] * x;  t = fma(H.m[9], y, t);  t = fma(H.m[10], z, t);  oz = t + H.m[11];
+}
+__device__ __forceinline__ double pdist(double dx, double dy, double dz, float nx, float ny, float nz)
+{
+    const double a = dx * (double)nx, b = dy * (double)ny, c = dz * (double)nz;
+    return (a + b) + c;
+}
+__device__ __forceinline__ double wsum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long okey(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double oval(unsigned long long k)
+{
+    const unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+struct Shared {
+    union {
+        unsigned long long key[SOLVE_MAX_Q];   // order-statistics buffer (rejection phase)
+        double ja[7][SOLVE_MAX_Q];             // staged rows [a0..a5 | r] of the kept correspondences (LM phase)
+    };
+    double red[SOLVE_BLOCK / 64][32];      // per-wave partials
+    double ne[2][32];                      // normal equations: current / trial
+    double sc[6];                          // sin, cos of the three trial angles
+    double dx[8];                          // LM step + ok flag
+    double bc[4];                          // broadcast scalars
+};
+
+// block-wide sum of up to NV values per thread -> s.red, folded by the first NV threads into dst[]
+template <int NV>
+__device__ void block_sum(Shared &s, const double (&v)[NV], double *dst)
+{
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double t = wsum(v[i]);
+        if (lane == 0) s.red[wid][i] = t;
+    }
+    __syncthreads();
+    if (tid < NV) {
+        double t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s.red[w][tid];
+        dst[tid] = t;
+    }
+    __syncthreads();
+}
+
+// in-LDS bitonic sort of n (power of two) keys, ascending
+__device__ void bitonic(unsigned long long *k, int n)
+{
+    for (int size = 2; size <= n; size <<= 1)
+        for (int j = size >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = (i & size) == 0;
+                const unsigned long long a = k[i], b = k[l];
+                if ((a > b) == up) { k[i] = b; k[l] = a; }
+            }
+            __syncthreads();
+        }
+}
+
+// rank-based selection for small n: every thread counts how many keys precede its own (broadcast LDS
+// reads, no barriers inside); the owners of ranks r0 and r1 publish their keys.  keys[] has n entries.
+__device__ void select_ranks(Shared &s, int n, long r0, long r1, double *dst2)
+{
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const unsigned long long mine = s.key[t];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const unsigned long long k = s.key[j];
+            rank += (k < mine || (k == mine && j < t)) ? 1 : 0;
+        }
+        if (rank == r0) dst2[0] = oval(mine);
+        if (rank == r1) dst2[1] = oval(mine);
+    }
+    __syncthreads();
+}
+
+// normal equations of the unweighted residuals at x over the kept correspondences.
+// Phase 1: one correspondence per lane -> its Jacobian row [a0..a5] and residual r go to LDS
+// (zeros when rejected).  Phase 2: the 29 sums are 29 dot products of LDS columns, dealt to the
+// waves; each costs ONE wave reduction (30 block-wide reductions of per-lane accumulators would
+// serialise on the LDS permute pipe -- measured 25k cycles per evaluation, this is ~5k).
+__constant__ unsigned char kPairU[29] = {0,0,0,0,0,0, 1,1,1,1,1, 2,2,2,2, 3,3,3, 4,4, 5,  0,1,2,3,4,5, 6, 6};
+__constant__ unsigned char kPairV[29] = {0,1,2,3,4,5, 1,2,3,4,5, 2,3,4,5, 3,4,5, 4,5, 5,  6,6,6,6,6,6, 7, 6};
+
+__device__ void eval_ne(Shared &s, const SolveArgs &A, const double x[6], const double *__restrict__ qx,
+                        const double *__restrict__ qy, const double *__restrict__ qz, const float *__restrict__ normals,
+                        const double *__restrict__ p2, const uint8_t *__restrict__ keep, double nk, double *dst,
+                        double *__restrict__ resid)
+{
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    if (tid < 3) { double sn, cs; sincos(x[tid], &sn, &cs); s.sc[2 * tid] = sn; s.sc[2 * tid + 1] = cs; }
+    __syncthreads();
+    const double s1 = s.sc[0], c1 = s.sc[1], s2 = s.sc[2], c2 = s.sc[3], s3 = s.sc[4], c3 = s.sc[5];
+    Xf H;
+    H.m[0] = c2 * c3;                 H.m[1] = -c2 * s3;                H.m[2] = s2;        H.m[3] = x[3];
+    H.m[4] = c1 * s3 + s1 * s2 * c3;  H.m[5] = c1 * c3 - s1 * s2 * s3;  H.m[6] = -s1 * c2;  H.m[7] = x[4];
+    H.m[8] = s1 * s3 - c1 * s2 * c3;  H.m[9] = s1 * c3 + c1 * s2 * s3;  H.m[10] = c1 * c2;  H.m[11] = x[5];
+    double dR[27];
+    dR[0] = 0; dR[1] = 0; dR[2] = 0;
+    dR[3] = -s1 * s3 + c1 * s2 * c3;  dR[4] = -s1 * c3 - c1 * s2 * s3;  dR[5] = -c1 * c2;
+    dR[6] = c1 * s3 + s1 * s2 * c3;   dR[7] = c1 * c3 - s1 * s2 * s3;   dR[8] = -s1 * c2;
+    dR[9] = -s2 * c3;        dR[10] = s2 * s3;        dR[11] = c2;
+    dR[12] = s1 * c2 * c3;   dR[13] = -s1 * c2 * s3;  dR[14] = s1 * s2;
+    dR[15] = -c1 * c2 * c3;  dR[16] = c1 * c2 * s3;   dR[17] = -c1 * s2;
+    dR[18] = -c2 * s3;                 dR[19] = -c2 * c3;                  dR[20] = 0;
+    dR[21] = c1 * c3 - s1 * s2 * s3;   dR[22] = -c1 * s3 - s1 * s2 * c3;   dR[23] = 0;
+    dR[24] = s1 * c3 + c1 * s2 * s3;   dR[25] = -s1 * s3 + c1 * s2 * c3;   dR[26] = 0;
+
+    const int Q = (int)A.Q;
+    for (int i = tid; i < Q; i += blockDim.x) {
+        double a[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (keep[i]) {
+            const double px = p2[3 * i], py = p2[3 * i + 1], pz = p2[3 * i + 2];
+            double X, Y, Z;
+            xfm(H, px, py, pz, X, Y, Z);
+            const float fx = normals[3 * i], fy = normals[3 * i + 1], fz = normals[3 * i + 2];
+            a[6] = pdist(X - qx[i], Y - qy[i], Z - qz[i], fx, fy, fz);
+            const double nx = fx, ny = fy, nz = fz;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double *D = dR + 9 * c;
+                const double gx = D[0] * px + D[1] * py + D[2] * pz;
+                const double gy = D[3] * px + D[4] * py + D[5] * pz;
+                const double gz = D[6] * px + D[7] * py + D[8] * pz;
+                a[c] = nx * gx + ny * gy + nz * gz;
+            }
+            a[3] = nx; a[4] = ny; a[5] = nz;
+        }
+#pragma unroll
+        for (int c = 0; c < 7; ++c) s.ja[c][i] = a[c];
+        if (resid) resid[i] = a[6];
+    }
+    __syncthreads();
+    // wave w owns sums w, w+8, w+16, w+24: accumulated together so the LDS reads overlap
+    constexpr int NW = SOLVE_BLOCK / 64;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int pu[4], pv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int p = wid + NW * k; pu[k] = p < 29 ? kPairU[p] : 0; pv[k] = p < 29 ? kPairV[p] : 0; }
+#pragma unroll 2
+    for (int i = lane; i < Q; i += 64) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double a = s.ja[pu[k]][i];
+            const double b = (pv[k] == 7) ? 1.0 : s.ja[pv[k] == 7 ? 0 : pv[k]][i];
+            acc[k] = fma(a, b, acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = wsum(acc[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int p = wid + NW * k; if (p < 29) dst[p] = acc[k]; }
+    }
+    if (tid == 0) dst[29] = nk;
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool observed(double w) { return w > 0 && w < __builtin_inf(); }
+
+__device__ double objective(const double *ne, double w, const double x[6], const SolveArgs &A)
+{
+    double c = w * w * ne[28];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+        if (observed(A.ow[j])) { const double e = A.ow[j] * (x[j] - A.obs[j]); c += e * e; }
+    return c;
+}
+
+// wave 0: Gauss-Jordan on the 6x7 augmented system held one element per lane (lane = 7*row + col);
+// fixed parameters get an identity row/column.  Writes s.dx[0..5] and s.dx[6] = 1 on success.
+__device__ void lm_solve(Shared &s, const SolveArgs &A, const double *ne, double w, const double x[6], double lambda)
+{
+    const int lane = threadIdx.x;                 // caller guarantees threadIdx.x < 64
+    const int i = lane / 7, j = lane % 7;
+    double a = 0.0;
+    if (lane < 42) {
+        const bool fi = !(A.ow[i] < __builtin_inf());          // parameter i fixed (weight = inf)
+        if (j < 6) {
+            const bool fj = !(A.ow[j] < __builtin_inf());
+            if (fi || fj) a = (i == j) ? 1.0 : 0.0;
+            else {
+                const int u = i < j ? i : j, v = i < j ? j : i;
+                const int t = u * 6 - (u * (u - 1)) / 2 + (v - u);   // index in the upper triangle
+                a = w * w * ne[t];
+                if (i == j) { if (observed(A.ow[i])) a += A.ow[i] * A.ow[i]; a += lambda * a; }
+            }
+        } else {
+            if (fi) a = 0.0;
+            else {
+                double g = w * w * ne[21 + i];
+                if (observed(A.ow[i])) g += A.ow[i] * A.ow[i] * (x[i] - A.obs[i]);
+                a = -g;
+            }
+        }
+    }
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double piv = __shfl(a, k * 7 + k, 64);
+        const double rk = __shfl(a, k * 7 + (lane < 42 ? j : 0), 64);
+        const double fac = __shfl(a, (lane < 42 ? i : 0) * 7 + k, 64);
+        ok = ok && (piv > 0.0) && (piv < __builtin_inf());
+        const double t = rk / piv;
+        if (lane < 42) a = (i == k) ? t : (a - fac * t);
+    }
+    if (lane < 42 && j == 6) s.dx[i] = a;
+    if (lane == 0) s.dx[6] = ok ? 1.0 : 0.0;
+}
+
+}  // namespace
+
+// out layout (doubles): 0 n_planar, 1 median, 2 mad, 3 n_kept, 4 dist_mean, 5 dist_std, 6 w_used, 7 cost,
+// 8 lm_steps, 9 ne_evals, 10..15 x, 16 res_mean, 17 res_std, 18 status (0 ok / 1 too few / 2 numeric),
+// 20..49 normal equations at x
+__global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+    const float *__restrict__ normals, const float *__restrict__ planarity, const double *__restrict__ p2,
+    const int64_t *__restrict__ idx, SolveArgs A, double *__restrict__ dist, uint8_t *__restrict__ flag,
+    uint8_t *__restrict__ keep, double *__restrict__ resid, double *__restrict__ out)
+{
+    __shared__ Shared s;
+    const int tid = threadIdx.x;
+    const long Q = A.Q;
+    long long tk[6]; tk[0] = clock64();          // phase stamps (shader clock), reported in out[50..54]
+
+    // ---- distances + planarity flag ----
+    double cnt[1] = {0.0};
+    for (long i = tid; i < Q; i += blockDim.x) {
+        double X, Y, Z;
+        xfm(A.H, p2[3 * i], p2[3 * i + 1], p2[3 * i + 2], X, Y, Z);
+        dist[i] = pdist(X - qx[i], Y - qy[i], Z - qz[i], normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]);
+        const uint8_t f = (idx[i] >= 0 && planarity[i] >= A.min_planarity) ? 1 : 0;
+        flag[i] = f; cnt[0] += f;
+    }
+    block_sum<1>(s, cnt, s.bc);
+    const long m = (long)s.bc[0];
+    __syncthreads();
+    if (m == 0) {
+        for (long i = tid; i < Q; i += blockDim.x) keep[i] = 0;
+        if (tid == 0) { for (int k = 0; k < 50; ++k) out[k] = 0; out[1] = __builtin_nan(""); out[2] = __builtin_nan(""); out[18] = 1; }
+        return;
+    }
+    tk[1] = clock64();
+    // ---- median / raw MAD: exact order statistics in LDS (rank counting for n <= 1024, bitonic sort above) ----
+    int n2 = 1; while (n2 < Q) n2 <<= 1;
+    const bool by_rank = false;     // rank counting measured slower than the bitonic network (LDS latency bound)
+    double med, mad;
+    for (int i = tid; i < n2; i += blockDim.x) s.key[i] = (i < Q && flag[i]) ? okey(dist[i]) : ~0ull;
+    __syncthreads();
+    if (by_rank) select_ranks(s, (int)Q, (m - 1) / 2, m / 2, s.bc); else bitonic(s.key, n2);
+    med = by_rank ? (s.bc[0] + s.bc[1]) / 2.0 : (oval(s.key[(m - 1) / 2]) + oval(s.key[m / 2])) / 2.0;
+    __syncthreads();
+    for (int i = tid; i < n2; i += blockDim.x) s.key[i] = (i < Q && flag[i]) ? okey(fabs(dist[i] - med)) : ~0ull;
+    __syncthreads();
+    if (by_rank) select_ranks(s, (int)Q, (m - 1) / 2, m / 2, s.bc); else bitonic(s.key, n2);
+    mad = by_rank ? (s.bc[0] + s.bc[1]) / 2.0 : (oval(s.key[(m - 1) / 2]) + oval(s.key[m / 2])) / 2.0;
+    __syncthreads();
+    const double bound = 3 * mad;
+    tk[2] = clock64();
+    // ---- keep mask + mean of kept distances, then their std (two-pass, ddof 0) ----
+    double v2[2] = {0.0, 0.0};
+    for (long i = tid; i < Q; i += blockDim.x) {
+        const uint8_t k = (flag[i] && fabs(dist[i] - med) <= bound) ? 1 : 0;
+        keep[i] = k;
+        if (k) { v2[0] += 1.0; v2[1] += dist[i]; }
+    }
+    block_sum<2>(s, v2, s.bc);
+    const double nk = s.bc[0], dmean = s.bc[1] / s.bc[0];
+    __syncthreads();
+    double v1[1] = {0.0};
+    for (long i = tid; i < Q; i += blockDim.x) if (keep[i]) { const double e = dist[i] - dmean; v1[0] += e * e; }
+    block_sum<1>(s, v1, s.bc + 2);
+    const double dstd = sqrt(s.bc[2] / nk);
+    if (tid == 0) { out[0] = (double)m; out[1] = med; out[2] = mad; out[3] = nk; out[4] = dmean; out[5] = dstd; }
+    if (nk < 6.0) {
+        if (tid == 0) { for (int k = 6; k < 50; ++k) out[k] = 0; for (int k = 0; k < 6; ++k) out[10 + k] = A.x0[k]; out[18] = 1; }
+        return;
+    }
+    const double w = (A.w > 0) ? A.w : 1.0 / (dstd * dstd);          // simpleicp.py:233-234
+
+    tk[3] = clock64();
+    // ---- Levenberg-Marquardt on the fused 6x6 reductions ----
+    int nfree = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) nfree += (A.ow[j] < __builtin_inf()) ? 1 : 0;
+    double x[6], xn[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) x[j] = A.x0[j];
+    int cur = 0, steps = 0, evals = 0;
+    eval_ne(s, A, x, qx, qy, qz, normals, p2, keep, nk, s.ne[cur], nullptr); ++evals;
+    double cost = objective(s.ne[cur], w, x, A);
+    double lambda = 0.0;
+    for (int it = 0; it < A.max_steps && nfree > 0; ++it) {
+        bool accepted = false;
+        double costn = cost, dxmax = 0.0;
+        for (int tries = 0; tries < 40; ++tries) {
+            if (tid < 64) lm_solve(s, A, s.ne[cur], w, x, lambda);
+            __syncthreads();
+            const bool ok = s.dx[6] != 0.0;
+            dxmax = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { const double d = s.dx[j]; xn[j] = x[j] + d; dxmax = fmax(dxmax, fabs(d)); }
+            __syncthreads();                                   // s.dx consumed before the next solve rewrites it
+            if (!ok || !(dxmax < __builtin_inf())) { lambda = lambda > 0 ? lambda * 10 : 1e-6; continue; }
+            eval_ne(s, A, xn, qx, qy, qz, normals, p2, keep, nk, s.ne[cur ^ 1], nullptr); ++evals;
+            costn = objective(s.ne[cur ^ 1], w, xn, A);
+            if (costn <= cost * (1 + 1e-12) || dxmax < 1e-15) { accepted = true; break; }   // 1e-12: rounding noise of the sums
+            lambda = lambda > 0 ? lambda * 10 : 1e-6;
+        }
+        if (!accepted) break;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x[j] = xn[j];
+        cur ^= 1; cost = costn;
+        lambda = lambda > 0 ? lambda * 0.1 : 0.0;
+        if (lambda < 1e-12) lambda = 0.0;
+        ++steps;
+        double xmax = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) xmax = fmax(xmax, fabs(x[j]));
+        if (dxmax <= 1e-13 * (1.0 + xmax)) break;
+    }
+    // ---- residuals at the optimum + their mean / std ----
+    __syncthreads();
+    tk[4] = clock64();
+    eval_ne(s, A, x, qx, qy, qz, normals, p2, keep, nk, s.ne[cur], resid); ++evals;
+    const double rmean = s.ne[cur][27] / s.ne[cur][29];
+    double v3[1] = {0.0};
+    for (long i = tid; i < Q; i += blockDim.x) if (keep[i]) { const double e = resid[i] - rmean; v3[0] += e * e; }
+    block_sum<1>(s, v3, s.bc + 3);
+    if (tid < 30) out[20 + tid] = s.ne[cur][tid];
+    if (tid == 0) {
+        out[6] = w; out[7] = cost; out[8] = steps; out[9] = evals;
+        for (int j = 0; j < 6; ++j) out[10 + j] = x[j];
+        out[16] = rmean; out[17] = sqrt(s.bc[3] / s.ne[cur][29]);
+        out[18] = (cost < __builtin_inf()) ? 0.0 : 2.0;
+        tk[5] = clock64();
+        for (int k = 0; k < 5; ++k) out[50 + k] = (double)(tk[k + 1] - tk[k]);
+    }
+}
+
+void launch_icp_solve(hipStream_t st, const double *qx, const double *qy, const double *qz, const float *normals,
+                      const float *planarity, const double *p2, const int64_t *idx, const SolveArgs &A, double *dist,
+                      uint8_t *flag, uint8_t *keep, double *resid, double *out)
+{
+    hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(SOLVE_BLOCK), 0, st, qx, qy, qz, normals, planarity, p2, idx, A, dist, flag,
+                       keep, resid, out);
+}
+
+}  // namespace sicp
