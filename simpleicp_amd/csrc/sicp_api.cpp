@@ -415,15 +415,9 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
     if (rigid && (c->knn1_mode == 3 || (c->knn1_mode == 0 && big))) {
         CHK(grid_build(c, slot));
         Grid &gr = cl.grid;
-        const double *bnd = nullptr;
-        if (prev_p2) {
-            CHK(c->bound.reserve(qpad));
-            launch_bound_prev(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, prev_p2, Q, qpad, *H, c->bound.p);
-            bnd = c->bound.p;
-        }
         {
             Timed t(c, SICP_K_KNN1);
-            launch_grid_nn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, bnd, gr.g, gr.cell_start.p, gr.sxyz.p,
+            launch_grid_nn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, prev_p2, gr.g, gr.cell_start.p, gr.sxyz.p,
                            gr.sxyz.p + cl.n, gr.sxyz.p + 2 * cl.n, gr.sidx.p, H, H ? &Hinv : nullptr, cl.rmax, max_d2,
                            cl.idx_base, d2_out, idx_out, p2_out);
         }
@@ -590,7 +584,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
         return fail(SICP_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, arch.c_str());
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipStreamCreate failed"); }
-    if (hipHostMalloc((void **)&c->h_small, 128 * sizeof(double)) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipHostMalloc failed"); }
+    if (hipHostMalloc((void **)&c->h_small, 128 * sizeof(double), hipHostMallocMapped) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipHostMalloc failed"); }
     int rc = c->small.reserve(128);
     if (rc == SICP_OK) rc = c->ne_partial.reserve((size_t)NE_MAX_GRID * 32);
     if (rc == SICP_OK) rc = c->ticket.reserve(4);
@@ -815,18 +809,18 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
         SolveArgs A;
         A.H = X;
         for (int j = 0; j < 6; ++j) { A.x0[j] = P->x[j]; A.obs[j] = P->obs[j]; A.ow[j] = P->obs_weight[j]; }
+        for (int j = 0; j < 3; ++j) { A.sc0[2 * j] = std::sin(P->x[j]); A.sc0[2 * j + 1] = std::cos(P->x[j]); }
         A.w = (P->distance_weight > 0) ? P->distance_weight : -1.0;
         A.min_planarity = (float)P->min_planarity;
         A.max_steps = P->max_lm_steps > 0 ? (int)P->max_lm_steps : 100;
         A.Q = Q;
-        double *d_out = c->small.p + 64;
+        double *d_out = c->h_small + 64;      // pinned + mapped: the kernel's 56 result doubles land on the host directly
         {
             Timed t(c, SICP_K_NORMALEQ);
             launch_icp_solve(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p,
                              c->m_p2.p, c->m_idx.p, A, c->dist.p, c->flag.p, c->keep.p, c->resid.p, d_out);
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(c->h_small + 64, d_out, 56 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         CHK(sync(c));
         const double *o = c->h_small + 64;
         R->n_queries = Q; R->n_planar = (int64_t)o[0]; R->median = o[1]; R->mad = o[2]; R->n_kept = (int64_t)o[3];

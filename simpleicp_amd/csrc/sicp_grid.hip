@@ -103,7 +103,8 @@ __device__ __forceinline__ void xf(const Xf &H, double x, double y, double z, do
 template <bool XFORM>
 __global__ __launch_bounds__(256) void k_grid_nn(
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, long Q,
-    const double *__restrict__ bound /* nullable: exact upper bound of the NN d2 per query */,
+    const double *__restrict__ prev_p2 /* nullable: (Q,3) a cloud point per query (last match) -> its exact
+                                          distance under H bounds the answer; saves the expanding search */,
     GridGeom G, const uint32_t *__restrict__ cell_start, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const uint32_t *__restrict__ sidx,
     Xf H, Xf Hinv, double rmax, double max_d2, int64_t idx_base,
@@ -120,8 +121,15 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     const double scale = rmax + sqrt(fma(czq, czq, fma(cyq, cyq, cxq * cxq))) + 1.0;
     const double slack = 1e-12 * scale;
     const double r_cap = (max_d2 < __builtin_inf()) ? sqrt(max_d2) * (1.0 + 1e-12) + slack : __builtin_inf();
-    const bool has_bound = bound && (bound[q] < __builtin_inf());
-    double r = has_bound ? sqrt(bound[q]) * (1.0 + 1e-12) + slack : 0.5 * G.h;
+    double bnd = __builtin_inf();
+    if (prev_p2) {
+        double X = prev_p2[3 * q], Y = prev_p2[3 * q + 1], Z = prev_p2[3 * q + 2];
+        if (XFORM) { double u, v, w; xf(H, X, Y, Z, u, v, w); X = u; Y = v; Z = w; }
+        const double dx = X - ax, dy = Y - ay, dz = Z - az;
+        bnd = fma(dz, dz, fma(dy, dy, dx * dx));
+    }
+    const bool has_bound = bnd < __builtin_inf();
+    double r = has_bound ? sqrt(bnd) * (1.0 + 1e-12) + slack : 0.5 * G.h;
     if (r > r_cap) r = r_cap;
 
     double best = __builtin_inf();
@@ -140,21 +148,47 @@ __global__ __launch_bounds__(256) void k_grid_nn(
             all = all && (fl <= 0.0) && (fh >= (double)(G.dim[a] - 1));
         }
         best = __builtin_inf(); bidx = 0xffffffffu; bpos = 0;
-        for (int cz = lo[2]; cz <= hi[2]; ++cz)
-            for (int cy = lo[1]; cy <= hi[1]; ++cy) {
-                const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
-                const uint32_t b = cell_start[row + lo[0]], e = cell_start[row + hi[0] + 1];
-                for (uint32_t i = b + lane; i < e; i += 64) {
-                    double X = sx[i], Y = sy[i], Z = sz[i];
-                    if (XFORM) { double u, v, w; xf(H, X, Y, Z, u, v, w); X = u; Y = v; Z = w; }
-                    const double dx = X - ax, dy = Y - ay, dz = Z - az;
-                    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
-                    if (d2 <= best) {
-                        const uint32_t oi = sidx[i];
-                        if (d2 < best || oi < bidx) { best = d2; bidx = oi; bpos = i; }
-                    }
-                }
+        const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
+        const long nrows = (long)ny * nz;
+        auto visit = [&](uint32_t i) {
+            double X = sx[i], Y = sy[i], Z = sz[i];
+            if (XFORM) { double u, v, w; xf(H, X, Y, Z, u, v, w); X = u; Y = v; Z = w; }
+            const double dx = X - ax, dy = Y - ay, dz = Z - az;
+            const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+            if (d2 <= best) {
+                const uint32_t oi = sidx[i];
+                if (d2 < best || oi < bidx) { best = d2; bidx = oi; bpos = i; }
             }
+        };
+        // cells of one (cy, cz) row are contiguous in the sorted order: lane r fetches row r's point
+        // range, a wave scan turns up to 64 ranges into one flat candidate list, and the lanes stride
+        // over it -- two dependent memory round trips per batch instead of two per row
+        for (long rb = 0; rb < nrows; rb += 64) {
+            uint32_t b = 0, len = 0;
+            if (rb + lane < nrows) {
+                const long rr = rb + lane;
+                const int cy = lo[1] + (int)(rr % ny), cz = lo[2] + (int)(rr / ny);
+                const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
+                b = cell_start[row + lo[0]];
+                len = cell_start[row + hi[0] + 1] - b;
+            }
+            uint32_t incl = len;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+            const uint32_t total = __shfl(incl, 63, 64);
+            for (uint32_t base = 0; base < total; base += 64) {      // wave-uniform trip count: shuffles need all lanes
+                const uint32_t k = base + lane;
+                int r0 = 0;                                     // first row whose inclusive offset exceeds k
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const uint32_t v = __shfl(incl, r0 + step - 1, 64);
+                    if (v <= k) r0 += step;
+                }
+                r0 = r0 > 63 ? 63 : r0;
+                const uint32_t rbeg = __shfl(b, r0, 64), ri = __shfl(incl, r0, 64), rl = __shfl(len, r0, 64);
+                if (k < total) visit(rbeg + (k - (ri - rl)));
+            }
+        }
         // wave-wide lexicographic (d2, original index) minimum
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -236,7 +270,7 @@ void launch_gather_sorted(hipStream_t s, const double *x, const double *y, const
     hipLaunchKernelGGL(k_gather_sorted, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, sidx, n, sx, sy, sz);
 }
 
-void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *bound,
+void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                     const GridGeom &G, const uint32_t *cell_start, const double *sx, const double *sy, const double *sz,
                     const uint32_t *sidx, const Xf *H, const Xf *Hinv, double rmax, double max_d2, int64_t idx_base,
                     double *d2_out, int64_t *idx_out, double *p2_out)
@@ -244,10 +278,10 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
     const dim3 grid(cdiv(Q, 4)), block(256);
     Xf id = {};
     if (H)
-        hipLaunchKernelGGL((k_grid_nn<true>), grid, block, 0, s, qx, qy, qz, Q, bound, G, cell_start, sx, sy, sz, sidx, *H,
+        hipLaunchKernelGGL((k_grid_nn<true>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, sx, sy, sz, sidx, *H,
                            *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out);
     else
-        hipLaunchKernelGGL((k_grid_nn<false>), grid, block, 0, s, qx, qy, qz, Q, bound, G, cell_start, sx, sy, sz, sidx, id,
+        hipLaunchKernelGGL((k_grid_nn<false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, sx, sy, sz, sidx, id,
                            id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out);
 }
 

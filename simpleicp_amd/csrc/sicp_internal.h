@@ -26,6 +26,7 @@ constexpr int SOLVE_BLOCK = 512;   // 8 waves: 256-VGPR budget (30 fp64 accumula
 struct SolveArgs {
     Xf H;                       // transform of the match (H(x0))
     double x0[6], obs[6], ow[6];
+    double sc0[6];              // sin, cos of x0[0..2] from the host libm
     double w;                   // distance weight; <= 0 = automatic
     float min_planarity;
     int max_steps;
@@ -49,7 +50,7 @@ hipError_t grid_sort(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t 
 hipError_t grid_scan(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, long ncells);
 void launch_gather_sorted(hipStream_t s, const double *x, const double *y, const double *z, const uint32_t *sidx, long n,
                           double *sx, double *sy, double *sz);
-void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *bound,
+void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                     const GridGeom &G, const uint32_t *cell_start, const double *sx, const double *sy, const double *sz,
                     const uint32_t *sidx, const Xf *H, const Xf *Hinv, double rmax, double max_d2, int64_t idx_base,
                     double *d2_out, int64_t *idx_out, double *p2_out);

@@ -75,11 +75,18 @@ __device__ void block_sum(Shared &s, const double (&v)[NV], double *dst)
     __syncthreads();
 }
 
-// in-LDS bitonic sort of n (power of two) keys, ascending
-__device__ void bitonic(unsigned long long *k, int n)
+// in-LDS bitonic sort of n (power of two) keys, ascending; merge_only: the input already is a
+// bitonic sequence (falls, then rises), so the last log2(n) stages alone sort it.
+// Pair t of a stage with partner distance j touches elements inside one aligned 128-element chunk
+// whenever j <= 64, and wave w owns pairs 64w..64w+63 (+ multiples of the block size): those stages
+// need no workgroup barrier (a wave's LDS operations execute in order), only the j >= 128 ones do.
+__device__ void bitonic(unsigned long long *k, int n, bool merge_only = false)
 {
-    for (int size = 2; size <= n; size <<= 1)
+    bool need_barrier = true;                 // the fill before the call was done by other waves
+    for (int size = merge_only ? n : 2; size <= n; size <<= 1)
         for (int j = size >> 1; j > 0; j >>= 1) {
+            if (j >= 128 || need_barrier) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            need_barrier = (j >= 128);
             for (int t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const int l = i | j;
@@ -87,44 +94,34 @@ __device__ void bitonic(unsigned long long *k, int n)
                 const unsigned long long a = k[i], b = k[l];
                 if ((a > b) == up) { k[i] = b; k[l] = a; }
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
-}
-
-// rank-based selection for small n: every thread counts how many keys precede its own (broadcast LDS
-// reads, no barriers inside); the owners of ranks r0 and r1 publish their keys.  keys[] has n entries.
-__device__ void select_ranks(Shared &s, int n, long r0, long r1, double *dst2)
-{
-    for (int t = threadIdx.x; t < n; t += blockDim.x) {
-        const unsigned long long mine = s.key[t];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const unsigned long long k = s.key[j];
-            rank += (k < mine || (k == mine && j < t)) ? 1 : 0;
-        }
-        if (rank == r0) dst2[0] = oval(mine);
-        if (rank == r1) dst2[1] = oval(mine);
-    }
     __syncthreads();
 }
 
 // normal equations of the unweighted residuals at x over the kept correspondences.
-// Phase 1: one correspondence per lane -> its Jacobian row [a0..a5] and residual r go to LDS
-// (zeros when rejected).  Phase 2: the 29 sums are 29 dot products of LDS columns, dealt to the
-// waves; each costs ONE wave reduction (30 block-wide reductions of per-lane accumulators would
-// serialise on the LDS permute pipe -- measured 25k cycles per evaluation, this is ~5k).
+// Phase 1: each lane turns ITS correspondences (held in registers for the whole kernel) into the
+// Jacobian row [a0..a5] and residual r and parks them in LDS (zeros when rejected).  Phase 2: the 29
+// sums are 29 dot products of LDS columns, dealt to the waves; each costs ONE wave reduction (30
+// block-wide reductions of per-lane accumulators serialise on the LDS permute pipe -- measured 25k
+// cycles per evaluation against ~4k here).
 __constant__ unsigned char kPairU[29] = {0,0,0,0,0,0, 1,1,1,1,1, 2,2,2,2, 3,3,3, 4,4, 5,  0,1,2,3,4,5, 6, 6};
 __constant__ unsigned char kPairV[29] = {0,1,2,3,4,5, 1,2,3,4,5, 2,3,4,5, 3,4,5, 4,5, 5,  6,6,6,6,6,6, 7, 6};
 
-__device__ void eval_ne(Shared &s, const SolveArgs &A, const double x[6], const double *__restrict__ qx,
-                        const double *__restrict__ qy, const double *__restrict__ qz, const float *__restrict__ normals,
-                        const double *__restrict__ p2, const uint8_t *__restrict__ keep, double nk, double *dst,
+constexpr int EPT = SOLVE_MAX_Q / SOLVE_BLOCK;      // correspondences per thread (4)
+
+struct Corr {                                       // one thread's correspondences, register resident
+    double px[EPT], py[EPT], pz[EPT], qx[EPT], qy[EPT], qz[EPT];
+    float nx[EPT], ny[EPT], nz[EPT];
+    bool keep[EPT];
+};
+
+// sc = (sin a1, cos a1, sin a2, cos a2, sin a3, cos a3) of the angles in x
+__device__ void eval_ne(Shared &s, int Q, const double x[6], const double sc[6], const Corr &C, double nk, double *dst,
                         double *__restrict__ resid)
 {
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-    if (tid < 3) { double sn, cs; sincos(x[tid], &sn, &cs); s.sc[2 * tid] = sn; s.sc[2 * tid + 1] = cs; }
-    __syncthreads();
-    const double s1 = s.sc[0], c1 = s.sc[1], s2 = s.sc[2], c2 = s.sc[3], s3 = s.sc[4], c3 = s.sc[5];
+    const double s1 = sc[0], c1 = sc[1], s2 = sc[2], c2 = sc[3], s3 = sc[4], c3 = sc[5];
     Xf H;
     H.m[0] = c2 * c3;                 H.m[1] = -c2 * s3;                H.m[2] = s2;        H.m[3] = x[3];
     H.m[4] = c1 * s3 + s1 * s2 * c3;  H.m[5] = c1 * c3 - s1 * s2 * s3;  H.m[6] = -s1 * c2;  H.m[7] = x[4];
@@ -140,29 +137,31 @@ __device__ void eval_ne(Shared &s, const SolveArgs &A, const double x[6], const 
     dR[21] = c1 * c3 - s1 * s2 * s3;   dR[22] = -c1 * s3 - s1 * s2 * c3;   dR[23] = 0;
     dR[24] = s1 * c3 + c1 * s2 * s3;   dR[25] = -s1 * s3 + c1 * s2 * c3;   dR[26] = 0;
 
-    const int Q = (int)A.Q;
-    for (int i = tid; i < Q; i += blockDim.x) {
-        double a[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (keep[i]) {
-            const double px = p2[3 * i], py = p2[3 * i + 1], pz = p2[3 * i + 2];
-            double X, Y, Z;
-            xfm(H, px, py, pz, X, Y, Z);
-            const float fx = normals[3 * i], fy = normals[3 * i + 1], fz = normals[3 * i + 2];
-            a[6] = pdist(X - qx[i], Y - qy[i], Z - qz[i], fx, fy, fz);
-            const double nx = fx, ny = fy, nz = fz;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double *D = dR + 9 * c;
-                const double gx = D[0] * px + D[1] * py + D[2] * pz;
-                const double gy = D[3] * px + D[4] * py + D[5] * pz;
-                const double gz = D[6] * px + D[7] * py + D[8] * pz;
-                a[c] = nx * gx + ny * gy + nz * gz;
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * SOLVE_BLOCK;
+        if (i < Q) {
+            double a[7] = {0, 0, 0, 0, 0, 0, 0};
+            if (C.keep[e]) {
+                const double px = C.px[e], py = C.py[e], pz = C.pz[e];
+                double X, Y, Z;
+                xfm(H, px, py, pz, X, Y, Z);
+                a[6] = pdist(X - C.qx[e], Y - C.qy[e], Z - C.qz[e], C.nx[e], C.ny[e], C.nz[e]);
+                const double nx = C.nx[e], ny = C.ny[e], nz = C.nz[e];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double *D = dR + 9 * c;
+                    const double gx = D[0] * px + D[1] * py + D[2] * pz;
+                    const double gy = D[3] * px + D[4] * py + D[5] * pz;
+                    const double gz = D[6] * px + D[7] * py + D[8] * pz;
+                    a[c] = nx * gx + ny * gy + nz * gz;
+                }
+                a[3] = nx; a[4] = ny; a[5] = nz;
             }
-            a[3] = nx; a[4] = ny; a[5] = nz;
-        }
 #pragma unroll
-        for (int c = 0; c < 7; ++c) s.ja[c][i] = a[c];
-        if (resid) resid[i] = a[6];
+            for (int c = 0; c < 7; ++c) s.ja[c][i] = a[c];
+            if (resid) resid[i] = a[6];
+        }
     }
     __syncthreads();
     // wave w owns sums w, w+8, w+16, w+24: accumulated together so the LDS reads overlap
@@ -188,6 +187,33 @@ __device__ void eval_ne(Shared &s, const SolveArgs &A, const double x[6], const 
     }
     if (tid == 0) dst[29] = nk;
     __syncthreads();
+}
+
+// sin/cos of (a + d) from sin/cos of a: exact addition theorem with a short Taylor series for the
+// small step d (|d| <= 0.25 rad: d^17/17! < 2e-25); larger steps take the library routine.
+// Keeps the LM loop free of double-precision sincos calls (hundreds of dependent instructions each).
+__device__ __forceinline__ void sincos_step(double a_new, double d, double sa, double ca, double &sn, double &cn)
+{
+    if (fabs(d) > 0.25) { sincos(a_new, &sn, &cn); return; }
+    const double d2 = d * d;
+    double sd = 1.0 / 1307674368000.0;                       // 1/15!
+    sd = fma(sd, d2, -1.0 / 6227020800.0);                   // 1/13!
+    sd = fma(sd, d2, 1.0 / 39916800.0);
+    sd = fma(sd, d2, -1.0 / 362880.0);
+    sd = fma(sd, d2, 1.0 / 5040.0);
+    sd = fma(sd, d2, -1.0 / 120.0);
+    sd = fma(sd, d2, 1.0 / 6.0);
+    sd = d - d * d2 * sd;                                     // sin d
+    double cd = 1.0 / 20922789888000.0;                      // 1/16!
+    cd = fma(cd, d2, -1.0 / 87178291200.0);                  // 1/14!
+    cd = fma(cd, d2, 1.0 / 479001600.0);
+    cd = fma(cd, d2, -1.0 / 3628800.0);
+    cd = fma(cd, d2, 1.0 / 40320.0);
+    cd = fma(cd, d2, -1.0 / 720.0);
+    cd = fma(cd, d2, 1.0 / 24.0);
+    cd = 1.0 - d2 * (0.5 - d2 * cd);                          // cos d
+    sn = fma(sa, cd, ca * sd);
+    cn = fma(ca, cd, -(sa * sd));
 }
 
 __device__ __forceinline__ bool observed(double w) { return w > 0 && w < __builtin_inf(); }
@@ -258,14 +284,24 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
     const long Q = A.Q;
     long long tk[6]; tk[0] = clock64();          // phase stamps (shader clock), reported in out[50..54]
 
-    // ---- distances + planarity flag ----
+    // ---- distances + planarity flag; every thread keeps its correspondences in registers ----
+    Corr C;
     double cnt[1] = {0.0};
-    for (long i = tid; i < Q; i += blockDim.x) {
-        double X, Y, Z;
-        xfm(A.H, p2[3 * i], p2[3 * i + 1], p2[3 * i + 2], X, Y, Z);
-        dist[i] = pdist(X - qx[i], Y - qy[i], Z - qz[i], normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]);
-        const uint8_t f = (idx[i] >= 0 && planarity[i] >= A.min_planarity) ? 1 : 0;
-        flag[i] = f; cnt[0] += f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const long i = tid + (long)e * SOLVE_BLOCK;
+        C.keep[e] = false;
+        C.px[e] = C.py[e] = C.pz[e] = C.qx[e] = C.qy[e] = C.qz[e] = 0.0; C.nx[e] = C.ny[e] = C.nz[e] = 0.f;
+        if (i < Q) {
+            C.px[e] = p2[3 * i]; C.py[e] = p2[3 * i + 1]; C.pz[e] = p2[3 * i + 2];
+            C.qx[e] = qx[i]; C.qy[e] = qy[i]; C.qz[e] = qz[i];
+            C.nx[e] = normals[3 * i]; C.ny[e] = normals[3 * i + 1]; C.nz[e] = normals[3 * i + 2];
+            double X, Y, Z;
+            xfm(A.H, C.px[e], C.py[e], C.pz[e], X, Y, Z);
+            dist[i] = pdist(X - C.qx[e], Y - C.qy[e], Z - C.qz[e], C.nx[e], C.ny[e], C.nz[e]);
+            const uint8_t f = (idx[i] >= 0 && planarity[i] >= A.min_planarity) ? 1 : 0;
+            flag[i] = f; cnt[0] += f;
+        }
     }
     block_sum<1>(s, cnt, s.bc);
     const long m = (long)s.bc[0];
@@ -278,26 +314,31 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
     tk[1] = clock64();
     // ---- median / raw MAD: exact order statistics in LDS (rank counting for n <= 1024, bitonic sort above) ----
     int n2 = 1; while (n2 < Q) n2 <<= 1;
-    const bool by_rank = false;     // rank counting measured slower than the bitonic network (LDS latency bound)
     double med, mad;
     for (int i = tid; i < n2; i += blockDim.x) s.key[i] = (i < Q && flag[i]) ? okey(dist[i]) : ~0ull;
     __syncthreads();
-    if (by_rank) select_ranks(s, (int)Q, (m - 1) / 2, m / 2, s.bc); else bitonic(s.key, n2);
-    med = by_rank ? (s.bc[0] + s.bc[1]) / 2.0 : (oval(s.key[(m - 1) / 2]) + oval(s.key[m / 2])) / 2.0;
+    bitonic(s.key, n2);
+    med = (oval(s.key[(m - 1) / 2]) + oval(s.key[m / 2])) / 2.0;
     __syncthreads();
-    for (int i = tid; i < n2; i += blockDim.x) s.key[i] = (i < Q && flag[i]) ? okey(fabs(dist[i] - med)) : ~0ull;
+    // |d - med| over the SORTED distances falls towards the median and rises after it (the unflagged
+    // sentinels stay at the top): a bitonic sequence, so one merge (log2 n stages) sorts it
+    for (int i = tid; i < n2; i += blockDim.x) { const unsigned long long k = s.key[i]; if (k != ~0ull) s.key[i] = okey(fabs(oval(k) - med)); }
     __syncthreads();
-    if (by_rank) select_ranks(s, (int)Q, (m - 1) / 2, m / 2, s.bc); else bitonic(s.key, n2);
-    mad = by_rank ? (s.bc[0] + s.bc[1]) / 2.0 : (oval(s.key[(m - 1) / 2]) + oval(s.key[m / 2])) / 2.0;
+    bitonic(s.key, n2, true);
+    mad = (oval(s.key[(m - 1) / 2]) + oval(s.key[m / 2])) / 2.0;
     __syncthreads();
     const double bound = 3 * mad;
     tk[2] = clock64();
     // ---- keep mask + mean of kept distances, then their std (two-pass, ddof 0) ----
     double v2[2] = {0.0, 0.0};
-    for (long i = tid; i < Q; i += blockDim.x) {
-        const uint8_t k = (flag[i] && fabs(dist[i] - med) <= bound) ? 1 : 0;
-        keep[i] = k;
-        if (k) { v2[0] += 1.0; v2[1] += dist[i]; }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const long i = tid + (long)e * SOLVE_BLOCK;
+        if (i < Q) {
+            const uint8_t k = (flag[i] && fabs(dist[i] - med) <= bound) ? 1 : 0;
+            keep[i] = k; C.keep[e] = k != 0;
+            if (k) { v2[0] += 1.0; v2[1] += dist[i]; }
+        }
     }
     block_sum<2>(s, v2, s.bc);
     const double nk = s.bc[0], dmean = s.bc[1] / s.bc[0];
@@ -318,11 +359,11 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
     int nfree = 0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) nfree += (A.ow[j] < __builtin_inf()) ? 1 : 0;
-    double x[6], xn[6];
+    double x[6], xn[6], sc[6], scn[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) x[j] = A.x0[j];
+    for (int j = 0; j < 6; ++j) { x[j] = A.x0[j]; sc[j] = A.sc0[j]; }
     int cur = 0, steps = 0, evals = 0;
-    eval_ne(s, A, x, qx, qy, qz, normals, p2, keep, nk, s.ne[cur], nullptr); ++evals;
+    eval_ne(s, (int)Q, x, sc, C, nk, s.ne[cur], nullptr); ++evals;
     double cost = objective(s.ne[cur], w, x, A);
     double lambda = 0.0;
     for (int it = 0; it < A.max_steps && nfree > 0; ++it) {
@@ -333,18 +374,21 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
             __syncthreads();
             const bool ok = s.dx[6] != 0.0;
             dxmax = 0.0;
+            double dstep[6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) { const double d = s.dx[j]; xn[j] = x[j] + d; dxmax = fmax(dxmax, fabs(d)); }
+            for (int j = 0; j < 6; ++j) { const double d = s.dx[j]; dstep[j] = d; xn[j] = x[j] + d; dxmax = fmax(dxmax, fabs(d)); }
             __syncthreads();                                   // s.dx consumed before the next solve rewrites it
             if (!ok || !(dxmax < __builtin_inf())) { lambda = lambda > 0 ? lambda * 10 : 1e-6; continue; }
-            eval_ne(s, A, xn, qx, qy, qz, normals, p2, keep, nk, s.ne[cur ^ 1], nullptr); ++evals;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sincos_step(xn[j], dstep[j], sc[2 * j], sc[2 * j + 1], scn[2 * j], scn[2 * j + 1]);
+            eval_ne(s, (int)Q, xn, scn, C, nk, s.ne[cur ^ 1], nullptr); ++evals;
             costn = objective(s.ne[cur ^ 1], w, xn, A);
             if (costn <= cost * (1 + 1e-12) || dxmax < 1e-15) { accepted = true; break; }   // 1e-12: rounding noise of the sums
             lambda = lambda > 0 ? lambda * 10 : 1e-6;
         }
         if (!accepted) break;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) x[j] = xn[j];
+        for (int j = 0; j < 6; ++j) { x[j] = xn[j]; sc[j] = scn[j]; }
         cur ^= 1; cost = costn;
         lambda = lambda > 0 ? lambda * 0.1 : 0.0;
         if (lambda < 1e-12) lambda = 0.0;
@@ -357,7 +401,7 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
     // ---- residuals at the optimum + their mean / std ----
     __syncthreads();
     tk[4] = clock64();
-    eval_ne(s, A, x, qx, qy, qz, normals, p2, keep, nk, s.ne[cur], resid); ++evals;
+    eval_ne(s, (int)Q, x, sc, C, nk, s.ne[cur], resid); ++evals;
     const double rmean = s.ne[cur][27] / s.ne[cur][29];
     double v3[1] = {0.0};
     for (long i = tid; i < Q; i += blockDim.x) if (keep[i]) { const double e = resid[i] - rmean; v3[0] += e * e; }
