@@ -154,16 +154,24 @@ int sicp_params_to_H(const double x[6], double H_out[16]);
  * All pointers handed to the callback are DEVICE pointers owned by the ctx, the library's
  * stream is idle when it is called, and the callback must complete (results visible in
  * device memory) before it returns 0.
- *   SICP_XCHG_BEST_MATCH : a = d2 f64[count], b = idx i64[count], c = xyz f64[3*count]
- *                          (row-major, movable coordinates of the local winner); replace
- *                          in place by the job-wide lexicographic (d2, idx) minimum's.
- *   SICP_XCHG_SUM_F64    : a = f64[count]; replace in place by the sum over ranks.        */
-#define SICP_XCHG_BEST_MATCH 1
-#define SICP_XCHG_SUM_F64    2
+ *   SICP_XCHG_ALLGATHER_F64 : a = send f64[count], b = recv f64[world*count]; fill b with every
+ *                             rank's `a` in rank order (the library packs per-query
+ *                             (d2, idx, x, y, z) records into `a` and afterwards reduces `b` to
+ *                             the job-wide lexicographic (d2, idx) minimum with its own kernel).
+ *   SICP_XCHG_SUM_F64       : a = f64[count]; replace in place by the sum over ranks.          */
+#define SICP_XCHG_ALLGATHER_F64 1
+#define SICP_XCHG_SUM_F64       2
 typedef int (*sicp_exchange_fn)(void *user, int what, void *a, void *b, void *c, int64_t count);
-/* gn_shard: 0 = every rank reduces all correspondences (no collective in the solver),
+/* With an exchange registered, sicp_knn(k == 1) and the iteration's match return JOB-WIDE winners.
+ * gn_shard: 0 = every rank reduces all correspondences (no collective in the solver),
  *           1 = rank r reduces slice r of the correspondences + SUM exchange per step.   */
 int sicp_set_exchange(sicp_ctx *ctx, sicp_exchange_fn fn, void *user, int rank, int world, int gn_shard);
+
+/* Reduction used after the all-gather, exposed for tests: gathered = [world][Q][5] records
+ * (d2, idx as int64 bits, x, y, z); outputs the lexicographic (d2, idx) minimum per query over the
+ * records with idx >= 0 (idx -1 / d2 +inf / xyz 0 when none).  Host-or-device pointers. */
+int sicp_lexmin_gathered(sicp_ctx *ctx, const double *gathered, int world, int64_t Q,
+                         double *d2_out, int64_t *idx_out, double *xyz_out);
 
 /* ---- kernel timing (HIP events on the library's own stream) -------------------------- */
 #define SICP_K_KNN1     0   /* brute-force 1-NN scan (dominant kernel)  */

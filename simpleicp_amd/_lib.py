@@ -16,7 +16,7 @@ LIB_PATH = PKG / "libsimpleicp_hip.so"
 
 FIX, MOV = 0, 1
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_TOO_FEW, ERR_NUMERIC, ERR_EXCHANGE = 0, -1, -2, -3, -4, -5, -6
-XCHG_BEST_MATCH, XCHG_SUM_F64 = 1, 2
+XCHG_ALLGATHER_F64, XCHG_SUM_F64 = 1, 2
 K_KNN1, K_KNNK, K_NORMALEQ, K_SELECT = 0, 1, 2, 3
 KERNEL_NAMES = {K_KNN1: "knn1_scan", K_KNNK: "knnk_scan", K_NORMALEQ: "normal_eq", K_SELECT: "reject_select"}
 
@@ -25,7 +25,7 @@ EXPORTS = [
     "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_size", "sicp_cloud_transform",
     "sicp_cloud_download", "sicp_knn", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
-    "sicp_set_exchange", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get",
+    "sicp_set_exchange", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get",
 ]
 
 
@@ -91,6 +91,7 @@ def load():
     L.sicp_icp_normal_equations.argtypes = [vp, vp, vp]
     L.sicp_params_to_H.argtypes = [vp, vp]
     L.sicp_set_exchange.argtypes = [vp, EXCHANGE_FN, vp, cint, cint, cint]
+    L.sicp_lexmin_gathered.argtypes = [vp, vp, cint, i64, vp, vp, vp]
     L.sicp_timing_enable.argtypes = [vp, cint]
     L.sicp_timing_reset.argtypes = [vp]
     L.sicp_timing_get.argtypes = [vp, cint, C.POINTER(dbl), C.POINTER(i64)]
@@ -272,6 +273,15 @@ class Context:
                     return 1
             self._cb = EXCHANGE_FN(tramp)
         self._chk(self._L.sicp_set_exchange(self._h, self._cb, None, int(rank), int(world), int(bool(gn_shard))))
+
+    def lexmin_gathered(self, gathered):
+        """gathered: (world, Q, 5) float64 records (d2, idx bits, x, y, z) -> (d2, idx, xyz)."""
+        g = _f64(gathered)
+        world, Q, five = g.shape
+        assert five == 5
+        d2, idx, xyz = np.empty(Q), np.empty(Q, np.int64), np.empty((Q, 3))
+        self._chk(self._L.sicp_lexmin_gathered(self._h, _ptr(g), world, Q, _ptr(d2), _ptr(idx), _ptr(xyz)))
+        return d2, idx, xyz
 
     # -- timing --
     def timing_enable(self, on=True):

@@ -178,6 +178,7 @@ struct sicp_ctx {
     DevBuf<double> floor_d2;
     DevBuf<uint32_t> floor_idx;
     DevBuf<double> bound;          // per-query upper bound of the NN distance (filtered scan)
+    DevBuf<double> x_send, x_recv; // exchange records: [Q][5] and [world][Q][5]
     int fs_blocks_per_cu[2] = {0, 0};   // occupancy of k_knn1_fscan<128>, <256>
     int knn1_mode = 0;             // SICP_KNN1 = exact | filter | grid: force one 1-NN flavour (A/B + tests); 0 = auto
     DevBuf<uint32_t> g_keys, g_vals, g_keys2, g_counts;   // grid build scratch
@@ -243,6 +244,23 @@ struct Timed {
         c->pending.push_back(ev);
     }
 };
+
+// job-wide winner per query: pack (d2, idx, xyz) records, all-gather through the host's callback
+// (torch.distributed over RCCL), reduce lexicographically on the device -- one collective per call
+int exchange_best(sicp_ctx *c, double *d2, int64_t *idx, double *p2, long Q)
+{
+    if (!c->xfn) return SICP_OK;
+    CHK(c->x_send.reserve((size_t)5 * Q));
+    CHK(c->x_recv.reserve((size_t)5 * Q * c->world));
+    launch_pack_best(c->stream, d2, idx, p2, Q, c->x_send.p);
+    HIPCHK(hipGetLastError());
+    CHK(sync(c));
+    if (c->xfn(c->xuser, SICP_XCHG_ALLGATHER_F64, c->x_send.p, c->x_recv.p, nullptr, 5 * Q) != 0)
+        return fail(SICP_ERR_EXCHANGE, "exchange callback (ALLGATHER_F64) failed");
+    launch_lexmin_gathered(c->stream, c->x_recv.p, c->world, Q, d2, idx, p2);
+    HIPCHK(hipGetLastError());
+    return SICP_OK;
+}
 
 // how the scanned cloud is cut into chunks so the grid fills 256 CUs several times over
 void plan_chunks(const sicp_ctx *c, long npad, long qblocks, size_t bytes_per_chunk_row, int *chunk_pts, int *nchunks)
@@ -519,7 +537,7 @@ int normal_eq_host(sicp_ctx *c, const double x[6], bool write_resid, bool allow_
     params_to_H12(x, H12);
     euler_dR(x, dR);
     long lo = 0, hi = c->Q;
-    const bool shard = allow_shard && c->world > 1 && c->gn_shard && c->xfn;
+    const bool shard = allow_shard && c->gn_shard && c->xfn;
     if (shard) {
         const long per = (c->Q + c->world - 1) / c->world;
         lo = std::min<long>(c->Q, per * c->rank);
@@ -607,7 +625,7 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     for (auto &cl : c->cloud) { cl.xyz.release(); cl.grid.cell_start.release(); cl.grid.sidx.release(); cl.grid.sxyz.release(); }
     c->g_keys.release(); c->g_vals.release(); c->g_keys2.release(); c->g_counts.release(); c->g_tmp.release();
     c->stage.release(); c->part_d2.release(); c->part_idx.release(); c->kq.release(); c->k_d2.release();
-    c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->q.release(); c->normals.release();
+    c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
     c->resid.release(); c->flag.release(); c->keep.release(); c->small.release(); c->ne_partial.release();
     c->ticket.release();
@@ -710,6 +728,7 @@ SICP_EXPORT int sicp_knn(sicp_ctx *c, int slot, const double *q_xyz, int64_t Q, 
         Xf X;
         if (H) H16_to_Xf(H, &X);
         CHK(knn1_device(c, slot, c->kq.p, Q, qpad, H ? &X : nullptr, max_dist, nullptr, c->k_d2.p, c->k_idx.p, nullptr));
+        CHK(exchange_best(c, c->k_d2.p, c->k_idx.p, nullptr, Q));
     } else {
         CHK(knnk_device(c, slot, c->kq.p, Q, qpad, k, c->k_d2.p, c->k_idx.p));
     }
@@ -797,14 +816,10 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
     Xf X; for (int i = 0; i < 12; ++i) X.m[i] = H12[i];
     CHK(knn1_device(c, SICP_MOV, c->q.p, Q, c->qpad, &X, std::numeric_limits<double>::infinity(),
                     c->have_prev_match ? c->m_p2.p : nullptr, c->m_d2.p, c->m_idx.p, c->m_p2.p));
-    c->have_prev_match = (c->world == 1);   // after an exchange idx -1 rows would carry zeros: keep it simple
-    if (c->world > 1 && c->xfn) {
-        CHK(sync(c));
-        if (c->xfn(c->xuser, SICP_XCHG_BEST_MATCH, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q) != 0)
-            return fail(SICP_ERR_EXCHANGE, "exchange callback (BEST_MATCH) failed");
-    }
+    c->have_prev_match = true;              // (after an exchange: the job-wide winner's coordinates -- still a valid bound)
+    CHK(exchange_best(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
     // ---- small Q: the whole tail of the iteration is ONE single-workgroup launch (sicp_solve.hip) ----
-    const bool sharded_gn = c->world > 1 && c->gn_shard && c->xfn;
+    const bool sharded_gn = c->gn_shard && c->xfn;
     if (Q <= SOLVE_MAX_Q && !sharded_gn && c->solve_mode != 2) {
         SolveArgs A;
         A.H = X;
@@ -1005,6 +1020,31 @@ SICP_EXPORT int sicp_set_exchange(sicp_ctx *c, sicp_exchange_fn fn, void *user, 
     if (world > 1 && !fn) return fail(SICP_ERR_INVALID, "world > 1 needs an exchange callback");
     c->xfn = fn; c->xuser = user; c->rank = rank; c->world = world; c->gn_shard = gn_shard ? 1 : 0;
     return SICP_OK;
+}
+
+SICP_EXPORT int sicp_lexmin_gathered(sicp_ctx *c, const double *gathered, int world, int64_t Q, double *d2_out,
+                                     int64_t *idx_out, double *xyz_out)
+{
+    if (!c || !gathered || !d2_out || !idx_out || world < 1 || Q < 1) return fail(SICP_ERR_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    DevBuf<double> g, d2, xyz; DevBuf<int64_t> idx;
+    int rc = g.reserve((size_t)5 * Q * world);
+    if (rc == SICP_OK) rc = d2.reserve(Q);
+    if (rc == SICP_OK) rc = xyz.reserve((size_t)3 * Q);
+    if (rc == SICP_OK) rc = idx.reserve(Q);
+    auto body = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(g.p, gathered, (size_t)5 * Q * world * sizeof(double), hipMemcpyDefault, c->stream));
+        launch_lexmin_gathered(c->stream, g.p, world, Q, d2.p, idx.p, xyz.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(d2_out, d2.p, (size_t)Q * sizeof(double), hipMemcpyDefault, c->stream));
+        HIPCHK(hipMemcpyAsync(idx_out, idx.p, (size_t)Q * sizeof(int64_t), hipMemcpyDefault, c->stream));
+        if (xyz_out) HIPCHK(hipMemcpyAsync(xyz_out, xyz.p, (size_t)3 * Q * sizeof(double), hipMemcpyDefault, c->stream));
+        return sync(c);
+    };
+    if (rc == SICP_OK) rc = body();
+    (void)hipStreamSynchronize(c->stream);
+    g.release(); d2.release(); xyz.release(); idx.release();
+    return rc;
 }
 
 SICP_EXPORT int sicp_timing_enable(sicp_ctx *c, int on)

@@ -819,9 +819,49 @@ __global__ __launch_bounds__(NE_BLOCK) void k_normal_eq(
 }
 
 // ------------------------------------------------------------------------------------
+// multi-GPU exchange helpers: per-query records (d2, idx bits, x, y, z) <-> job-wide winner
+// ------------------------------------------------------------------------------------
+__global__ void k_pack_best(const double *__restrict__ d2, const int64_t *__restrict__ idx,
+                            const double *__restrict__ p2, long Q, double *__restrict__ rec)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    rec[5 * q] = d2[q];
+    rec[5 * q + 1] = __longlong_as_double((long long)idx[q]);
+    rec[5 * q + 2] = p2 ? p2[3 * q] : 0.0; rec[5 * q + 3] = p2 ? p2[3 * q + 1] : 0.0; rec[5 * q + 4] = p2 ? p2[3 * q + 2] : 0.0;
+}
+
+__global__ void k_lexmin_gathered(const double *__restrict__ g, int world, long Q, double *__restrict__ d2,
+                                  int64_t *__restrict__ idx, double *__restrict__ p2)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    double bd = __builtin_inf(), bx = 0, by = 0, bz = 0;
+    int64_t bi = -1;
+    for (int r = 0; r < world; ++r) {
+        const double *rec = g + ((long)r * Q + q) * 5;
+        const double d = rec[0];
+        const int64_t i = (int64_t)__double_as_longlong(rec[1]);
+        if (i >= 0 && (bi < 0 || d < bd || (d == bd && i < bi))) { bd = d; bi = i; bx = rec[2]; by = rec[3]; bz = rec[4]; }
+    }
+    d2[q] = bi >= 0 ? bd : __builtin_inf();
+    idx[q] = bi;
+    if (p2) { p2[3 * q] = bx; p2[3 * q + 1] = by; p2[3 * q + 2] = bz; }
+}
+
+// ------------------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------------------
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
+void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec)
+{
+    hipLaunchKernelGGL(k_pack_best, dim3(cdiv(Q, 256)), dim3(256), 0, s, d2, idx, p2, Q, rec);
+}
+void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, double *d2, int64_t *idx, double *p2)
+{
+    hipLaunchKernelGGL(k_lexmin_gathered, dim3(cdiv(Q, 256)), dim3(256), 0, s, g, world, Q, d2, idx, p2);
+}
 
 void launch_aos_to_soa(hipStream_t s, const double *aos, long n, long npad, double *x, double *y, double *z)
 {

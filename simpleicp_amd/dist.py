@@ -3,11 +3,14 @@
 
 Partitioning: the MOVABLE cloud is sharded by contiguous index range,
 the Q selected fixed points (+ normals, planarity) are replicated.  Per iteration there is ONE
-exchange step after the local brute-force scan:
+exchange step after the local search:
 
     every rank holds, per query, its shard's best (d2, global idx, xyz of that point)
-    -> all_gather of the three arrays (Q * 40 B per rank)
-    -> lexicographic (d2, idx) minimum over ranks  == the single-GPU (d2, idx) rule, bit-exact
+    -> ONE all_gather of the packed records (Q * 40 B per rank; the library packs them and calls
+       back with device pointers, `make_exchange`)
+    -> lexicographic (d2, idx) minimum over ranks (library kernel `k_lexmin_gathered`; the same
+       rule is spelled out in torch ops in `exchange_best_match` below, which the CPU/gloo tests
+       and the GPU test of the kernel use as the reference) == the single-GPU (d2, idx) rule
 
 after which every rank owns the complete correspondence set, so the rejection statistics
 (median / MAD are not sums) need no further collective.  The 6x6 normal-equation reduction can
@@ -30,6 +33,14 @@ def is_distributed() -> bool:
     try:
         import torch.distributed as td
         return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+    except Exception:  # noqa: BLE001
+        return False
+
+
+def is_initialized() -> bool:
+    try:
+        import torch.distributed as td
+        return td.is_available() and td.is_initialized()
     except Exception:  # noqa: BLE001
         return False
 
@@ -94,21 +105,39 @@ def _wrap(ptr, shape, typestr, device):
     return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device)
 
 
+def allgather_into(recv, send, group=None):
+    """recv[(world*count)] <- every rank's send[(count)], rank order."""
+    import torch.distributed as td
+    td.all_gather_into_tensor(recv, send, group=group)
+    return recv
+
+
 def make_exchange(device, group=None):
-    """Callback for Context.set_exchange: receives DEVICE pointers owned by the library."""
+    """Callback for Context.set_exchange.  The library hands over DEVICE pointers it owns (stable
+    across iterations, so the zero-copy tensor views are cached) and reduces the gathered records
+    itself; the host side only issues the collective."""
     import torch
+    import torch.distributed as td
 
     dev = torch.device("cuda", device)
+    world = td.get_world_size(group)
+    views = {}
+
+    def view(ptr, count):
+        key = (ptr, count)
+        t = views.get(key)
+        if t is None:
+            if len(views) > 64:
+                views.clear()
+            t = views[key] = _wrap(ptr, (count,), "<f8", dev)
+        return t
 
     def fn(what, a, b, c, count):
         with torch.cuda.device(dev):
-            if what == _lib.XCHG_BEST_MATCH:
-                d2 = _wrap(a, (count,), "<f8", dev)
-                idx = _wrap(b, (count,), "<i8", dev)
-                xyz = _wrap(c, (count, 3), "<f8", dev)
-                exchange_best_match(d2, idx, xyz, group)
+            if what == _lib.XCHG_ALLGATHER_F64:
+                allgather_into(view(b, count * world), view(a, count), group)
             elif what == _lib.XCHG_SUM_F64:
-                allreduce_sum(_wrap(a, (count,), "<f8", dev), group)
+                allreduce_sum(view(a, count), group)
             else:
                 return 1
             torch.cuda.current_stream(dev).synchronize()

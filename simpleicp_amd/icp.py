@@ -87,7 +87,8 @@ class SimpleICP:
         t_start = time.time()
         pc1, pc2 = self.pc1, self.pc2
         ctx = backend.get_context()
-        sharded = dist.is_distributed()
+        import os
+        sharded = dist.is_distributed() or (os.environ.get("SICP_FORCE_EXCHANGE") == "1" and dist.is_initialized())
 
         if debug_dirpath:
             _log.info(f'Write debug files to directory "{debug_dirpath}"')
@@ -203,18 +204,10 @@ class SimpleICP:
 
     # --------------------------------------------------------------------------------------
     def _nn_in_movable(self, ctx, queries, H, max_dist, sharded):
-        """1-NN index (or -1) of `queries` in the H-transformed movable cloud (all shards)."""
-        idx, d2 = ctx.knn(_lib.MOV, queries, k=1, H=H, max_dist=max_dist)
-        if not sharded:
-            return idx[:, 0]
-        import torch
-        import torch.distributed as td
-        dev = torch.device("cuda", ctx.device) if td.get_backend() == "nccl" else torch.device("cpu")
-        t_d2 = torch.from_numpy(d2[:, 0].copy()).to(dev)
-        t_idx = torch.from_numpy(idx[:, 0].copy()).to(dev)
-        t_xyz = torch.zeros((len(queries), 3), dtype=torch.float64, device=dev)
-        dist.exchange_best_match(t_d2, t_idx, t_xyz)
-        return t_idx.cpu().numpy()
+        """1-NN index (or -1) of `queries` in the H-transformed movable cloud (job-wide when an
+        exchange is registered: the library all-gathers the shard winners itself)."""
+        idx, _ = ctx.knn(_lib.MOV, queries, k=1, H=H, max_dist=max_dist)
+        return idx[:, 0]
 
     @staticmethod
     def _converged(new, old, min_change) -> bool:

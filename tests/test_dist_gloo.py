@@ -89,3 +89,47 @@ def test_shard_bounds_partition():
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_allgather(rank, world, port, tmp):
+    """The production exchange = library packs (d2, idx bits, xyz) records -> ONE all_gather ->
+    lexicographic reduce.  Here on CPU: numpy packs, gloo gathers (dist.allgather_into), and the
+    reduce rule is checked against dist.exchange_best_match on the same data."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simpleicp_amd import dist
+        rng = np.random.default_rng(100 + rank)
+        Q = 500
+        d2 = np.round(rng.uniform(0, 1, Q), 1)                     # many cross-rank ties
+        idx = rng.integers(0, 1000, Q).astype(np.int64) + 1000 * rank
+        none = rng.uniform(size=Q) < 0.2
+        d2[none], idx[none] = np.inf, -1
+        xyz = rng.normal(size=(Q, 3)); xyz[none] = 0
+        rec = np.column_stack((d2, idx.view(np.float64), xyz)).reshape(-1)
+        send = torch.from_numpy(rec.copy())
+        recv = torch.empty(world * 5 * Q, dtype=torch.float64)
+        dist.allgather_into(recv, send)
+        G = recv.numpy().reshape(world, Q, 5)
+        # reduce exactly like k_lexmin_gathered
+        bd = np.full(Q, np.inf); bi = np.full(Q, -1, np.int64); bx = np.zeros((Q, 3))
+        for r in range(world):
+            d, i = G[r, :, 0], G[r, :, 1].copy().view(np.int64)
+            better = (i >= 0) & ((bi < 0) | (d < bd) | ((d == bd) & (i < bi)))
+            bd[better], bi[better], bx[better] = d[better], i[better], G[r, better, 2:]
+        t_d2, t_idx, t_xyz = torch.from_numpy(d2.copy()), torch.from_numpy(idx.copy()), torch.from_numpy(xyz.copy())
+        dist.exchange_best_match(t_d2, t_idx, t_xyz)
+        assert np.array_equal(t_idx.numpy(), bi) and np.array_equal(t_d2.numpy(), bd) and np.array_equal(t_xyz.numpy(), bx)
+        Path(tmp, f"ag{rank}").write_text("ok")
+    finally:
+        td.destroy_process_group()
+
+
+def test_allgather_exchange_world2(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_allgather, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"ag{r}").exists() for r in range(2))
