@@ -8,24 +8,24 @@
 Workload (BASELINE.json configs[3], SURVEY.md section 8d "C4"): synthetic 10M-vs-10M surface
 (two independent samplings, known rigid perturbation), correspondences=1000, neighbors=10,
 float64 like the reference.  A "step" is ONE full ICP iteration through the C ABI
-(`sicp_icp_iterate`: fused transform + brute-force 1-NN match of the Q selected fixed points
-in the movable cloud, point-to-plane distances, planarity + raw-MAD rejection, and the
-Levenberg-Marquardt solve on fused 6x6 normal-equation reductions).  Both clouds, the selected
-points and their normals are resident in HBM before the timed region; the timed region is K
-consecutive iterations of a run that starts at the initial pose (min_change = 0, no early
-stop), bracketed by barrier + device synchronisation, MAX over ranks.
+(`sicp_icp_iterate`: exact 1-NN match of the Q selected fixed points in the movable cloud under
+the current H, point-to-plane distances, planarity + raw-MAD rejection, Levenberg-Marquardt solve
+of the reference's objective).  Both clouds, the selected points and their normals are resident
+in HBM before the timed region; the timed region is K consecutive iterations of a run that starts
+at the initial pose (no early stop), bracketed by barrier + device synchronisation, MAX over ranks.
 
 N > 1: STRONG scaling -- the same 10M-point movable cloud is sharded by index range over the
 ranks (one process per GPU), one all_gather exchange per iteration (simpleicp_amd/dist.py).
+After pruning, one iteration is ~100 us of latency-bound work on ONE GPU, so sharding cannot
+speed it up (the exchange adds latency); the N > 1 numbers document that cost.
 
-One JSON line on stdout (rank 0).  Extra objects:
-  roofline     dominant kernel (k_knn1_scan): algorithmic bytes per launch / HIP-event time.
-               The brute-force scan is FP64-VALU-bound by construction, so the
-               HBM fraction is small; `valu_frac` relates pair evaluations/s to the FP64 vector
-               peak (78.6 TFLOP/s / 8 flop per pair).
-  cpu_baseline the reference's algorithm (oracle/ref_port.py: cKDTree rebuild + query +
-               least_squares per iteration, numpy transforms) on this box's host cores, on a
-               bounded sample (2 iterations of the same workload).
+One JSON line on stdout (rank 0).  Extra objects (all on the same line):
+  roofline             the kernel with the largest share of the step's GPU time, SURVEY 8(d) bytes
+  roofline_match       the 1-NN kernel of the default path (pruned grid search)
+  roofline_bruteforce  the north-star brute-force scan (`k_knn1_fscan`), measured in a short extra
+                       leg on the same inputs: HBM fraction and FP32-VALU fraction
+  cpu_baseline         the reference's algorithm (oracle/ref_port.py: cKDTree rebuild + query +
+                       least_squares per iteration) on this box's host cores, bounded sample
 """
 import argparse
 import json
@@ -40,14 +40,12 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP64_VALU_PEAK_TFLOPS = 78.6     # vector FP64 peak (half the 157.3 TF FP32 vector peak)
-FLOP_PER_PAIR = 8                # 3 sub + 1 mul + 2 fma(=2 flop each) -- SURVEY.md section 8d
+FP32_VALU_PEAK_TFLOPS = 157.3    # vector FP32 peak (spec); v_fma_f32 measures 111 TF (scripts/ubench)
 
 
 def synthetic_pair(n, seed_fix=0, seed_mov=1):
     """SURVEY.md section 8(d) generator (pinned): 10 pts/m^2 surface, independent samplings,
-    centroid removed, movable = H_true^-1 applied.  (Same function as oracle/ref_port.py's,
-    restated here so the product benchmark does not import the oracle for its inputs.)"""
+    centroid removed, movable = H_true^-1 applied."""
     L = np.sqrt(n / 10.0)
 
     def sample(seed):
@@ -70,6 +68,15 @@ def synthetic_pair(n, seed_fix=0, seed_mov=1):
     return np.ascontiguousarray(Xf), np.ascontiguousarray(Xm), H_true
 
 
+def iterate(ctx, n_it, x, obs, ow):
+    evals, last = 0, None
+    for _ in range(n_it):
+        last = ctx.icp_iterate(x, obs, ow, 0.3, 1.0)
+        x = np.array(last.x[:])
+        evals += last.ne_evals
+    return x, evals, last
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +86,7 @@ def main():
     ap.add_argument("--correspondences", type=int, default=1000)
     ap.add_argument("--neighbors", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bruteforce-leg", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=2)
     args = ap.parse_args()
 
@@ -103,7 +111,6 @@ def main():
         td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from simpleicp_amd import _lib, dist
-    from simpleicp_amd.pointcloud import PointCloud   # noqa: F401  (API import check)
 
     N, Q, k = args.points, args.correspondences, args.neighbors
     Xf, Xm, H_true = synthetic_pair(N)
@@ -123,25 +130,14 @@ def main():
     knnk = ctx.timing()["knnk_scan"]
     ctx.icp_setup(sel, normals, planarity)
 
-    obs = np.zeros(6)
-    ow = np.zeros(6)
-
-    def iterate(n_it, x):
-        lm = 0
-        last = None
-        for _ in range(n_it):
-            last = ctx.icp_iterate(x, obs, ow, 0.3, 1.0)
-            x = np.array(last.x[:])
-            lm += last.ne_evals
-        return x, lm, last
-
-    iterate(args.warmup, obs.copy())                  # untimed warm-up from the initial pose
+    obs, ow = np.zeros(6), np.zeros(6)
+    iterate(ctx, args.warmup, obs.copy(), obs, ow)        # untimed warm-up from the initial pose (builds the grid)
     ctx.timing_reset()
     if world > 1:
         td.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    x, ne_evals, last = iterate(args.steps, obs.copy())
+    x, ne_evals, last = iterate(ctx, args.steps, obs.copy(), obs, ow)
     torch.cuda.synchronize()
     if world > 1:
         td.barrier()
@@ -152,19 +148,46 @@ def main():
         elapsed = float(t.item())
 
     timing = ctx.timing()
+    match_kernel = ctx.last_match_kernel()
     if rank != 0:
         if world > 1:
             td.destroy_process_group()
         return
 
     H = _lib.params_to_H(x)
-    scan = timing["knn1_scan"]
-    scan_ms = scan["ms"] / max(1, scan["launches"])
-    n_local = hi - lo
-    bytes_alg = n_local * 24 + Q * (24 + 16)           # read the shard once + queries, write (d2, idx)
-    pairs = n_local * Q
-    achieved = bytes_alg / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    pair_rate = pairs / (scan_ms * 1e-3) if scan_ms > 0 else 0.0
+    n_local, nq = hi - lo, len(sel)
+    avg = {kname: v["ms"] / max(1, v["launches"]) for kname, v in timing.items()}
+    match_ms, solve_ms = avg["match"], avg["solve"]
+    fused = nq <= 2048
+    # SURVEY 8(d) algorithmic bytes per launch
+    bytes_match = n_local * 24 + nq * (24 + 16)                      # read the searched cloud once + queries + (idx, d2)
+    evals_per_it = ne_evals / args.steps
+    bytes_solve = int(last.n_kept) * 72 * evals_per_it + nq * 8 * 3  # 72 B/correspondence/GN evaluation + median/MAD passes
+    pmc = {}
+    pmc_file = ROOT / "profiles" / "latest_pmc.json"
+    if pmc_file.exists():
+        pmc = json.loads(pmc_file.read_text())
+
+    def roof(kernel, ms, bytes_alg, note, extra=None):
+        ach = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "traffic": pmc.get(kernel), "kernel": kernel, "avg_ms": ms, "bytes_alg_per_launch": int(bytes_alg),
+             "note": note}
+        if extra:
+            d.update(extra)
+        return d
+
+    r_match = roof(match_kernel, match_ms, bytes_match,
+                   "exact 1-NN on a static uniform grid: only the cells inside the bound ball are read, so measured "
+                   "traffic is far BELOW the brute-force algorithmic bytes (pruning); wave-per-query, latency-bound"
+                   if match_kernel == "k_grid_nn" else
+                   "brute-force Q x N scan: VALU-bound by construction (SURVEY 8d), cloud read once")
+    r_solve = roof("k_icp_solve" if fused else "k_normal_eq", solve_ms, bytes_solve,
+                   "everything after the match in ONE single-workgroup launch (distances, MAD rejection, LM with "
+                   "device-side 6x6 solves): ~1000 correspondences = latency-bound on one CU by design, not bandwidth"
+                   if fused else "fused residual + 6x6 normal-equation reduction, 72 B/correspondence")
+    dominant = r_solve if solve_ms * (1 if fused else evals_per_it) >= match_ms else r_match
+
     out = {
         "metric": "ICP iterations/sec (kNN correspondences/sec in `correspondences_per_s`), 10M-vs-10M pts",
         "value": args.steps / elapsed,
@@ -179,32 +202,65 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"C4 synthetic {N}-vs-{N} surface (SURVEY 8d generator), correspondences={Q}, "
-                               f"neighbors={k}, brute-force exact kNN",
-                   "n_fixed": N, "n_movable": N, "correspondences": int(len(sel)), "neighbors": k,
+                               f"neighbors={k}, exact 1-NN (bit-identical to brute force)",
+                   "n_fixed": N, "n_movable": N, "correspondences": nq, "neighbors": k,
                    "parallelism": f"movable-cloud index shards x{world}, queries replicated"},
-        "correspondences_per_s": len(sel) * args.steps / elapsed,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_knn1_scan", "avg_ms": scan_ms, "launches": scan["launches"],
-                     "bytes_alg_per_launch": bytes_alg,
-                     "pair_evals_per_s": pair_rate,
-                     "valu_frac": pair_rate * FLOP_PER_PAIR / (FP64_VALU_PEAK_TFLOPS * 1e12),
-                     "note": "brute-force Q x N scan is FP64-VALU-bound (8 flop/pair, >30 queries per pass); "
-                             "HBM fraction is small by construction, see valu_frac"},
-        "kernels": {name: {"avg_ms": v["ms"] / max(1, v["launches"]), "launches": v["launches"]}
-                    for name, v in timing.items()},
-        "normals": {"seconds": normals_s, "knnk_scan_ms": knnk["ms"], "pairs": int(N) * len(sel)},
-        "solver": {"normal_eq_reductions_per_iteration": ne_evals / args.steps,
-                   "final_n_kept": int(last.n_kept), "final_res_std": last.res_std},
+        "correspondences_per_s": nq * args.steps / elapsed,
+        "roofline": dominant,
+        "roofline_match": r_match,
+        "kernels": {name: {"avg_ms": avg[name], "launches": timing[name]["launches"]} for name in timing},
+        "gpu_ms_per_step": match_ms + solve_ms * (1 if fused else evals_per_it),
+        "normals": {"seconds": normals_s, "knnk_scan_ms": knnk["ms"], "pairs": int(N) * nq},
+        "solver": {"normal_eq_evaluations_per_iteration": evals_per_it, "final_n_kept": int(last.n_kept),
+                   "final_res_std": last.res_std},
         "accuracy": {"max_abs_H_minus_H_true": float(np.abs(H - H_true).max())},
         "device": ctx.device_name(),
     }
 
-    if not args.no_cpu_baseline and world == 1:
+    if world == 1 and not args.no_bruteforce_leg:
+        out["roofline_bruteforce"] = bruteforce_leg(local_rank, Xf, Xm, sel, normals, planarity, x, pmc)
+    if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(Xf, Xm, sel, normals, planarity, args.cpu_iterations)
     print(json.dumps(out), flush=True)
     if world > 1:
         td.destroy_process_group()
+
+
+def bruteforce_leg(device, Xf, Xm, sel, normals, planarity, x_ref, pmc):
+    """The north-star kernel: brute-force scan (FP32 conservative filter + exact FP64 verification) of the
+    same Q x N problem, 6 iterations; also checks that it lands on the same estimate as the default path."""
+    from simpleicp_amd import _lib
+    os.environ["SICP_KNN1"] = "filter"
+    try:
+        ctx = _lib.Context(device)
+    finally:
+        del os.environ["SICP_KNN1"]
+    ctx.upload(_lib.FIX, Xf)
+    ctx.upload(_lib.MOV, Xm)
+    ctx.icp_setup(sel, normals, planarity)
+    obs, ow = np.zeros(6), np.zeros(6)
+    iterate(ctx, 2, obs.copy(), obs, ow)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    x, _, _ = iterate(ctx, 6, obs.copy(), obs, ow)
+    dt = time.perf_counter() - t0
+    tm = ctx.timing()["match"]
+    ms = tm["ms"] / max(1, tm["launches"])
+    n, q = len(Xm), len(sel)
+    bytes_alg = n * 24 + q * 40
+    pairs = n * q
+    ach = bytes_alg / (ms * 1e-3) / 1e9
+    kern = ctx.last_match_kernel()
+    ctx.close()
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": pmc.get(kern), "kernel": kern, "avg_ms": ms, "bytes_alg_per_launch": bytes_alg,
+            "pair_evals_per_s": pairs / (ms * 1e-3),
+            "valu_frac": pairs * 6 / (ms * 1e-3) / (FP32_VALU_PEAK_TFLOPS * 1e12),
+            "iterations_per_s": 6 / dt,
+            "note": "brute-force Q x N scan is VALU-bound by construction (SURVEY 8d): 3 v_fma_f32 + 1/2 v_min3 per pair "
+                    "(6 flop/pair against the 157.3 TF FP32 vector peak; v_fma_f32 alone measures 111 TF), exact FP64 "
+                    "re-evaluation of the few passing pairs; the cloud is read from HBM once per 1024 queries"}
 
 
 def cpu_baseline(Xf, Xm, sel, normals, planarity, iterations):

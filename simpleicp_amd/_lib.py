@@ -18,14 +18,15 @@ FIX, MOV = 0, 1
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_TOO_FEW, ERR_NUMERIC, ERR_EXCHANGE = 0, -1, -2, -3, -4, -5, -6
 XCHG_ALLGATHER_F64, XCHG_SUM_F64 = 1, 2
 K_KNN1, K_KNNK, K_NORMALEQ, K_SELECT = 0, 1, 2, 3
-KERNEL_NAMES = {K_KNN1: "knn1_scan", K_KNNK: "knnk_scan", K_NORMALEQ: "normal_eq", K_SELECT: "reject_select"}
+KERNEL_NAMES = {K_KNN1: "match", K_KNNK: "knnk_scan", K_NORMALEQ: "solve", K_SELECT: "reject_select"}
+MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn"}
 
 EXPORTS = [
     "sicp_abi_version", "sicp_last_error", "sicp_device_count", "sicp_ctx_create", "sicp_ctx_destroy",
     "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_size", "sicp_cloud_transform",
     "sicp_cloud_download", "sicp_knn", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
-    "sicp_set_exchange", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get",
+    "sicp_set_exchange", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_last_match_kernel",
 ]
 
 
@@ -94,6 +95,7 @@ def load():
     L.sicp_lexmin_gathered.argtypes = [vp, vp, cint, i64, vp, vp, vp]
     L.sicp_timing_enable.argtypes = [vp, cint]
     L.sicp_timing_reset.argtypes = [vp]
+    L.sicp_last_match_kernel.argtypes = [vp, C.POINTER(cint)]
     L.sicp_timing_get.argtypes = [vp, cint, C.POINTER(dbl), C.POINTER(i64)]
     for name in EXPORTS:
         if name != "sicp_last_error":
@@ -289,6 +291,11 @@ class Context:
 
     def timing_reset(self):
         self._chk(self._L.sicp_timing_reset(self._h))
+
+    def last_match_kernel(self):
+        k = C.c_int()
+        self._chk(self._L.sicp_last_match_kernel(self._h, C.byref(k)))
+        return MATCH_KERNELS[k.value]
 
     def timing(self):
         out = {}

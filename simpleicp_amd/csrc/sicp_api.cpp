@@ -184,6 +184,7 @@ struct sicp_ctx {
     DevBuf<uint32_t> g_keys, g_vals, g_keys2, g_counts;   // grid build scratch
     DevBuf<unsigned char> g_tmp;
     bool have_prev_match = false;  // m_p2 holds last iteration's winners (bound source)
+    int last_match_kernel = 0;     // 0 exact scan, 1 filtered scan, 2 grid
     // ICP state (selected fixed points and per-iteration products)
     int64_t Q = 0, qpad = 0;
     DevBuf<double> q;              // qx|qy|qz [qpad]
@@ -433,6 +434,7 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
     if (rigid && (c->knn1_mode == 3 || (c->knn1_mode == 0 && big))) {
         CHK(grid_build(c, slot));
         Grid &gr = cl.grid;
+        c->last_match_kernel = 2;
         {
             Timed t(c, SICP_K_KNN1);
             launch_grid_nn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, prev_p2, gr.g, gr.cell_start.p, gr.sxyz.p,
@@ -445,6 +447,7 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
     const bool small = cl.n <= 262144;                       // launch-bound anyway: one exact pass
     const bool filter_ok = std::isfinite(rmax_t) && rmax_t < 1e18;   // squares must fit float32
     if (c->knn1_mode == 1 || (small && c->knn1_mode != 2) || !filter_ok) {
+        c->last_match_kernel = 0;
         const long qblocks = (Q + KNN_BLOCK * KNN1_R - 1) / (KNN_BLOCK * KNN1_R);
         long want = std::max<long>(1, (8L * cus + qblocks - 1) / qblocks);
         want = std::min(want, tiles);
@@ -464,6 +467,7 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
     }
 
     // ---- bound ----
+    c->last_match_kernel = 1;
     CHK(c->bound.reserve(qpad));
     if (prev_p2) {
         launch_bound_prev(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, prev_p2, Q, qpad, *H, c->bound.p);
@@ -1051,6 +1055,12 @@ SICP_EXPORT int sicp_timing_enable(sicp_ctx *c, int on)
 {
     if (!c) return fail(SICP_ERR_INVALID, "null ctx");
     c->timing = on != 0;
+    return SICP_OK;
+}
+SICP_EXPORT int sicp_last_match_kernel(sicp_ctx *c, int *kind_out)
+{
+    if (!c || !kind_out) return fail(SICP_ERR_INVALID, "null argument");
+    *kind_out = c->last_match_kernel;
     return SICP_OK;
 }
 SICP_EXPORT int sicp_timing_reset(sicp_ctx *c)
