@@ -507,6 +507,18 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
 int knnk_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, int k, double *d2_out, int64_t *idx_out)
 {
     Cloud &cl = c->cloud[slot];
+    const bool big = cl.n > 65536 || (double)cl.n * (double)Q > 1.0e9;
+    if (c->knn1_mode == 3 || (c->knn1_mode == 0 && big)) {     // pruned search on the slot's grid
+        CHK(grid_build(c, slot));
+        Grid &gr = cl.grid;
+        {
+            Timed t(c, SICP_K_KNNK);
+            launch_grid_knn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, k, gr.g, gr.cell_start.p, gr.sxyz.p,
+                            gr.sxyz.p + cl.n, gr.sxyz.p + 2 * cl.n, gr.sidx.p, cl.rmax, cl.idx_base, d2_out, idx_out);
+        }
+        HIPCHK(hipGetLastError());
+        return SICP_OK;
+    }
     int done = 0;
     bool floor_valid = false;
     while (done < k) {

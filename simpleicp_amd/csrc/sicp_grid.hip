@@ -216,6 +216,100 @@ __global__ __launch_bounds__(256) void k_grid_nn(
 }
 
 // ------------------------------------------------------------------------------------
+// k nearest neighbours on the grid (estimate_normals, pointcloud.py:185-186): one wave per query,
+// cloud in its own frame (no transform).  The ball radius grows until its cells hold >= k points
+// and the k-th distance found fits inside the ball; neighbours are then extracted one per round
+// as the lexicographic (d2, original index) minimum above the previous one -- k rounds over a few
+// hundred L2-resident candidates, no per-lane lists, any k.  Same answer as the brute-force k-NN.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grid_knn(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, long Q, int k,
+    GridGeom G, const uint32_t *__restrict__ cell_start, const double *__restrict__ sx,
+    const double *__restrict__ sy, const double *__restrict__ sz, const uint32_t *__restrict__ sidx,
+    double rmax, int64_t idx_base, double *__restrict__ d2_out, int64_t *__restrict__ idx_out)
+{
+    const int lane = threadIdx.x & 63;
+    const long q = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const double ax = qx[q], ay = qy[q], az = qz[q];
+    const double scale = rmax + sqrt(fma(az, az, fma(ay, ay, ax * ax))) + 1.0;
+    const double slack = 1e-12 * scale;
+    const double c3[3] = {ax, ay, az};
+    double r = 0.5 * G.h;
+    bool final_pass = false;
+    for (int pass = 0; pass < 80; ++pass) {
+        int lo[3], hi[3];
+        bool all = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double fl = floor((c3[a] - r - G.mn[a]) * G.inv_h - 1e-6);
+            const double fh = floor((c3[a] + r - G.mn[a]) * G.inv_h + 1e-6);
+            lo[a] = fl < 0.0 ? 0 : (fl > (double)(G.dim[a] - 1) ? G.dim[a] - 1 : (int)fl);
+            hi[a] = fh < 0.0 ? 0 : (fh > (double)(G.dim[a] - 1) ? G.dim[a] - 1 : (int)fh);
+            all = all && (fl <= 0.0) && (fh >= (double)(G.dim[a] - 1));
+        }
+        const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
+        const long nrows = (long)ny * nz;
+        // how many points do these cells hold?
+        unsigned long long cnt = 0;
+        for (long rr = lane; rr < nrows; rr += 64) {
+            const int cy = lo[1] + (int)(rr % ny), cz = lo[2] + (int)(rr / ny);
+            const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
+            cnt += cell_start[row + hi[0] + 1] - cell_start[row + lo[0]];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (cnt < (unsigned long long)k && !all) { r *= 2.0; continue; }
+
+        // k extraction rounds over the candidate cells
+        double fd = -1.0; uint32_t fi = 0;                 // exclusive lexicographic floor
+        bool first = true;
+        double dk = __builtin_inf();
+        for (int j = 0; j < k; ++j) {
+            double best = __builtin_inf(); uint32_t bidx = 0xffffffffu;
+            for (long rr = 0; rr < nrows; ++rr) {
+                const int cy = lo[1] + (int)(rr % ny), cz = lo[2] + (int)(rr / ny);
+                const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
+                const uint32_t b = cell_start[row + lo[0]], e = cell_start[row + hi[0] + 1];
+                for (uint32_t i = b + lane; i < e; i += 64) {
+                    const double dx = sx[i] - ax, dy = sy[i] - ay, dz = sz[i] - az;
+                    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                    if (d2 <= best && (first || d2 >= fd)) {
+                        const uint32_t oi = sidx[i];
+                        const bool above = first || d2 > fd || oi > fi;
+                        if (above && (d2 < best || oi < bidx)) { best = d2; bidx = oi; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double od = __shfl_xor(best, off, 64);
+                const uint32_t oi = __shfl_xor(bidx, off, 64);
+                if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; }
+            }
+            const bool ok = bidx != 0xffffffffu;
+            if (final_pass || all) {
+                if (lane == 0) {
+                    idx_out[q * k + j] = ok ? idx_base + (int64_t)bidx : (int64_t)-1;
+                    if (d2_out) d2_out[q * k + j] = ok ? best : __builtin_inf();
+                }
+            }
+            if (!ok) { dk = __builtin_inf(); fd = __builtin_inf(); fi = 0xffffffffu; first = false; continue; }
+            fd = best; fi = bidx; first = false; dk = best;
+        }
+        if (final_pass || all) break;
+        const double r_eff = (r - slack) / (1.0 + 1e-12);
+        if (dk < __builtin_inf() && sqrt(dk) <= r_eff) {
+            // the k-th neighbour lies inside the ball: nothing outside can enter the list; emit
+            final_pass = true;                              // same r, this time writing the outputs
+            continue;
+        }
+        r = (dk < __builtin_inf()) ? sqrt(dk) * (1.0 + 1e-12) + slack : 2.0 * r;
+        final_pass = dk < __builtin_inf();
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
@@ -283,6 +377,14 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
     else
         hipLaunchKernelGGL((k_grid_nn<false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, sx, sy, sz, sidx, id,
                            id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out);
+}
+
+void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int k, const GridGeom &G,
+                     const uint32_t *cell_start, const double *sx, const double *sy, const double *sz, const uint32_t *sidx,
+                     double rmax, int64_t idx_base, double *d2_out, int64_t *idx_out)
+{
+    hipLaunchKernelGGL(k_grid_knn, dim3(cdiv(Q, 4)), dim3(256), 0, s, qx, qy, qz, Q, k, G, cell_start, sx, sy, sz, sidx,
+                       rmax, idx_base, d2_out, idx_out);
 }
 
 }  // namespace sicp

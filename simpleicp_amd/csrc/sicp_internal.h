@@ -57,6 +57,9 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
 
 void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec);
 void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, double *d2, int64_t *idx, double *p2);
+void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int k, const GridGeom &G,
+                     const uint32_t *cell_start, const double *sx, const double *sy, const double *sz, const uint32_t *sidx,
+                     double rmax, int64_t idx_base, double *d2_out, int64_t *idx_out);
 void launch_aos_to_soa(hipStream_t s, const double *aos, long n, long npad, double *x, double *y, double *z);
 void launch_soa_to_aos(hipStream_t s, const double *x, const double *y, const double *z, long n, double *aos);
 void launch_transform(hipStream_t s, double *x, double *y, double *z, long n, const Xf &H);

@@ -252,3 +252,21 @@ def test_filtered_iteration_uses_previous_match_bound(ctx_filter, clouds):
         assert np.array_equal(idx, o["nn"]) and np.array_equal(dist, o["dist"]) and np.array_equal(keep, o["keep"])
         x = np.array(R.x[:])
         assert np.abs(x - o["x"]).max() < 1e-11
+
+
+@pytest.mark.parametrize("n,q,k", [(20, 5, 2), (5000, 300, 10), (30_000, 500, 40), (3000, 64, 70), (100, 3, 100),
+                                   (200_000, 1000, 10), (50, 4, 60)])
+def test_grid_knn_equals_brute_force(ctx_filter, n, q, k):
+    """k-NN on the grid (forced by SICP_KNN1=grid; the `filter` context runs the brute-force kernels)."""
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(k + n)
+    if n >= 100_000:
+        P = _surface(n, 9)
+    else:
+        P = np.round(rng.uniform(-5, 5, (n, 3)), 2)          # quantised: plenty of exact ties
+    Qp = P[rng.choice(n, q, replace=False)]
+    ctx_filter.upload(_lib.FIX, P)
+    idx, d2 = ctx_filter.knn(_lib.FIX, Qp, k=k)
+    ridx, rd2 = orc.knn(P, Qp, k=k)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(d2, rd2)
