@@ -183,6 +183,7 @@ struct sicp_ctx {
     int knn1_mode = 0;             // SICP_KNN1 = exact | filter | grid: force one 1-NN flavour (A/B + tests); 0 = auto
     DevBuf<uint32_t> g_keys, g_vals, g_keys2, g_counts;   // grid build scratch
     DevBuf<unsigned char> g_tmp;
+    DevBuf<unsigned long long> rj_keys;   // sort-based rejection scratch (2Q)
     bool have_prev_match = false;  // m_p2 holds last iteration's winners (bound source)
     int last_match_kernel = 0;     // 0 exact scan, 1 filtered scan, 2 grid
     // ICP state (selected fixed points and per-iteration products)
@@ -639,7 +640,7 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &cl : c->cloud) { cl.xyz.release(); cl.grid.cell_start.release(); cl.grid.sidx.release(); cl.grid.sxyz.release(); }
-    c->g_keys.release(); c->g_vals.release(); c->g_keys2.release(); c->g_counts.release(); c->g_tmp.release();
+    c->g_keys.release(); c->g_vals.release(); c->g_keys2.release(); c->g_counts.release(); c->g_tmp.release(); c->rj_keys.release();
     c->stage.release(); c->part_d2.release(); c->part_idx.release(); c->kq.release(); c->k_d2.release();
     c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
@@ -888,7 +889,18 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
                      c->m_idx.p, Q, X, (float)P->min_planarity, c->dist.p, c->flag.p);
     {
         Timed t(c, SICP_K_SELECT);
-        launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p);
+        if (Q > 16384) {
+            // one workgroup cannot chew a million distances: exact order statistics by device radix sort
+            const size_t tb = reject_sort_temp_bytes(Q);
+            CHK(c->g_tmp.reserve(tb + 256));
+            CHK(c->rj_keys.reserve((size_t)2 * Q));
+            unsigned long long *small = (unsigned long long *)(c->small.p + 56);
+            if (reject_by_sort(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->rj_keys.p, c->rj_keys.p + Q,
+                               c->g_tmp.p, tb, small) != hipSuccess)
+                return fail(SICP_ERR_HIP, "sort-based rejection failed");
+        } else {
+            launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p);
+        }
     }
     launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4);
     HIPCHK(hipGetLastError());

@@ -20,6 +20,8 @@
 
 namespace sicp {
 
+static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
 __device__ __forceinline__ unsigned long long okey(double v)
 {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -310,9 +312,100 @@ __global__ __launch_bounds__(256) void k_grid_knn(
 }
 
 // ------------------------------------------------------------------------------------
+// median / raw-MAD rejection for LARGE Q (corrpts.py:165-188): exact order statistics by two
+// device radix sorts (hipCUB) of the order-preserving uint64 image of the distances, everything
+// chained on the stream without a host round trip.  out4 = (m, median, mad, n_kept) like k_reject.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double oval64(unsigned long long k)
+{
+    const unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// keys of flagged distances (or of |d - med| when center != null), ~0 for the rest; counts the flagged
+__global__ void k_reject_keys(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
+                              const double *__restrict__ center, unsigned long long *__restrict__ keys,
+                              unsigned long long *__restrict__ count)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = 0;
+    if (i < Q) {
+        const bool f = flag[i] != 0;
+        const double v = center ? fabs(dist[i] - center[0]) : dist[i];
+        keys[i] = f ? okey(v) : ~0ull;
+        c = f ? 1 : 0;
+    }
+    if (count) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+    }
+}
+
+// np.median of the m smallest sorted keys -> dst[0]
+__global__ void k_reject_median(const unsigned long long *__restrict__ sorted, const unsigned long long *__restrict__ count,
+                                double *__restrict__ dst)
+{
+    const long m = (long)count[0];
+    dst[0] = m > 0 ? (oval64(sorted[(m - 1) / 2]) + oval64(sorted[m / 2])) / 2.0 : __builtin_nan("");
+}
+
+__global__ void k_reject_keep(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
+                              const double *__restrict__ med_mad, uint8_t *__restrict__ keep,
+                              unsigned long long *__restrict__ kept)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = 0;
+    if (i < Q) {
+        const uint8_t k = (flag[i] && fabs(dist[i] - med_mad[0]) <= 3 * med_mad[1]) ? 1 : 0;
+        keep[i] = k; c = k;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(kept, c);
+}
+
+__global__ void k_reject_finish(const unsigned long long *__restrict__ counts /*[0]=m,[1]=kept*/,
+                                const double *__restrict__ med_mad, double *__restrict__ out4)
+{
+    out4[0] = (double)counts[0]; out4[1] = med_mad[0]; out4[2] = med_mad[1]; out4[3] = (double)counts[1];
+}
+
+size_t reject_sort_temp_bytes(long Q)
+{
+    size_t t = 0;
+    unsigned long long *p = nullptr;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, t, p, p, (int)Q, 0, 64, (hipStream_t)0);
+    return t;
+}
+
+// scratch: keys_a, keys_b (Q u64 each), tmp (reject_sort_temp_bytes), small (4 u64/doubles: m, kept, med, mad)
+hipError_t reject_by_sort(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
+                          unsigned long long *keys_a, unsigned long long *keys_b, void *tmp, size_t tmp_bytes,
+                          unsigned long long *small)
+{
+    unsigned long long *counts = small;            // [0] m, [1] kept
+    double *med_mad = (double *)(small + 2);       // [0] median, [1] mad
+    hipError_t e = hipMemsetAsync(small, 0, 4 * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    const unsigned g = cdiv(Q, 256);
+    hipLaunchKernelGGL(k_reject_keys, dim3(g), dim3(256), 0, s, dist, flag, Q, (const double *)nullptr, keys_a, counts);
+    e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys_a, keys_b, (int)Q, 0, 64, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_reject_median, dim3(1), dim3(1), 0, s, keys_b, counts, med_mad);
+    hipLaunchKernelGGL(k_reject_keys, dim3(g), dim3(256), 0, s, dist, flag, Q, (const double *)med_mad, keys_a,
+                       (unsigned long long *)nullptr);
+    e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys_a, keys_b, (int)Q, 0, 64, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_reject_median, dim3(1), dim3(1), 0, s, keys_b, counts, med_mad + 1);
+    hipLaunchKernelGGL(k_reject_keep, dim3(g), dim3(256), 0, s, dist, flag, Q, (const double *)med_mad, keep, counts + 1);
+    hipLaunchKernelGGL(k_reject_finish, dim3(1), dim3(1), 0, s, counts, (const double *)med_mad, out4);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------
-static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 
 void launch_bbox(hipStream_t s, const double *x, const double *y, const double *z, long n, unsigned long long *out6)
 {

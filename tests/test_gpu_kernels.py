@@ -270,3 +270,27 @@ def test_grid_knn_equals_brute_force(ctx_filter, n, q, k):
     ridx, rd2 = orc.knn(P, Qp, k=k)
     assert np.array_equal(idx, ridx)
     assert np.array_equal(d2, rd2)
+
+
+def test_large_q_iteration_multi_kernel_path(ctx):
+    """Q > 16384: sort-based rejection + multi-block reductions + host LM must agree with the oracle."""
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(8)
+    n = 60_000
+    P = _surface(n, 21)
+    x_true = np.array([0.002, -0.001, 0.003, 0.05, -0.03, 0.02])
+    Xm = orc.transform(np.linalg.inv(orc.params_to_H(x_true)), P + rng.normal(0, 0.01, P.shape))
+    sel = np.arange(0, n, 2)                                  # Q = 30000
+    ctx.upload(_lib.FIX, P)
+    ctx.upload(_lib.MOV, Xm)
+    nv, pl = ctx.estimate_normals(_lib.FIX, sel, 10)
+    ctx.icp_setup(sel, nv, pl)
+    x = np.zeros(6)
+    for it in range(3):
+        R = ctx.icp_iterate(x, np.zeros(6), np.zeros(6), 0.3, 1.0)
+        o = orc.icp_iteration(Xm, P[sel], nv, pl, x, x, 1.0, np.zeros(6), np.zeros(6), 0.3)
+        idx, dist, keep, resid = ctx.icp_state()
+        assert np.array_equal(idx, o["nn"]) and np.array_equal(dist, o["dist"]) and np.array_equal(keep, o["keep"])
+        assert R.n_kept == o["n"] and R.median == o["median"] and R.mad == o["mad"]
+        x = np.array(R.x[:])
+        assert np.abs(x - o["x"]).max() < 1e-10
