@@ -46,12 +46,22 @@ def run():
     H, X, rbp, res = icp.run(**kw)
     return H, X, res, icp.last_run_info["iterations"]
 H0, X0, r0, it0 = run()                                # no process group: plain single-GPU path
+from simpleicp_amd import backend
+os.environ["SICP_SOLVE"] = "host"; backend.reset_context()
+Hh, Xh, rh, ith = run()                                # multi-kernel tail + host LM (what gn_shard builds on)
+del os.environ["SICP_SOLVE"]; backend.reset_context()
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%(port)d", SICP_FORCE_EXCHANGE="1")
 torch.cuda.set_device(0)
 td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 H1, X1, r1, it1 = run()                                # same job through the exchange (all_gather of 1 rank)
 td.destroy_process_group()
 assert it0 == it1 and np.array_equal(H0, H1) and np.array_equal(X0, X1) and np.array_equal(r0, r1), (H0 - H1)
+assert ith == it0 and np.abs(Hh - H0).max() < 1e-10    # device LM vs host LM: same minimiser
+os.environ["SICP_GN_SHARD"] = "1"
+td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+H2, X2, r2, it2 = run()                                # + sharded 6x6 reduction with a SUM all-reduce per solver step
+td.destroy_process_group()
+assert it2 == ith and np.array_equal(H2, Hh) and np.array_equal(r2, rh), (H2 - Hh)
 print("EXCHANGE_OK", it0)
 '''
 

@@ -118,3 +118,34 @@ def test_exceptions(clouds):
         icp.run(rbp_observed_values=(0, 0, 0))
     with pytest.raises(SimpleICPException, match="finite"):
         icp.run(rbp_observation_weights=(np.inf,) * 6)
+
+
+def test_edge_cases(clouds):
+    """Inputs the reference handles (or rejects) at its API: tiny clouds, Q below 6, identical clouds,
+    k larger than the cloud, selection preserved across runs."""
+    from simpleicp_amd import PointCloud, SimpleICP, SimpleICPException, _lib
+    rng = np.random.default_rng(1)
+    X = np.column_stack((rng.uniform(0, 10, 400), rng.uniform(0, 10, 400), rng.normal(0, 0.01, 400)))
+    # identical clouds: residuals are exactly zero, convergence test sees 0/0 -> 0 % change (simpleicp.py:364-366)
+    icp = SimpleICP(verbose=False)
+    icp.add_point_clouds(PointCloud(X, columns=["x", "y", "z"]), PointCloud(X.copy(), columns=["x", "y", "z"]))
+    H, Xt, rbp, res = icp.run(correspondences=100)
+    assert np.abs(H - np.eye(4)).max() < 1e-12 and np.all(res == 0) and icp.last_run_info["iterations"] == 2
+    # fewer than 6 correspondences -> the reference's exception text (simpleicp.py:209-214)
+    icp = SimpleICP(verbose=False)
+    icp.add_point_clouds(PointCloud(X, columns=["x", "y", "z"]), PointCloud(X + 0.01, columns=["x", "y", "z"]))
+    with pytest.raises(SimpleICPException, match="Too few correspondences"):
+        icp.run(correspondences=5)
+    # neighbors > number of points -> loud error, not garbage
+    pc = PointCloud(X[:8], columns=["x", "y", "z"])
+    with pytest.raises(_lib.BackendError, match="exceeds the number of points"):
+        pc.estimate_normals(20)
+    # standalone operators of the PointCloud mirror
+    pc = PointCloud(X, columns=["x", "y", "z"])
+    pc.select_in_range(X[:50] + 0.001, max_range=0.05)
+    from oracle import orc
+    idx, _ = orc.knn(X[:50] + 0.001, X, k=1, max_dist=0.05)
+    assert np.array_equal(pc.idx_selected, np.flatnonzero(idx[:, 0] >= 0))
+    Hm = orc.params_to_H(np.array([0.1, 0.2, 0.3, 1, 2, 3]))
+    pc.transform_by_H(Hm)
+    assert np.array_equal(pc.X, orc.transform(Hm, X))
