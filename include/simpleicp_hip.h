@@ -173,6 +173,17 @@ int sicp_set_exchange(sicp_ctx *ctx, sicp_exchange_fn fn, void *user, int rank, 
 int sicp_lexmin_gathered(sicp_ctx *ctx, const double *gathered, int world, int64_t Q,
                          double *d2_out, int64_t *idx_out, double *xyz_out);
 
+/* ---- .xyz text I/O (host only, multithreaded) --------------------------- */
+/* What the reference's callers do with np.genfromtxt (python/simpleicp/tests/test_simpleicp.py:102-103)
+ * and PointCloud.write_xyz / CorrPts.write_xyz (pointcloud.py:219-226, corrpts.py:213-237).
+ * Data rows are the lines that start with a number; the first three columns are read.  Values are
+ * parsed with strtod and printed with printf, i.e. identical to Python's float() / "%.3f". */
+int sicp_xyz_count(const char *path, int64_t *rows_out);
+int sicp_xyz_read(const char *path, double *xyz_out, int64_t capacity_rows, int64_t *rows_out, int threads);
+/* decimals >= 0: "%.<decimals>f"; < 0: "%.18e" (np.savetxt default).  header may be NULL. */
+int sicp_xyz_write(const char *path, const double *data, int64_t n, int cols, int decimals,
+                   const char *header, int threads);
+
 /* ---- kernel timing (HIP events on the library's own stream) -------------------------- */
 #define SICP_K_KNN1     0   /* brute-force 1-NN scan (dominant kernel)  */
 #define SICP_K_KNNK     1   /* brute-force k-NN scan                    */

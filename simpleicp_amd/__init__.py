@@ -14,5 +14,7 @@ from .pointcloud import PointCloud, PointCloudException          # noqa: E402
 from .rbp import Parameter, RigidBodyParameters                  # noqa: E402
 from .icp import SimpleICP, SimpleICPException                   # noqa: E402
 
+from . import io                                                 # noqa: E402,F401
+
 __all__ = ["SimpleICP", "SimpleICPException", "PointCloud", "PointCloudException",
            "RigidBodyParameters", "Parameter"]

@@ -27,6 +27,7 @@ EXPORTS = [
     "sicp_cloud_download", "sicp_knn", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
     "sicp_set_exchange", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_last_match_kernel",
+    "sicp_xyz_count", "sicp_xyz_read", "sicp_xyz_write",
 ]
 
 
@@ -96,6 +97,9 @@ def load():
     L.sicp_timing_enable.argtypes = [vp, cint]
     L.sicp_timing_reset.argtypes = [vp]
     L.sicp_last_match_kernel.argtypes = [vp, C.POINTER(cint)]
+    L.sicp_xyz_count.argtypes = [C.c_char_p, C.POINTER(i64)]
+    L.sicp_xyz_read.argtypes = [C.c_char_p, vp, i64, C.POINTER(i64), cint]
+    L.sicp_xyz_write.argtypes = [C.c_char_p, vp, i64, cint, cint, C.c_char_p, cint]
     L.sicp_timing_get.argtypes = [vp, cint, C.POINTER(dbl), C.POINTER(i64)]
     for name in EXPORTS:
         if name != "sicp_last_error":

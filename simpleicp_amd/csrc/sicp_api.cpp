@@ -36,6 +36,22 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+}  // namespace
+
+// error sink for the host-only translation units (sicp_io.cpp)
+int sicp_io_fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+namespace {
+
 #define HIPCHK(expr)                                                                             \
     do {                                                                                         \
         hipError_t e_ = (expr);                                                                  \

@@ -219,7 +219,8 @@ class SimpleICP:
     def _write_cloud(file, X, H):
         Xh = np.column_stack((X, np.ones(len(X))))
         Xt = (H @ Xh.T).T[:, :3]
-        np.savetxt(file, Xt, fmt="%.3f", delimiter=" ", header="//X Y Z", comments="")
+        from . import io
+        io.write_xyz(file, Xt, decimals=3, header="//X Y Z")
 
     @staticmethod
     def _write_correspondences(ctx, file, X_fix, X_mov, sel, H):
@@ -227,8 +228,9 @@ class SimpleICP:
         idx, d, keep, _ = ctx.icp_state(residual=False)
         p2 = X_mov[idx[keep]]
         p2 = (H @ np.column_stack((p2, np.ones(len(p2)))).T).T[:, :3]
-        np.savetxt(file, np.column_stack((X_fix[sel[keep]], p2, d[keep])), delimiter=" ",
-                   header="X1 Y1 Z1 X2 Y2 Z2 point_to_plane_distance", comments="//")
+        from . import io
+        io.write_xyz(file, np.column_stack((X_fix[sel[keep]], p2, d[keep])), decimals=-1,
+                     header="//X1 Y1 Z1 X2 Y2 Z2 point_to_plane_distance")
 
     @staticmethod
     def _log_result(H, rbp):

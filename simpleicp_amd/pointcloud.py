@@ -156,4 +156,5 @@ class PointCloud(pd.DataFrame):
     # ---- I/O (pointcloud.py:219-226) ------------------------------------------------------
     def write_xyz(self, file: Path):
         """CloudCompare-style text file: header `//X Y Z`, 3 decimals."""
-        self[_XYZ].to_csv(file, sep=" ", header=["//X", "Y", "Z"], index=False, float_format="%.3f")
+        from . import io
+        io.write_xyz(file, self.X, decimals=3, header="//X Y Z")     # same bytes as pandas' to_csv(float_format="%.3f")

@@ -12,7 +12,7 @@ from conftest import GOLDEN_CASES, load_golden
 pytestmark = pytest.mark.gpu
 
 
-def _run(name, clouds, inject_normals, verbose=False):
+def _run(name, clouds, inject_normals, verbose=False, **extra):
     from simpleicp_amd import PointCloud, SimpleICP
     g, files, kw = load_golden(name)
     pc_fix = PointCloud(clouds(files[0]), columns=["x", "y", "z"])
@@ -29,7 +29,7 @@ def _run(name, clouds, inject_normals, verbose=False):
         pc_fix["planarity"] = pd.arrays.SparseArray(v)
     icp = SimpleICP(verbose=verbose)
     icp.add_point_clouds(pc_fix, pc_mov)
-    out = icp.run(**kw)
+    out = icp.run(**{**kw, **extra})
     return g, kw, icp, pc_fix, pc_mov, out
 
 
@@ -149,3 +149,23 @@ def test_edge_cases(clouds):
     Hm = orc.params_to_H(np.array([0.1, 0.2, 0.3, 1, 2, 3]))
     pc.transform_by_H(Hm)
     assert np.array_equal(pc.X, orc.transform(Hm, X))
+
+
+def test_debug_dirpath_dumps(tmp_path, clouds):
+    """simpleicp.py:141-143,189-200,216-221,317-320: same file names and formats as the reference."""
+    from simpleicp_amd import PointCloud, SimpleICP, io
+    g, files, kw = load_golden("bunny")
+    _run("bunny", clouds, True, max_iterations=3, debug_dirpath=str(tmp_path / "dbg"))   # reference normals injected
+    names = sorted(p.name for p in (tmp_path / "dbg").iterdir())
+    assert names == ["iteration000_preoptim_correspondences.xyz", "iteration000_preoptim_pcfix.xyz",
+                     "iteration000_preoptim_pcmov.xyz", "iteration001_preoptim_correspondences.xyz",
+                     "iteration001_preoptim_pcmov.xyz", "iteration002_postoptim_pcmov.xyz",
+                     "iteration002_preoptim_correspondences.xyz", "iteration002_preoptim_pcmov.xyz"]
+    head = (tmp_path / "dbg" / "iteration000_preoptim_correspondences.xyz").read_text().splitlines()
+    assert head[0] == "//X1 Y1 Z1 X2 Y2 Z2 point_to_plane_distance" and len(head[1].split()) == 7
+    assert (tmp_path / "dbg" / "iteration000_preoptim_pcfix.xyz").read_text().splitlines()[0] == "//X Y Z"
+    assert io.read_xyz(tmp_path / "dbg" / "iteration002_postoptim_pcmov.xyz").shape == clouds(files[1]).shape
+    # the correspondence dump is what the reference wrote at iteration 0 (same kept set, same %.18e distances)
+    C = np.loadtxt(tmp_path / "dbg" / "iteration000_preoptim_correspondences.xyz", comments="//")
+    assert len(C) == int(g["counts"][0])
+    assert np.array_equal(C[:, 6], g["it000_dist"][np.isin(g["it000_pc1_idx"], g["it000_kept_pc1_idx"])])
