@@ -230,13 +230,8 @@ class Context:
     def icp_iterate(self, x, obs, obs_weight, min_planarity=0.3, distance_weight=1.0, max_lm_steps=0):
         """One iteration; distance_weight None = automatic (simpleicp.py:233-234).  Returns IterResult;
         raises BackendError(code=ERR_TOO_FEW) when fewer than 6 correspondences survive."""
-        P = IterParams()
-        P.x[:] = list(map(float, x))
-        P.obs[:] = list(map(float, obs))
-        P.obs_weight[:] = list(map(float, obs_weight))
-        P.min_planarity = float(min_planarity)
-        P.distance_weight = -1.0 if distance_weight is None else float(distance_weight)
-        P.max_lm_steps = int(max_lm_steps)
+        P = IterParams((C.c_double * 6)(*x), (C.c_double * 6)(*obs), (C.c_double * 6)(*obs_weight),
+                       min_planarity, -1.0 if distance_weight is None else distance_weight, int(max_lm_steps))
         R = IterResult()
         rc = self._L.sicp_icp_iterate(self._h, C.byref(P), C.byref(R))
         if rc != OK:

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -218,6 +219,7 @@ struct sicp_ctx {
     double last_ne[30] = {0};      // normal equations at last_x (fused path caches them)
     bool have_last_ne = false;
     int solve_mode = 0;            // SICP_SOLVE = fused | host (A/B + tests); 0 = auto
+    long solve_seq = 0;            // completion tickets of the fused kernel
     // exchange
     sicp_exchange_fn xfn = nullptr;
     void *xuser = nullptr;
@@ -862,6 +864,7 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
         A.min_planarity = (float)P->min_planarity;
         A.max_steps = P->max_lm_steps > 0 ? (int)P->max_lm_steps : 100;
         A.Q = Q;
+        A.seq = (double)(++c->solve_seq);
         double *d_out = c->h_small + 64;      // pinned + mapped: the kernel's 56 result doubles land on the host directly
         {
             Timed t(c, SICP_K_NORMALEQ);
@@ -869,7 +872,18 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
                              c->m_p2.p, c->m_idx.p, A, c->dist.p, c->flag.p, c->keep.p, c->resid.p, d_out);
         }
         HIPCHK(hipGetLastError());
-        CHK(sync(c));
+        // the kernel publishes a ticket in pinned memory once its results are there: poll it (a few us
+        // sooner than the end-of-kernel signal); fall back to a stream wait if it does not show up
+        {
+            volatile double *flag = c->h_small + 64 + 55;
+            bool seen = false;
+            for (long spin = 0; spin < 4000000L; ++spin) {
+                if (*flag == A.seq) { seen = true; break; }
+                __builtin_ia32_pause();
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (!seen || c->timing) CHK(sync(c));
+        }
         const double *o = c->h_small + 64;
         R->n_queries = Q; R->n_planar = (int64_t)o[0]; R->median = o[1]; R->mad = o[2]; R->n_kept = (int64_t)o[3];
         R->dist_mean = o[4]; R->dist_std = o[5];
@@ -954,7 +968,7 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
         for (int u = 0; u < 6; ++u) g[u] = w * w * ne[21 + u];
         for (int j = 0; j < 6; ++j)
             if (is_observed(ow[j])) { N[j * 6 + j] += ow[j] * ow[j]; g[j] += ow[j] * ow[j] * (x[j] - obs[j]); }
-        bool accepted = false;
+        bool accepted = false, blind = false;
         double xn[6], nen[30], costn = cost, dxmax = 0;
         for (int tries = 0; tries < 40; ++tries) {
             double A[36], b[6];
@@ -967,12 +981,17 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
             std::memcpy(xn, x, sizeof x);
             dxmax = 0;
             for (int u = 0; u < nfree; ++u) { xn[freeidx[u]] += b[u]; dxmax = std::max(dxmax, std::fabs(b[u])); }
+            {
+                double xm = 0; for (int j = 0; j < 6; ++j) xm = std::max(xm, std::fabs(x[j]));
+                if (lambda == 0.0 && dxmax <= 1e-9 * (1.0 + xm)) { blind = true; accepted = true; break; }   // see k_icp_solve
+            }
             CHK(normal_eq_host(c, xn, false, true, nen)); R->ne_evals++;
             costn = objective(nen, w, xn, obs, ow);
             if (costn <= cost * (1 + 1e-12) || dxmax < 1e-15) { accepted = true; break; }
             lambda = lambda > 0 ? lambda * 10 : 1e-6;
         }
         if (!accepted) break;
+        if (blind) { std::memcpy(x, xn, sizeof x); R->lm_steps++; break; }
         std::memcpy(x, xn, sizeof x); std::memcpy(ne, nen, sizeof ne);
         cost = costn;
         lambda = lambda > 0 ? lambda * 0.1 : 0.0;
@@ -985,6 +1004,7 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
 
     // ---- residuals at the optimum (optimization.py:117-124) + their mean/std (simpleicp.py:356-379) ----
     CHK(normal_eq_host(c, x, true, false, ne)); R->ne_evals++;
+    cost = objective(ne, w, x, obs, ow);
     launch_stats(c->stream, c->resid.p, c->keep.p, Q, c->small.p + 4);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_small + 4, c->small.p + 4, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -28,6 +28,7 @@ struct SolveArgs {
     double x0[6], obs[6], ow[6];
     double sc0[6];              // sin, cos of x0[0..2] from the host libm
     double w;                   // distance weight; <= 0 = automatic
+    double seq;                 // completion ticket the kernel publishes in out[55] when everything is written
     float min_planarity;
     int max_steps;
     long Q;

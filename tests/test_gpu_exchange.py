@@ -56,7 +56,7 @@ td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda
 H1, X1, r1, it1 = run()                                # same job through the exchange (all_gather of 1 rank)
 td.destroy_process_group()
 assert it0 == it1 and np.array_equal(H0, H1) and np.array_equal(X0, X1) and np.array_equal(r0, r1), (H0 - H1)
-assert ith == it0 and np.abs(Hh - H0).max() < 1e-10    # device LM vs host LM: same minimiser
+assert ith == it0 and np.abs(Hh - H0).max() < 1e-9     # device LM vs host LM: same minimiser
 os.environ["SICP_GN_SHARD"] = "1"
 td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 H2, X2, r2, it2 = run()                                # + sharded 6x6 reduction with a SUM all-reduce per solver step

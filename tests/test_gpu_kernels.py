@@ -115,7 +115,7 @@ def test_normals_vs_oracle(ctx, name, clouds):
 @pytest.mark.parametrize("name", ["dragon", "bunny", "multisensor", "webots", "bunny_obs"])
 def test_iteration_vs_oracle(ctx, name, clouds):
     """Whole iterations (match -> reject -> LM on fused reductions) against the oracle, fed with
-    the reference's normals; indices / masks bit-exact, parameters to 1e-11."""
+    the reference's normals; indices / masks bit-exact, parameters to 1e-9."""
     from simpleicp_amd import _lib
     g, files, kw = load_golden(name)
     Xf, Xm = clouds(files[0]), clouds(files[1])
@@ -137,7 +137,7 @@ def test_iteration_vs_oracle(ctx, name, clouds):
         assert np.array_equal(keep, o["keep"])
         assert R.n_kept == o["n"] and R.median == o["median"] and R.mad == o["mad"]
         xg = np.array(R.x[:])
-        assert np.abs(xg - o["x"]).max() < 1e-11
+        assert np.abs(xg - o["x"]).max() < 1e-9     # solver stops once an undamped step is < 1e-9 (oracle iterates to 1e-13)
         assert np.allclose(resid[keep], orc.residuals(xg, Xf[sel], g["normals"], Xm[idx], keep), rtol=0, atol=1e-13)   # device sin/cos vs libm: ulp-level
         assert abs(R.res_mean - resid[keep].mean()) < 1e-15 and abs(R.res_std - resid[keep].std()) < 1e-14
         assert abs(R.dist_std - dist[keep].std()) < 1e-14
@@ -251,7 +251,7 @@ def test_filtered_iteration_uses_previous_match_bound(ctx_filter, clouds):
         idx, dist, keep, _ = ctx_filter.icp_state()
         assert np.array_equal(idx, o["nn"]) and np.array_equal(dist, o["dist"]) and np.array_equal(keep, o["keep"])
         x = np.array(R.x[:])
-        assert np.abs(x - o["x"]).max() < 1e-11
+        assert np.abs(x - o["x"]).max() < 1e-9
 
 
 @pytest.mark.parametrize("n,q,k", [(20, 5, 2), (5000, 300, 10), (30_000, 500, 40), (3000, 64, 70), (100, 3, 100),
@@ -293,4 +293,4 @@ def test_large_q_iteration_multi_kernel_path(ctx):
         assert np.array_equal(idx, o["nn"]) and np.array_equal(dist, o["dist"]) and np.array_equal(keep, o["keep"])
         assert R.n_kept == o["n"] and R.median == o["median"] and R.mad == o["mad"]
         x = np.array(R.x[:])
-        assert np.abs(x - o["x"]).max() < 1e-10
+        assert np.abs(x - o["x"]).max() < 1e-9
