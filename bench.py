@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce-leg", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=2)
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="register the multi-GPU exchange even with one rank (measures its overhead on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -106,8 +108,9 @@ def main():
         print("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU path)", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from simpleicp_amd import _lib, dist
@@ -118,8 +121,8 @@ def main():
     ctx.upload(_lib.FIX, Xf)
     lo, hi = dist.shard_bounds(N, rank, world)
     ctx.upload(_lib.MOV, Xm[lo:hi], index_base=lo)
-    if world > 1:
-        ctx.set_exchange(dist.make_exchange(local_rank), rank, world, gn_shard=Q >= 262144)
+    if world > 1 or args.force_exchange:
+        ctx.set_exchange(dist.make_exchange(ctx), rank, world, gn_shard=Q >= 262144)
 
     # select_n_points (pointcloud.py:132-147) + estimate_normals (one-off, untimed but reported)
     sel = np.unique(np.round(np.linspace(0, N - 1, Q)).astype(np.int64)) if N > Q else np.arange(N)
@@ -151,6 +154,7 @@ def main():
     match_kernel = ctx.last_match_kernel()
     if rank != 0:
         if world > 1:
+            ctx.close()
             td.destroy_process_group()
         return
 
@@ -221,9 +225,18 @@ def main():
         out["roofline_bruteforce"] = bruteforce_leg(local_rank, Xf, Xm, sel, normals, planarity, x, pmc)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(Xf, Xm, sel, normals, planarity, args.cpu_iterations)
-    print(json.dumps(out), flush=True)
-    if world > 1:
+    if args.force_exchange:
+        out["config"]["parallelism"] += " (exchange forced on 1 rank)"
+    if world > 1 or args.force_exchange:
         td.destroy_process_group()
+    # RCCL prints a version banner through C stdio; flush it first so the JSON line is the LAST line
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
 
 
 def bruteforce_leg(device, Xf, Xm, sel, normals, planarity, x_ref, pmc):

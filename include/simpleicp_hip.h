@@ -151,9 +151,11 @@ int sicp_params_to_H(const double x[6], double H_out[16]);
 /* ---- multi-GPU exchange hook (one process per GPU; collectives supplied by the host) -- */
 /* The library never links RCCL: the host binding (torch.distributed over RCCL/xGMI in
  * simpleicp_amd/dist.py) registers a callback the iteration calls at its exchange points.
- * All pointers handed to the callback are DEVICE pointers owned by the ctx, the library's
- * stream is idle when it is called, and the callback must complete (results visible in
- * device memory) before it returns 0.
+ * All pointers handed to the callback are DEVICE pointers owned by the ctx.  The callback must either
+ * ENQUEUE the collective in order on the library's stream (sicp_ctx_stream; e.g. under
+ * torch.cuda.stream(torch.cuda.ExternalStream(ptr)) -- nothing then blocks the host), or finish it
+ * (results visible in device memory) before returning, after synchronising that stream itself.
+ * Return 0 on success.
  *   SICP_XCHG_ALLGATHER_F64 : a = send f64[count], b = recv f64[world*count]; fill b with every
  *                             rank's `a` in rank order (the library packs per-query
  *                             (d2, idx, x, y, z) records into `a` and afterwards reduces `b` to
@@ -166,6 +168,8 @@ typedef int (*sicp_exchange_fn)(void *user, int what, void *a, void *b, void *c,
  * gn_shard: 0 = every rank reduces all correspondences (no collective in the solver),
  *           1 = rank r reduces slice r of the correspondences + SUM exchange per step.   */
 int sicp_set_exchange(sicp_ctx *ctx, sicp_exchange_fn fn, void *user, int rank, int world, int gn_shard);
+/* the HIP stream (hipStream_t) every kernel and copy of this ctx is issued on */
+int sicp_ctx_stream(sicp_ctx *ctx, void **stream_out);
 
 /* Reduction used after the all-gather, exposed for tests: gathered = [world][Q][5] records
  * (d2, idx as int64 bits, x, y, z); outputs the lexicographic (d2, idx) minimum per query over the

@@ -26,7 +26,7 @@ EXPORTS = [
     "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_size", "sicp_cloud_transform",
     "sicp_cloud_download", "sicp_knn", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
-    "sicp_set_exchange", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_last_match_kernel",
+    "sicp_set_exchange", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_last_match_kernel",
     "sicp_xyz_count", "sicp_xyz_read", "sicp_xyz_write",
 ]
 
@@ -93,6 +93,7 @@ def load():
     L.sicp_icp_normal_equations.argtypes = [vp, vp, vp]
     L.sicp_params_to_H.argtypes = [vp, vp]
     L.sicp_set_exchange.argtypes = [vp, EXCHANGE_FN, vp, cint, cint, cint]
+    L.sicp_ctx_stream.argtypes = [vp, C.POINTER(vp)]
     L.sicp_lexmin_gathered.argtypes = [vp, vp, cint, i64, vp, vp, vp]
     L.sicp_timing_enable.argtypes = [vp, cint]
     L.sicp_timing_reset.argtypes = [vp]
@@ -258,6 +259,12 @@ class Context:
         out = np.empty(30)
         self._chk(self._L.sicp_icp_normal_equations(self._h, _ptr(_f64(x)), _ptr(out)))
         return out
+
+    def stream_ptr(self):
+        """Raw hipStream_t of the context (for torch.cuda.ExternalStream)."""
+        p = C.c_void_p()
+        self._chk(self._L.sicp_ctx_stream(self._h, C.byref(p)))
+        return p.value or 0
 
     # -- multi-GPU exchange hook --
     def set_exchange(self, fn, rank, world, gn_shard=False):

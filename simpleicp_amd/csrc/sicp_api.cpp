@@ -274,7 +274,7 @@ int exchange_best(sicp_ctx *c, double *d2, int64_t *idx, double *p2, long Q)
     CHK(c->x_recv.reserve((size_t)5 * Q * c->world));
     launch_pack_best(c->stream, d2, idx, p2, Q, c->x_send.p);
     HIPCHK(hipGetLastError());
-    CHK(sync(c));
+    // no host wait: the callback enqueues the collective in order on this stream (or synchronises itself)
     if (c->xfn(c->xuser, SICP_XCHG_ALLGATHER_F64, c->x_send.p, c->x_recv.p, nullptr, 5 * Q) != 0)
         return fail(SICP_ERR_EXCHANGE, "exchange callback (ALLGATHER_F64) failed");
     launch_lexmin_gathered(c->stream, c->x_recv.p, c->world, Q, d2, idx, p2);
@@ -586,7 +586,6 @@ int normal_eq_host(sicp_ctx *c, const double x[6], bool write_resid, bool allow_
     }
     HIPCHK(hipGetLastError());
     if (shard) {
-        CHK(sync(c));
         if (c->xfn(c->xuser, SICP_XCHG_SUM_F64, d_out, nullptr, nullptr, 30) != 0)
             return fail(SICP_ERR_EXCHANGE, "exchange callback (SUM_F64) failed");
     }
@@ -1109,6 +1108,13 @@ SICP_EXPORT int sicp_lexmin_gathered(sicp_ctx *c, const double *gathered, int wo
     (void)hipStreamSynchronize(c->stream);
     g.release(); d2.release(); xyz.release(); idx.release();
     return rc;
+}
+
+SICP_EXPORT int sicp_ctx_stream(sicp_ctx *c, void **stream_out)
+{
+    if (!c || !stream_out) return fail(SICP_ERR_INVALID, "null argument");
+    *stream_out = (void *)c->stream;
+    return SICP_OK;
 }
 
 SICP_EXPORT int sicp_timing_enable(sicp_ctx *c, int on)

@@ -112,15 +112,23 @@ def allgather_into(recv, send, group=None):
     return recv
 
 
-def make_exchange(device, group=None):
+def make_exchange(ctx, group=None, synchronous=None):
     """Callback for Context.set_exchange.  The library hands over DEVICE pointers it owns (stable
     across iterations, so the zero-copy tensor views are cached) and reduces the gathered records
-    itself; the host side only issues the collective."""
+    itself; the host side only issues the collective.  By default the collective is enqueued IN
+    ORDER ON THE LIBRARY'S OWN STREAM (torch.cuda.ExternalStream), so nothing blocks the host
+    between the pack kernel, the all-gather and the reduce kernel; SICP_XCHG_SYNC=1 (or
+    synchronous=True) restores the blocking variant."""
+    import os
     import torch
     import torch.distributed as td
 
+    device = ctx.device
     dev = torch.device("cuda", device)
     world = td.get_world_size(group)
+    if synchronous is None:
+        synchronous = os.environ.get("SICP_XCHG_SYNC") == "1"
+    lib_stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev)
     views = {}
 
     def view(ptr, count):
@@ -133,13 +141,16 @@ def make_exchange(device, group=None):
         return t
 
     def fn(what, a, b, c, count):
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), torch.cuda.stream(lib_stream):
+            if synchronous:
+                lib_stream.synchronize()
             if what == _lib.XCHG_ALLGATHER_F64:
                 allgather_into(view(b, count * world), view(a, count), group)
             elif what == _lib.XCHG_SUM_F64:
                 allreduce_sum(view(a, count), group)
             else:
                 return 1
-            torch.cuda.current_stream(dev).synchronize()
+            if synchronous:
+                lib_stream.synchronize()
         return 0
     return fn

@@ -107,7 +107,7 @@ class SimpleICP:
             rank, world = dist.rank_world()
             lo, hi = dist.shard_bounds(len(X_mov), rank, world)
             ctx.upload(_lib.MOV, X_mov[lo:hi], index_base=lo)
-            ctx.set_exchange(dist.make_exchange(ctx.device), rank, world,
+            ctx.set_exchange(dist.make_exchange(ctx), rank, world,
                              gn_shard=correspondences >= 262144 or os.environ.get("SICP_GN_SHARD") == "1")
         else:
             ctx.upload(_lib.MOV, X_mov)

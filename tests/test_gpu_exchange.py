@@ -60,8 +60,11 @@ assert ith == it0 and np.abs(Hh - H0).max() < 1e-9     # device LM vs host LM: s
 os.environ["SICP_GN_SHARD"] = "1"
 td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 H2, X2, r2, it2 = run()                                # + sharded 6x6 reduction with a SUM all-reduce per solver step
-td.destroy_process_group()
 assert it2 == ith and np.array_equal(H2, Hh) and np.array_equal(r2, rh), (H2 - Hh)
+os.environ["SICP_XCHG_SYNC"] = "1"; del os.environ["SICP_GN_SHARD"]
+H3, X3, r3, it3 = run()                                # blocking variant of the callback
+td.destroy_process_group()
+assert it3 == it0 and np.array_equal(H3, H0) and np.array_equal(r3, r0)
 print("EXCHANGE_OK", it0)
 '''
 
