@@ -908,8 +908,8 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
         std::memcpy(c->last_ne, o + 20, sizeof c->last_ne);
         c->have_last_ne = true;
         if (std::getenv("SICP_SOLVE_TRACE"))
-            std::fprintf(stderr, "[solve] cycles: dist %.0f sort %.0f stats %.0f lm %.0f (%lld evals, %lld steps) final %.0f\n",
-                         o[50], o[51], o[52], o[53], (long long)R->ne_evals, (long long)R->lm_steps, o[54]);
+            std::fprintf(stderr, "[solve] cycles: dist %.0f sort %.0f stats %.0f lm %.0f (%lld evals, %lld steps, 6x6 solves %.0f) final %.0f\n",
+                         o[50], o[51], o[52], o[53], (long long)R->ne_evals, (long long)R->lm_steps, o[56], o[54]);
         return SICP_OK;
     }
     c->have_last_ne = false;

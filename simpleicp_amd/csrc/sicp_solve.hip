@@ -108,16 +108,20 @@ __device__ void bitonic(unsigned long long *k, int n, bool merge_only = false)
 __constant__ unsigned char kPairU[29] = {0,0,0,0,0,0, 1,1,1,1,1, 2,2,2,2, 3,3,3, 4,4, 5,  0,1,2,3,4,5, 6, 6};
 __constant__ unsigned char kPairV[29] = {0,1,2,3,4,5, 1,2,3,4,5, 2,3,4,5, 3,4,5, 4,5, 5,  6,6,6,6,6,6, 7, 6};
 
-constexpr int EPT = SOLVE_MAX_Q / SOLVE_BLOCK;      // correspondences per thread (4)
-
+template <int EPT>                                  // correspondences per thread: 1, 2 or 4
 struct Corr {                                       // one thread's correspondences, register resident
     double px[EPT], py[EPT], pz[EPT], qx[EPT], qy[EPT], qz[EPT];
     float nx[EPT], ny[EPT], nz[EPT];
     bool keep[EPT];
 };
 
-// sc = (sin a1, cos a1, sin a2, cos a2, sin a3, cos a3) of the angles in x
-__device__ void eval_ne(Shared &s, int Q, const double x[6], const double sc[6], const Corr &C, double nk, double *dst,
+// sc = (sin a1, cos a1, sin a2, cos a2, sin a3, cos a3) of the angles in x.
+// Jacobian of r = n.(R p + t - p1) w.r.t. the Euler angles without the 27 entries of dR/dalpha:
+// d(Rp)/dalpha_k = w_k x (Rp) with the instantaneous axes w1 = e_x, w2 = Rx e_y = (0, c1, s1),
+// w3 = Rx Ry e_z = (s2, -s1 c2, c1 c2)  (R = Rx Ry Rz, mathutils.py:39-68), hence
+// a_k = n.(w_k x Rp) = w_k.(Rp x n): one cross product per correspondence and five constants.
+template <int EPT>
+__device__ void eval_ne(Shared &s, int Q, const double x[6], const double sc[6], const Corr<EPT> &C, double nk, double *dst,
                         double *__restrict__ resid)
 {
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
@@ -126,16 +130,7 @@ __device__ void eval_ne(Shared &s, int Q, const double x[6], const double sc[6],
     H.m[0] = c2 * c3;                 H.m[1] = -c2 * s3;                H.m[2] = s2;        H.m[3] = x[3];
     H.m[4] = c1 * s3 + s1 * s2 * c3;  H.m[5] = c1 * c3 - s1 * s2 * s3;  H.m[6] = -s1 * c2;  H.m[7] = x[4];
     H.m[8] = s1 * s3 - c1 * s2 * c3;  H.m[9] = s1 * c3 + c1 * s2 * s3;  H.m[10] = c1 * c2;  H.m[11] = x[5];
-    double dR[27];
-    dR[0] = 0; dR[1] = 0; dR[2] = 0;
-    dR[3] = -s1 * s3 + c1 * s2 * c3;  dR[4] = -s1 * c3 - c1 * s2 * s3;  dR[5] = -c1 * c2;
-    dR[6] = c1 * s3 + s1 * s2 * c3;   dR[7] = c1 * c3 - s1 * s2 * s3;   dR[8] = -s1 * c2;
-    dR[9] = -s2 * c3;        dR[10] = s2 * s3;        dR[11] = c2;
-    dR[12] = s1 * c2 * c3;   dR[13] = -s1 * c2 * s3;  dR[14] = s1 * s2;
-    dR[15] = -c1 * c2 * c3;  dR[16] = c1 * c2 * s3;   dR[17] = -c1 * s2;
-    dR[18] = -c2 * s3;                 dR[19] = -c2 * c3;                  dR[20] = 0;
-    dR[21] = c1 * c3 - s1 * s2 * s3;   dR[22] = -c1 * s3 - s1 * s2 * c3;   dR[23] = 0;
-    dR[24] = s1 * c3 + c1 * s2 * s3;   dR[25] = -s1 * s3 + c1 * s2 * c3;   dR[26] = 0;
+    const double w3y = -s1 * c2, w3z = c1 * c2;
 
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -143,19 +138,15 @@ __device__ void eval_ne(Shared &s, int Q, const double x[6], const double sc[6],
         if (i < Q) {
             double a[7] = {0, 0, 0, 0, 0, 0, 0};
             if (C.keep[e]) {
-                const double px = C.px[e], py = C.py[e], pz = C.pz[e];
                 double X, Y, Z;
-                xfm(H, px, py, pz, X, Y, Z);
+                xfm(H, C.px[e], C.py[e], C.pz[e], X, Y, Z);
                 a[6] = pdist(X - C.qx[e], Y - C.qy[e], Z - C.qz[e], C.nx[e], C.ny[e], C.nz[e]);
                 const double nx = C.nx[e], ny = C.ny[e], nz = C.nz[e];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const double *D = dR + 9 * c;
-                    const double gx = D[0] * px + D[1] * py + D[2] * pz;
-                    const double gy = D[3] * px + D[4] * py + D[5] * pz;
-                    const double gz = D[6] * px + D[7] * py + D[8] * pz;
-                    a[c] = nx * gx + ny * gy + nz * gz;
-                }
+                const double ux = X - x[3], uy = Y - x[4], uz = Z - x[5];          // R p
+                const double cx = uy * nz - uz * ny, cy = uz * nx - ux * nz, cz = ux * ny - uy * nx;   // (R p) x n
+                a[0] = cx;
+                a[1] = c1 * cy + s1 * cz;
+                a[2] = s2 * cx + w3y * cy + w3z * cz;
                 a[3] = nx; a[4] = ny; a[5] = nz;
             }
 #pragma unroll
@@ -273,6 +264,7 @@ __device__ void lm_solve(Shared &s, const SolveArgs &A, const double *ne, double
 // out layout (doubles): 0 n_planar, 1 median, 2 mad, 3 n_kept, 4 dist_mean, 5 dist_std, 6 w_used, 7 cost,
 // 8 lm_steps, 9 ne_evals, 10..15 x, 16 res_mean, 17 res_std, 18 status (0 ok / 1 too few / 2 numeric),
 // 20..49 normal equations at x
+template <int EPT>
 __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
     const float *__restrict__ normals, const float *__restrict__ planarity, const double *__restrict__ p2,
@@ -285,7 +277,7 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
     long long tk[6]; tk[0] = clock64();          // phase stamps (shader clock), reported in out[50..54]
 
     // ---- distances + planarity flag; every thread keeps its correspondences in registers ----
-    Corr C;
+    Corr<EPT> C;
     double cnt[1] = {0.0};
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -378,12 +370,15 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
     double cost = objective(s.ne[cur], w, x, A);
     double lambda = 0.0;
     bool rows_current = true;        // s.ja / s.ne[cur] describe x (no rejected trial since)
+    long long t_solve = 0;           // cycles spent in the 6x6 solves (trace only)
     for (int it = 0; it < A.max_steps && nfree > 0; ++it) {
         bool accepted = false, blind = false;
         double costn = cost, dxmax = 0.0;
         for (int tries = 0; tries < 40; ++tries) {
+            const long long ts0 = clock64();
             if (tid < 64) lm_solve(s, A, s.ne[cur], w, x, lambda);
             __syncthreads();
+            t_solve += clock64() - ts0;
             const bool ok = s.dx[6] != 0.0;
             dxmax = 0.0;
             double dstep[6];
@@ -442,6 +437,7 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
         out[18] = (cost < __builtin_inf()) ? 0.0 : 2.0;
         tk[5] = clock64();
         for (int k = 0; k < 5; ++k) out[50 + k] = (double)(tk[k + 1] - tk[k]);
+        out[56] = (double)t_solve;
     }
     // completion ticket for the host, which polls this pinned word instead of waiting for the
     // end-of-kernel signal: all result words first (system-scope fence), then the sequence number
@@ -456,8 +452,16 @@ void launch_icp_solve(hipStream_t st, const double *qx, const double *qy, const 
                       const float *planarity, const double *p2, const int64_t *idx, const SolveArgs &A, double *dist,
                       uint8_t *flag, uint8_t *keep, double *resid, double *out)
 {
-    hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(SOLVE_BLOCK), 0, st, qx, qy, qz, normals, planarity, p2, idx, A, dist, flag,
-                       keep, resid, out);
+    // correspondences per thread: the register-resident copy is sized to the problem
+    if (A.Q <= SOLVE_BLOCK)
+        hipLaunchKernelGGL(k_icp_solve<1>, dim3(1), dim3(SOLVE_BLOCK), 0, st, qx, qy, qz, normals, planarity, p2, idx, A, dist,
+                           flag, keep, resid, out);
+    else if (A.Q <= 2 * SOLVE_BLOCK)
+        hipLaunchKernelGGL(k_icp_solve<2>, dim3(1), dim3(SOLVE_BLOCK), 0, st, qx, qy, qz, normals, planarity, p2, idx, A, dist,
+                           flag, keep, resid, out);
+    else
+        hipLaunchKernelGGL(k_icp_solve<4>, dim3(1), dim3(SOLVE_BLOCK), 0, st, qx, qy, qz, normals, planarity, p2, idx, A, dist,
+                           flag, keep, resid, out);
 }
 
 }  // namespace sicp
