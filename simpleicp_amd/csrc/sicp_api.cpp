@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -245,6 +246,23 @@ int sync(sicp_ctx *c)
     }
     c->pending.clear();
     return SICP_OK;
+}
+
+// non-blocking: fold in the event pairs whose kernels have finished (used on the polling path so
+// that kernel timing does not add a stream synchronisation to every iteration)
+void collect_ready(sicp_ctx *c)
+{
+    size_t w = 0;
+    for (size_t i = 0; i < c->pending.size(); ++i) {
+        EventPair p = c->pending[i];
+        float ms = 0;
+        if (hipEventQuery(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c->t_ms[p.kernel] += ms; c->t_n[p.kernel] += 1; c->pool.push_back(p);
+        } else {
+            c->pending[w++] = p;
+        }
+    }
+    c->pending.resize(w);
 }
 
 struct Timed {
@@ -844,6 +862,8 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
         if (std::isfinite(P->obs_weight[j])) freeidx[nfree++] = j;
     }
 
+    const bool htrace = std::getenv("SICP_HOST_TRACE") != nullptr;
+    const auto h0 = std::chrono::steady_clock::now();
     // ---- match: simpleicp.py:188-202, corrpts.py:124-137 (transform fused into the scan) ----
     double H12[12];
     params_to_H12(P->x, H12);
@@ -864,6 +884,7 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
         A.max_steps = P->max_lm_steps > 0 ? (int)P->max_lm_steps : 100;
         A.Q = Q;
         A.seq = (double)(++c->solve_seq);
+        const auto h1 = std::chrono::steady_clock::now();
         double *d_out = c->h_small + 64;      // pinned + mapped: the kernel's 56 result doubles land on the host directly
         {
             Timed t(c, SICP_K_NORMALEQ);
@@ -871,6 +892,7 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
                              c->m_p2.p, c->m_idx.p, A, c->dist.p, c->flag.p, c->keep.p, c->resid.p, d_out);
         }
         HIPCHK(hipGetLastError());
+        const auto h2 = std::chrono::steady_clock::now();
         // the kernel publishes a ticket in pinned memory once its results are there: poll it (a few us
         // sooner than the end-of-kernel signal); fall back to a stream wait if it does not show up
         {
@@ -881,7 +903,13 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
                 __builtin_ia32_pause();
             }
             std::atomic_thread_fence(std::memory_order_acquire);
-            if (!seen || c->timing) CHK(sync(c));
+            if (htrace) {
+                const auto h3 = std::chrono::steady_clock::now();
+                auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+                std::fprintf(stderr, "[host] match launch %.1f us, solve launch %.1f us, wait %.1f us\n", us(h0, h1), us(h1, h2), us(h2, h3));
+            }
+            if (!seen) CHK(sync(c));
+            else if (c->timing) collect_ready(c);
         }
         const double *o = c->h_small + 64;
         R->n_queries = Q; R->n_planar = (int64_t)o[0]; R->median = o[1]; R->mad = o[2]; R->n_kept = (int64_t)o[3];
@@ -910,6 +938,8 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
         if (std::getenv("SICP_SOLVE_TRACE"))
             std::fprintf(stderr, "[solve] cycles: dist %.0f sort %.0f stats %.0f lm %.0f (%lld evals, %lld steps, 6x6 solves %.0f) final %.0f\n",
                          o[50], o[51], o[52], o[53], (long long)R->ne_evals, (long long)R->lm_steps, o[56], o[54]);
+        if (std::getenv("SICP_SOLVE_TRACE"))
+            std::fprintf(stderr, "[eval]  cycles over all evals: rows %.0f barrier %.0f sums %.0f barrier %.0f\n", o[57], o[58], o[59], o[60]);
         return SICP_OK;
     }
     c->have_last_ne = false;
@@ -1132,12 +1162,14 @@ SICP_EXPORT int sicp_last_match_kernel(sicp_ctx *c, int *kind_out)
 SICP_EXPORT int sicp_timing_reset(sicp_ctx *c)
 {
     if (!c) return fail(SICP_ERR_INVALID, "null ctx");
+    if (!c->pending.empty()) CHK(sync(c));
     for (int i = 0; i < SICP_K_COUNT; ++i) { c->t_ms[i] = 0; c->t_n[i] = 0; }
     return SICP_OK;
 }
 SICP_EXPORT int sicp_timing_get(sicp_ctx *c, int kernel, double *total_ms_out, int64_t *launches_out)
 {
     if (!c || kernel < 0 || kernel >= SICP_K_COUNT) return fail(SICP_ERR_INVALID, "bad arguments");
+    if (!c->pending.empty()) CHK(sync(c));          // fold in whatever is still in flight
     if (total_ms_out) *total_ms_out = c->t_ms[kernel];
     if (launches_out) *launches_out = c->t_n[kernel];
     return SICP_OK;

@@ -152,16 +152,6 @@ __global__ __launch_bounds__(256) void k_grid_nn(
         best = __builtin_inf(); bidx = 0xffffffffu; bpos = 0;
         const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
         const long nrows = (long)ny * nz;
-        auto visit = [&](uint32_t i) {
-            double X = sx[i], Y = sy[i], Z = sz[i];
-            if (XFORM) { double u, v, w; xf(H, X, Y, Z, u, v, w); X = u; Y = v; Z = w; }
-            const double dx = X - ax, dy = Y - ay, dz = Z - az;
-            const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
-            if (d2 <= best) {
-                const uint32_t oi = sidx[i];
-                if (d2 < best || oi < bidx) { best = d2; bidx = oi; bpos = i; }
-            }
-        };
         // cells of one (cy, cz) row are contiguous in the sorted order: lane r fetches row r's point
         // range, a wave scan turns up to 64 ranges into one flat candidate list, and the lanes stride
         // over it -- two dependent memory round trips per batch instead of two per row
@@ -178,17 +168,40 @@ __global__ __launch_bounds__(256) void k_grid_nn(
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
             const uint32_t total = __shfl(incl, 63, 64);
-            for (uint32_t base = 0; base < total; base += 64) {      // wave-uniform trip count: shuffles need all lanes
-                const uint32_t k = base + lane;
-                int r0 = 0;                                     // first row whose inclusive offset exceeds k
+            // four flat candidates per lane per round: their (row, offset) searches and coordinate loads
+            // are independent, so four memory round trips overlap (wave-uniform trip count: the
+            // shuffles need all lanes)
+            for (uint32_t base = 0; base < total; base += 256) {
+                uint32_t pos[4]; bool ok[4];
 #pragma unroll
-                for (int step = 32; step > 0; step >>= 1) {
-                    const uint32_t v = __shfl(incl, r0 + step - 1, 64);
-                    if (v <= k) r0 += step;
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t k = base + 64 * u + lane;
+                    int r0 = 0;                                 // first row whose inclusive offset exceeds k
+#pragma unroll
+                    for (int step = 32; step > 0; step >>= 1) {
+                        const uint32_t v = __shfl(incl, r0 + step - 1, 64);
+                        if (v <= k) r0 += step;
+                    }
+                    r0 = r0 > 63 ? 63 : r0;
+                    const uint32_t rbeg = __shfl(b, r0, 64), ri = __shfl(incl, r0, 64), rl = __shfl(len, r0, 64);
+                    ok[u] = k < total;
+                    pos[u] = ok[u] ? rbeg + (k - (ri - rl)) : 0u;
                 }
-                r0 = r0 > 63 ? 63 : r0;
-                const uint32_t rbeg = __shfl(b, r0, 64), ri = __shfl(incl, r0, 64), rl = __shfl(len, r0, 64);
-                if (k < total) visit(rbeg + (k - (ri - rl)));
+                double X[4], Y[4], Z[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { X[u] = sx[pos[u]]; Y[u] = sy[pos[u]]; Z[u] = sz[pos[u]]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!ok[u]) continue;
+                    double px = X[u], py = Y[u], pz = Z[u];
+                    if (XFORM) { double a, bq, cq; xf(H, px, py, pz, a, bq, cq); px = a; py = bq; pz = cq; }
+                    const double dx = px - ax, dy = py - ay, dz = pz - az;
+                    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                    if (d2 <= best) {
+                        const uint32_t oi = sidx[pos[u]];
+                        if (d2 < best || oi < bidx) { best = d2; bidx = oi; bpos = pos[u]; }
+                    }
+                }
             }
         }
         // wave-wide lexicographic (d2, original index) minimum

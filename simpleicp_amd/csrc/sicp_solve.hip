@@ -120,11 +120,14 @@ struct Corr {                                       // one thread's corresponden
 // d(Rp)/dalpha_k = w_k x (Rp) with the instantaneous axes w1 = e_x, w2 = Rx e_y = (0, c1, s1),
 // w3 = Rx Ry e_z = (s2, -s1 c2, c1 c2)  (R = Rx Ry Rz, mathutils.py:39-68), hence
 // a_k = n.(w_k x Rp) = w_k.(Rp x n): one cross product per correspondence and five constants.
+__device__ long long g_prof[4];     // trace only (SICP_SOLVE_TRACE): cycles in eval phase 1 / barrier / phase 2 / barrier
+
 template <int EPT>
 __device__ void eval_ne(Shared &s, int Q, const double x[6], const double sc[6], const Corr<EPT> &C, double nk, double *dst,
                         double *__restrict__ resid)
 {
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const long long e0 = clock64();
     const double s1 = sc[0], c1 = sc[1], s2 = sc[2], c2 = sc[3], s3 = sc[4], c3 = sc[5];
     Xf H;
     H.m[0] = c2 * c3;                 H.m[1] = -c2 * s3;                H.m[2] = s2;        H.m[3] = x[3];
@@ -154,7 +157,9 @@ __device__ void eval_ne(Shared &s, int Q, const double x[6], const double sc[6],
             if (resid) resid[i] = a[6];
         }
     }
+    const long long e1 = clock64();
     __syncthreads();
+    const long long e2 = clock64();
     // wave w owns sums w, w+8, w+16, w+24: accumulated together so the LDS reads overlap
     constexpr int NW = SOLVE_BLOCK / 64;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -177,7 +182,9 @@ __device__ void eval_ne(Shared &s, int Q, const double x[6], const double sc[6],
         for (int k = 0; k < 4; ++k) { const int p = wid + NW * k; if (p < 29) dst[p] = acc[k]; }
     }
     if (tid == 0) dst[29] = nk;
+    const long long e3 = clock64();
     __syncthreads();
+    if (tid == 0) { g_prof[0] += e1 - e0; g_prof[1] += e2 - e1; g_prof[2] += e3 - e2; g_prof[3] += clock64() - e3; }
 }
 
 // sin/cos of (a + d) from sin/cos of a: exact addition theorem with a short Taylor series for the
@@ -438,6 +445,7 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
         tk[5] = clock64();
         for (int k = 0; k < 5; ++k) out[50 + k] = (double)(tk[k + 1] - tk[k]);
         out[56] = (double)t_solve;
+        for (int k = 0; k < 4; ++k) { out[57 + k] = (double)g_prof[k]; g_prof[k] = 0; }
     }
     // completion ticket for the host, which polls this pinned word instead of waiting for the
     // end-of-kernel signal: all result words first (system-scope fence), then the sequence number
