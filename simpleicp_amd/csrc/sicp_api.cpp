@@ -997,7 +997,7 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
         for (int u = 0; u < 6; ++u) g[u] = w * w * ne[21 + u];
         for (int j = 0; j < 6; ++j)
             if (is_observed(ow[j])) { N[j * 6 + j] += ow[j] * ow[j]; g[j] += ow[j] * ow[j] * (x[j] - obs[j]); }
-        bool accepted = false, blind = false;
+        bool accepted = false, converged = false;
         double xn[6], nen[30], costn = cost, dxmax = 0;
         for (int tries = 0; tries < 40; ++tries) {
             double A[36], b[6];
@@ -1012,15 +1012,14 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
             for (int u = 0; u < nfree; ++u) { xn[freeidx[u]] += b[u]; dxmax = std::max(dxmax, std::fabs(b[u])); }
             {
                 double xm = 0; for (int j = 0; j < 6; ++j) xm = std::max(xm, std::fabs(x[j]));
-                if (lambda == 0.0 && dxmax <= 1e-9 * (1.0 + xm)) { blind = true; accepted = true; break; }   // see k_icp_solve
+                if (lambda == 0.0 && dxmax <= 1e-10 * (1.0 + xm)) { converged = true; break; }   // see k_icp_solve
             }
             CHK(normal_eq_host(c, xn, false, true, nen)); R->ne_evals++;
             costn = objective(nen, w, xn, obs, ow);
             if (costn <= cost * (1 + 1e-12) || dxmax < 1e-15) { accepted = true; break; }
             lambda = lambda > 0 ? lambda * 10 : 1e-6;
         }
-        if (!accepted) break;
-        if (blind) { std::memcpy(x, xn, sizeof x); R->lm_steps++; break; }
+        if (converged || !accepted) break;
         std::memcpy(x, xn, sizeof x); std::memcpy(ne, nen, sizeof ne);
         cost = costn;
         lambda = lambda > 0 ? lambda * 0.1 : 0.0;

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
     bool rows_current = true;        // s.ja / s.ne[cur] describe x (no rejected trial since)
     long long t_solve = 0;           // cycles spent in the 6x6 solves (trace only)
     for (int it = 0; it < A.max_steps && nfree > 0; ++it) {
-        bool accepted = false, blind = false;
+        bool accepted = false, converged = false;
         double costn = cost, dxmax = 0.0;
         for (int tries = 0; tries < 40; ++tries) {
             const long long ts0 = clock64();
@@ -398,10 +398,10 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
             double xm = 0.0;
 #pragma unroll
             for (int j = 0; j < 6; ++j) xm = fmax(xm, fabs(x[j]));
-            if (lambda == 0.0 && dxmax <= 1e-9 * (1.0 + xm)) {
-                // undamped Gauss-Newton step below 1e-9: what is left after it is (contraction rate) x 1e-9,
-                // far under the reference's own 1e-8 stopping tolerance -- take it without re-evaluating
-                accepted = true; blind = true; break;
+            if (lambda == 0.0 && dxmax <= 1e-10 * (1.0 + xm)) {
+                // the undamped Gauss-Newton step from x is below 1e-10: x is the minimiser to that accuracy
+                // (the reference stops at 1e-8); stop here -- rows and sums staged in LDS describe x
+                converged = true; break;
             }
             eval_ne(s, (int)Q, xn, scn, C, nk, s.ne[cur ^ 1], nullptr); ++evals;
             costn = objective(s.ne[cur ^ 1], w, xn, A);
@@ -409,10 +409,9 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
             rows_current = false;
             lambda = lambda > 0 ? lambda * 10 : 1e-6;
         }
-        if (!accepted) break;
+        if (converged || !accepted) break;
 #pragma unroll
         for (int j = 0; j < 6; ++j) { x[j] = xn[j]; sc[j] = scn[j]; }
-        if (blind) { ++steps; rows_current = false; break; }
         cur ^= 1; cost = costn;
         lambda = lambda > 0 ? lambda * 0.1 : 0.0;
         if (lambda < 1e-12) lambda = 0.0;
