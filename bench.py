@@ -22,7 +22,7 @@ speed it up (the exchange adds latency); the N > 1 numbers document that cost (D
 One JSON line on stdout (rank 0).  Extra objects (all on the same line):
   roofline             the kernel with the largest share of the step's GPU time, SURVEY 8(d) bytes
   roofline_match       the 1-NN kernel of the default path (pruned grid search)
-  roofline_bruteforce  the north-star brute-force scan (`k_knn1_fscan`), measured in a short extra
+  roofline_bruteforce  the north-star brute-force scan (`k_knn1_frec`), measured in a short extra
                        leg on the same inputs: HBM fraction and FP32-VALU fraction
   cpu_baseline         the reference's algorithm (oracle/ref_port.py: cKDTree rebuild + query +
                        least_squares per iteration) on this box's host cores, bounded sample
@@ -272,8 +272,9 @@ def bruteforce_leg(device, Xf, Xm, sel, normals, planarity, x_ref, pmc):
             "valu_frac": pairs * 6 / (ms * 1e-3) / (FP32_VALU_PEAK_TFLOPS * 1e12),
             "iterations_per_s": 6 / dt,
             "note": "brute-force Q x N scan is VALU-bound by construction (SURVEY 8d): 3 v_fma_f32 + 1/2 v_min3 per pair "
-                    "(6 flop/pair against the 157.3 TF FP32 vector peak; v_fma_f32 alone measures 111 TF), exact FP64 "
-                    "re-evaluation of the few passing pairs; the cloud is read from HBM once per 1024 queries"}
+                    "(6 flop/pair against the 157.3 TF FP32 vector peak; v_fma_f32 alone measures 111 TF); the few passing "
+                    "(query, group) pairs are recorded and re-evaluated exactly in FP64 by k_knn1_fixup; the cloud is read "
+                    "from HBM once per 1024 queries"}
 
 
 def cpu_baseline(Xf, Xm, sel, normals, planarity, iterations):

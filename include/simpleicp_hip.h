@@ -195,8 +195,9 @@ int sicp_xyz_write(const char *path, const double *data, int64_t n, int cols, in
 #define SICP_K_SELECT   3   /* median / MAD selection                   */
 #define SICP_K_COUNT    4
 int sicp_timing_enable(sicp_ctx *ctx, int on);
-/* which 1-NN flavour the last sicp_knn(k=1) / sicp_icp_iterate used: 0 exact scan, 1 filtered
- * scan, 2 grid search (all three return identical results) */
+/* which 1-NN flavour the last sicp_knn(k=1) / sicp_icp_iterate used: 0 exact scan, 1 filtered scan
+ * with inline verification, 2 grid search, 3 filtered scan with recorded candidates + fix-up kernel
+ * (all return identical results) */
 int sicp_last_match_kernel(sicp_ctx *ctx, int *kind_out);
 int sicp_timing_reset(sicp_ctx *ctx);
 int sicp_timing_get(sicp_ctx *ctx, int kernel, double *total_ms_out, int64_t *launches_out);

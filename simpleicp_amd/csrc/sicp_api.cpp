@@ -198,12 +198,16 @@ struct sicp_ctx {
     DevBuf<double> bound;          // per-query upper bound of the NN distance (filtered scan)
     DevBuf<double> x_send, x_recv; // exchange records: [Q][5] and [world][Q][5]
     int fs_blocks_per_cu[2] = {0, 0};   // occupancy of k_knn1_fscan<128>, <256>
+    int fr_blocks_per_cu[2] = {0, 0};   // occupancy of k_knn1_frec<128>, <256>
+    int fscan_variant = 0;         // SICP_FSCAN = record (default) | inline: which filtered-scan kernel
+    long fscan_cap = 0;            // SICP_FSCAN_CAP: recorded groups per query (tests force overflow with tiny values)
+    DevBuf<uint32_t> hit_cnt, hit_list;
     int knn1_mode = 0;             // SICP_KNN1 = exact | filter | grid: force one 1-NN flavour (A/B + tests); 0 = auto
     DevBuf<uint32_t> g_keys, g_vals, g_keys2, g_counts;   // grid build scratch
     DevBuf<unsigned char> g_tmp;
     DevBuf<unsigned long long> rj_keys;   // sort-based rejection scratch (2Q)
     bool have_prev_match = false;  // m_p2 holds last iteration's winners (bound source)
-    int last_match_kernel = 0;     // 0 exact scan, 1 filtered scan, 2 grid
+    int last_match_kernel = 0;     // 0 exact scan, 1 filtered scan (inline), 2 grid, 3 filtered scan (record + fix-up)
     // ICP state (selected fixed points and per-iteration products)
     int64_t Q = 0, qpad = 0;
     DevBuf<double> q;              // qx|qy|qz [qpad]
@@ -521,17 +525,44 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
     }
     // ---- filtered scan: fill the chip exactly once with resident blocks ----
     const int blk = (Q > 1024) ? 256 : 128;                  // 8 queries per lane either way
-    int &bpc = c->fs_blocks_per_cu[blk == 256];
-    if (bpc == 0) bpc = fscan_blocks_per_cu(blk);
     const long qblocks = (Q + blk * FS_R - 1) / (blk * FS_R);
     const int ftiles = (int)(cl.npad / FS_TILE);
+    // (a) record + fix-up: the streaming kernel carries no FP64 state; exact work in a second, tiny kernel
+    if (c->fscan_variant != 1) {
+        int &bpr = c->fr_blocks_per_cu[blk == 256];
+        if (bpr == 0) bpr = frec_blocks_per_cu(blk);
+        long nparts = std::max<long>(1, ((long)cus * bpr) / qblocks);
+        nparts = std::min<long>(nparts, ftiles);
+        uint32_t cap = c->fscan_cap > 0 ? (uint32_t)c->fscan_cap
+                                        : (uint32_t)std::max<long>(32, std::min<long>(4096, (256L << 20) / qpad));
+        CHK(c->hit_cnt.reserve((size_t)qpad + 4));
+        CHK(c->hit_list.reserve((size_t)qpad * cap));
+        HIPCHK(hipMemsetAsync(c->hit_cnt.p, 0, ((size_t)qpad + 4) * sizeof(uint32_t), c->stream));
+        uint32_t *d_over = c->hit_cnt.p + qpad;
+        {
+            Timed t(c, SICP_K_KNN1);
+            launch_knn1_frec(c->stream, blk, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, (int)qblocks, c->bound.p, cl.x(), cl.y(),
+                             cl.z(), ftiles, (int)nparts, H, rmax_t, c->hit_cnt.p, c->hit_list.p, cap);
+        }
+        launch_knn1_fixup(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, cl.x(), cl.y(), cl.z(), H, c->hit_cnt.p,
+                          c->hit_list.p, cap, max_d2, cl.idx_base, d2_out, idx_out, p2_out, d_over);
+        HIPCHK(hipGetLastError());
+        uint32_t *h_over = (uint32_t *)(c->h_small + 62);
+        HIPCHK(hipMemcpyAsync(h_over, d_over, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        CHK(sync(c));
+        if (*h_over == 0) { c->last_match_kernel = 3; return SICP_OK; }
+        // some query's candidate list overflowed (poor bound): fall through to the self-contained kernel
+    }
+    // (b) self-contained variant: exact re-evaluation inside the scan (tightens its own threshold)
+    int &bpc = c->fs_blocks_per_cu[blk == 256];
+    if (bpc == 0) bpc = fscan_blocks_per_cu(blk);
     long nparts = std::max<long>(1, ((long)cus * bpc) / qblocks);
     nparts = std::min<long>(nparts, ftiles);
     CHK(c->part_d2.reserve((size_t)nparts * qpad));
     CHK(c->part_idx.reserve((size_t)nparts * qpad));
     {
         Timed t(c, SICP_K_KNN1);
-        launch_knn1_fscan(c->stream, blk, qsoa, qsoa + qpad, qsoa + 2 * qpad, (int)qpad, (int)qblocks, c->bound.p, cl.x(),
+        launch_knn1_fscan(c->stream, blk, qsoa, qsoa + qpad, qsoa + 2 * qpad, (int)qpad, Q, (int)qblocks, c->bound.p, cl.x(),
                           cl.y(), cl.z(), ftiles, (int)nparts, H, rmax_t, c->part_d2.p, c->part_idx.p);
     }
     launch_knn1_reduce(c->stream, c->part_d2.p, c->part_idx.p, (int)nparts, (int)qpad, Q, max_d2, cl.idx_base, cl.x(),
@@ -660,6 +691,8 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (rc == SICP_OK) rc = c->ticket.reserve(4);
     if (rc == SICP_OK && hipMemsetAsync(c->ticket.p, 0, 4 * sizeof(unsigned), c->stream) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
+    if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : 0;
+    if (const char *e = std::getenv("SICP_FSCAN_CAP")) c->fscan_cap = std::atol(e);
     if (const char *e = std::getenv("SICP_SOLVE")) c->solve_mode = !std::strcmp(e, "fused") ? 1 : !std::strcmp(e, "host") ? 2 : 0;
     if (const char *e = std::getenv("SICP_KNN1"))
         c->knn1_mode = !std::strcmp(e, "exact") ? 1 : !std::strcmp(e, "filter") ? 2 : !std::strcmp(e, "grid") ? 3 : 0;
@@ -677,7 +710,7 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     for (auto &cl : c->cloud) { cl.xyz.release(); cl.grid.cell_start.release(); cl.grid.sidx.release(); cl.grid.sxyz.release(); }
     c->g_keys.release(); c->g_vals.release(); c->g_keys2.release(); c->g_counts.release(); c->g_tmp.release(); c->rj_keys.release();
     c->stage.release(); c->part_d2.release(); c->part_idx.release(); c->kq.release(); c->k_d2.release();
-    c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
+    c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->hit_cnt.release(); c->hit_list.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
     c->resid.release(); c->flag.release(); c->keep.release(); c->small.release(); c->ne_partial.release();
     c->ticket.release();

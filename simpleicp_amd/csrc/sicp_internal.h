@@ -74,10 +74,18 @@ void launch_aos_queries(hipStream_t s, const double *aos, long Q, long qpad, dou
 void launch_knn1_scan(hipStream_t s, const double *qx, const double *qy, const double *qz, int qpad, int qblocks,
                       const double *px, const double *py, const double *pz, long npad, int tile_step,
                       int tiles_per_chunk, int nchunks, const Xf *H, double *part_d2, uint32_t *part_idx);
-void launch_knn1_fscan(hipStream_t s, int block, const double *qx, const double *qy, const double *qz, int qpad,
+void launch_knn1_fscan(hipStream_t s, int block, const double *qx, const double *qy, const double *qz, int qpad, long Q,
                        int qblocks, const double *bound, const double *px, const double *py, const double *pz,
                        int ntiles, int nparts, const Xf *H, double rmax, double *part_d2, uint32_t *part_idx);
 int  fscan_blocks_per_cu(int block);
+void launch_knn1_frec(hipStream_t s, int block, const double *qx, const double *qy, const double *qz, long Q, int qblocks,
+                      const double *bound, const double *px, const double *py, const double *pz, int ntiles, int nparts,
+                      const Xf *H, double rmax, uint32_t *hit_cnt, uint32_t *hit_list, uint32_t cap);
+void launch_knn1_fixup(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *px,
+                       const double *py, const double *pz, const Xf *H, const uint32_t *hit_cnt, const uint32_t *hit_list,
+                       uint32_t cap, double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out,
+                       uint32_t *overflow);
+int  frec_blocks_per_cu(int block);
 void launch_bound_prev(hipStream_t s, const double *qx, const double *qy, const double *qz, const double *p2, long Q,
                        long qpad, const Xf &H, double *bound);
 void launch_max_norm2(hipStream_t s, const double *x, const double *y, const double *z, long n, unsigned long long *out);

@@ -189,7 +189,7 @@ __device__ __forceinline__ float filter_threshold(double bound, double qq, doubl
 
 template <int BLOCK, bool XFORM>
 __global__ __launch_bounds__(BLOCK) void k_knn1_fscan(
-    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, int qpad,
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, int qpad, long Q,
     const double *__restrict__ bound,
     const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
     int ntiles, Xf H, double rmax, double *__restrict__ part_d2, uint32_t *__restrict__ part_idx)
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(BLOCK) void k_knn1_fscan(
         const double x = qx[q], y = qy[q], z = qz[q];
         const double qq = fma(z, z, fma(y, y, x * x));
         m2x[r] = (float)(-2.0 * x); m2y[r] = (float)(-2.0 * y); m2z[r] = (float)(-2.0 * z);
-        thr[r] = filter_threshold(bound[q], qq, rmax);
+        thr[r] = (q < Q) ? filter_threshold(bound[q], qq, rmax) : -__builtin_inff();      // padding lanes never hit
         best[r] = __builtin_inf(); bidx[r] = 0xffffffffu;
     }
 
@@ -293,6 +293,143 @@ __global__ __launch_bounds__(BLOCK) void k_knn1_fscan(
         const long q = q0 + r * BLOCK + tid;
         part_d2[(long)blockIdx.y * qpad + q] = best[r];
         part_idx[(long)blockIdx.y * qpad + q] = bidx[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K1r: the filtered scan with the exact work split off -- the streaming kernel only RECORDS which
+// (query, 8-point group) pairs pass the conservative FP32 filter (a few dozen per query for the whole
+// cloud), so its hot loop carries no FP64 state at all (110 instead of 170 VGPRs: twice the
+// occupancy); k_knn1_fixup then evaluates the recorded groups with the exact FP64 contract, one wave
+// per query, and takes the lexicographic (d2, idx) minimum.  Same answer as K1 / K1f.  A query whose
+// list overflows `cap` is reported and the caller reruns the self-contained K1f kernel.
+// ------------------------------------------------------------------------------------
+template <int BLOCK, bool XFORM>
+__global__ __launch_bounds__(BLOCK) void k_knn1_frec(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, long Q,
+    const double *__restrict__ bound,
+    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
+    int ntiles, Xf H, double rmax, uint32_t *__restrict__ hit_cnt, uint32_t *__restrict__ hit_list, uint32_t cap)
+{
+    constexpr int R = FS_R;
+    __shared__ float4 tile[2][FS_TILE];
+    const int tid = threadIdx.x;
+    const long q0 = (long)blockIdx.x * (BLOCK * R);
+
+    float m2x[R], m2y[R], m2z[R], thr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long q = q0 + r * BLOCK + tid;
+        const double x = qx[q], y = qy[q], z = qz[q];
+        const double qq = fma(z, z, fma(y, y, x * x));
+        m2x[r] = (float)(-2.0 * x); m2y[r] = (float)(-2.0 * y); m2z[r] = (float)(-2.0 * z);
+        thr[r] = (q < Q) ? filter_threshold(bound[q], qq, rmax) : -__builtin_inff();   // padding lanes never hit
+    }
+    const int t_lo = (int)((long)blockIdx.y * ntiles / gridDim.y);
+    const int t_hi = (int)((long)(blockIdx.y + 1) * ntiles / gridDim.y);
+
+    constexpr int PER = FS_TILE / BLOCK;
+    double lx[PER], ly[PER], lz[PER];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const long g = (long)t * FS_TILE + u * BLOCK + tid;
+            lx[u] = px[g]; ly[u] = py[g]; lz[u] = pz[g];
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            double X = lx[u], Y = ly[u], Z = lz[u];
+            if (XFORM) { double a, b, c; xform(H, X, Y, Z, a, b, c); X = a; Y = b; Z = c; }
+            const double pp = fma(Z, Z, fma(Y, Y, X * X));
+            tile[buf][u * BLOCK + tid] = make_float4((float)X, (float)Y, (float)Z, (float)pp);
+        }
+    };
+    if (t_lo < t_hi) { gload(t_lo); lstore(0); }
+    int cur = 0;
+    for (int t = t_lo; t < t_hi; ++t) {
+        __syncthreads();
+        const bool more = (t + 1 < t_hi);
+        if (more) gload(t + 1);
+        const uint32_t tbase = (uint32_t)t * FS_TILE;
+        for (int g0 = 0; g0 < FS_TILE; g0 += FS_G) {
+            float gm[R];
+            {
+                const float4 P = tile[cur][g0];
+#pragma unroll
+                for (int r = 0; r < R; ++r) gm[r] = fmaf(m2x[r], P.x, fmaf(m2y[r], P.y, fmaf(m2z[r], P.z, P.w)));
+            }
+#pragma unroll
+            for (int g = 1; g < FS_G; ++g) {
+                const float4 P = tile[cur][g0 + g];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    gm[r] = fminf(gm[r], fmaf(m2x[r], P.x, fmaf(m2y[r], P.y, fmaf(m2z[r], P.z, P.w))));
+            }
+            unsigned long long hit = 0ull;
+#pragma unroll
+            for (int r = 0; r < R; ++r) hit |= __builtin_amdgcn_ballot_w64(gm[r] < thr[r]);
+            if (hit != 0ull) {
+                const uint32_t gid = (tbase + (uint32_t)g0) / FS_G;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (gm[r] < thr[r]) {
+                        const long q = q0 + r * BLOCK + tid;
+                        const uint32_t slot = atomicAdd(hit_cnt + q, 1u);
+                        if (slot < cap) hit_list[(size_t)q * cap + slot] = gid;
+                    }
+            }
+        }
+        if (more) lstore(cur ^ 1);
+        cur ^= 1;
+    }
+}
+
+// one wave per query: exact FP64 evaluation of the recorded groups, lexicographic minimum, strict
+// upper bound, gather of the winner's original coordinates; overflow[0] counts queries whose list
+// did not fit (their result is NOT final)
+template <bool XFORM>
+__global__ __launch_bounds__(256) void k_knn1_fixup(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, long Q,
+    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz, Xf H,
+    const uint32_t *__restrict__ hit_cnt, const uint32_t *__restrict__ hit_list, uint32_t cap, double max_d2,
+    int64_t idx_base, double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
+    uint32_t *__restrict__ overflow)
+{
+    const int lane = threadIdx.x & 63;
+    const long q = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const uint32_t cnt = hit_cnt[q];
+    const uint32_t n = cnt < cap ? cnt : cap;
+    if (cnt > cap && lane == 0) atomicAdd(overflow, 1u);
+    const double ax = qx[q], ay = qy[q], az = qz[q];
+    double best = __builtin_inf();
+    uint32_t bidx = 0xffffffffu;
+    const uint32_t total = n * FS_G;                       // candidates: FS_G points per recorded group
+    for (uint32_t k = lane; k < total; k += 64) {
+        const uint32_t id = hit_list[(size_t)q * cap + k / FS_G] * FS_G + k % FS_G;
+        double X = px[id], Y = py[id], Z = pz[id];
+        if (XFORM) { double a, b, c; xform(H, X, Y, Z, a, b, c); X = a; Y = b; Z = c; }
+        const double dx = X - ax, dy = Y - ay, dz = Z - az;
+        const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+        if (d2 < best || (d2 == best && id < bidx)) { best = d2; bidx = id; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double od = __shfl_xor(best, off, 64);
+        const uint32_t oi = __shfl_xor(bidx, off, 64);
+        if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; }
+    }
+    if (lane == 0) {
+        const bool ok = (bidx != 0xffffffffu) && (best < max_d2);
+        d2_out[q] = ok ? best : __builtin_inf();
+        idx_out[q] = ok ? idx_base + (int64_t)bidx : (int64_t)-1;
+        if (p2_out) {
+            p2_out[3 * q]     = ok ? px[bidx] : 0.0;
+            p2_out[3 * q + 1] = ok ? py[bidx] : 0.0;
+            p2_out[3 * q + 2] = ok ? pz[bidx] : 0.0;
+        }
     }
 }
 
@@ -900,27 +1037,75 @@ void launch_knn1_scan(hipStream_t s, const double *qx, const double *qy, const d
 }
 
 template <int BLOCK>
-static void fscan_launch(hipStream_t s, const double *qx, const double *qy, const double *qz, int qpad, int qblocks,
+static void fscan_launch(hipStream_t s, const double *qx, const double *qy, const double *qz, int qpad, long Q, int qblocks,
                          const double *bound, const double *px, const double *py, const double *pz, int ntiles,
                          int nparts, const Xf *H, double rmax, double *part_d2, uint32_t *part_idx)
 {
     const dim3 grid(qblocks, nparts), block(BLOCK);
     Xf id = {};
     if (H)
-        hipLaunchKernelGGL((k_knn1_fscan<BLOCK, true>), grid, block, 0, s, qx, qy, qz, qpad, bound, px, py, pz, ntiles,
+        hipLaunchKernelGGL((k_knn1_fscan<BLOCK, true>), grid, block, 0, s, qx, qy, qz, qpad, Q, bound, px, py, pz, ntiles,
                            *H, rmax, part_d2, part_idx);
     else
-        hipLaunchKernelGGL((k_knn1_fscan<BLOCK, false>), grid, block, 0, s, qx, qy, qz, qpad, bound, px, py, pz, ntiles,
+        hipLaunchKernelGGL((k_knn1_fscan<BLOCK, false>), grid, block, 0, s, qx, qy, qz, qpad, Q, bound, px, py, pz, ntiles,
                            id, rmax, part_d2, part_idx);
 }
 
 // BLOCK = 128 (1024 queries per block) or 256 (2048 queries per block)
-void launch_knn1_fscan(hipStream_t s, int block, const double *qx, const double *qy, const double *qz, int qpad,
+void launch_knn1_fscan(hipStream_t s, int block, const double *qx, const double *qy, const double *qz, int qpad, long Q,
                        int qblocks, const double *bound, const double *px, const double *py, const double *pz,
                        int ntiles, int nparts, const Xf *H, double rmax, double *part_d2, uint32_t *part_idx)
 {
-    if (block == 256) fscan_launch<256>(s, qx, qy, qz, qpad, qblocks, bound, px, py, pz, ntiles, nparts, H, rmax, part_d2, part_idx);
-    else              fscan_launch<128>(s, qx, qy, qz, qpad, qblocks, bound, px, py, pz, ntiles, nparts, H, rmax, part_d2, part_idx);
+    if (block == 256) fscan_launch<256>(s, qx, qy, qz, qpad, Q, qblocks, bound, px, py, pz, ntiles, nparts, H, rmax, part_d2, part_idx);
+    else              fscan_launch<128>(s, qx, qy, qz, qpad, Q, qblocks, bound, px, py, pz, ntiles, nparts, H, rmax, part_d2, part_idx);
+}
+
+template <int BLOCK>
+static void frec_launch(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int qblocks,
+                        const double *bound, const double *px, const double *py, const double *pz, int ntiles,
+                        int nparts, const Xf *H, double rmax, uint32_t *hit_cnt, uint32_t *hit_list, uint32_t cap)
+{
+    const dim3 grid(qblocks, nparts), block(BLOCK);
+    Xf id = {};
+    if (H)
+        hipLaunchKernelGGL((k_knn1_frec<BLOCK, true>), grid, block, 0, s, qx, qy, qz, Q, bound, px, py, pz, ntiles, *H, rmax,
+                           hit_cnt, hit_list, cap);
+    else
+        hipLaunchKernelGGL((k_knn1_frec<BLOCK, false>), grid, block, 0, s, qx, qy, qz, Q, bound, px, py, pz, ntiles, id, rmax,
+                           hit_cnt, hit_list, cap);
+}
+
+void launch_knn1_frec(hipStream_t s, int block, const double *qx, const double *qy, const double *qz, long Q, int qblocks,
+                      const double *bound, const double *px, const double *py, const double *pz, int ntiles, int nparts,
+                      const Xf *H, double rmax, uint32_t *hit_cnt, uint32_t *hit_list, uint32_t cap)
+{
+    if (block == 256) frec_launch<256>(s, qx, qy, qz, Q, qblocks, bound, px, py, pz, ntiles, nparts, H, rmax, hit_cnt, hit_list, cap);
+    else              frec_launch<128>(s, qx, qy, qz, Q, qblocks, bound, px, py, pz, ntiles, nparts, H, rmax, hit_cnt, hit_list, cap);
+}
+
+void launch_knn1_fixup(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *px,
+                       const double *py, const double *pz, const Xf *H, const uint32_t *hit_cnt, const uint32_t *hit_list,
+                       uint32_t cap, double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out,
+                       uint32_t *overflow)
+{
+    const dim3 grid(cdiv(Q, 4)), block(256);
+    Xf id = {};
+    if (H)
+        hipLaunchKernelGGL((k_knn1_fixup<true>), grid, block, 0, s, qx, qy, qz, Q, px, py, pz, *H, hit_cnt, hit_list, cap,
+                           max_d2, idx_base, d2_out, idx_out, p2_out, overflow);
+    else
+        hipLaunchKernelGGL((k_knn1_fixup<false>), grid, block, 0, s, qx, qy, qz, Q, px, py, pz, id, hit_cnt, hit_list, cap,
+                           max_d2, idx_base, d2_out, idx_out, p2_out, overflow);
+}
+
+int frec_blocks_per_cu(int block)
+{
+    int nb = 0;
+    hipError_t e = (block == 256)
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_knn1_frec<256, true>, 256, 0)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_knn1_frec<128, true>, 128, 0);
+    if (e != hipSuccess || nb < 1) nb = 2;
+    return nb > 16 ? 16 : nb;
 }
 
 int fscan_blocks_per_cu(int block)

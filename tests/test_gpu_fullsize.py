@@ -47,7 +47,7 @@ def test_three_exact_kernels_agree(data):
         with _ctx(mode) as c:
             c.upload(_lib.MOV, Xm)
             out[mode] = c.knn(_lib.MOV, q, k=1, H=H)
-            assert c.last_match_kernel() == {"grid": "k_grid_nn", "filter": "k_knn1_fscan"}[mode]
+            assert c.last_match_kernel() == {"grid": "k_grid_nn", "filter": "k_knn1_frec"}[mode]
     assert np.array_equal(out["grid"][0], out["filter"][0]) and np.array_equal(out["grid"][1], out["filter"][1])
     # exact FP64 scan on a slice that contains every winner's neighbourhood is too big; use a 1M-point prefix
     with _ctx("exact") as c:

@@ -294,3 +294,28 @@ def test_large_q_iteration_multi_kernel_path(ctx):
         assert R.n_kept == o["n"] and R.median == o["median"] and R.mad == o["mad"]
         x = np.array(R.x[:])
         assert np.abs(x - o["x"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("variant,cap", [("inline", None), ("record", 1), ("record", None)])
+def test_filtered_scan_variants_and_overflow_fallback(variant, cap):
+    """Both filtered-scan kernels (exact work inline / recorded + fixed up) and the overflow fallback
+    (candidate lists forced to one entry per query) return the brute-force answer."""
+    import os
+    from simpleicp_amd import _lib
+    env = {"SICP_KNN1": "filter", "SICP_FSCAN": variant}
+    if cap:
+        env["SICP_FSCAN_CAP"] = str(cap)
+    os.environ.update(env)
+    try:
+        c = _lib.Context(0)
+    finally:
+        for k in env:
+            del os.environ[k]
+    P = _surface(300_000, 31)
+    Qp = _surface(300_000, 32)[::200]
+    c.upload(_lib.MOV, P)
+    for Hm in (None, _H(7)):
+        idx, d2 = c.knn(_lib.MOV, Qp, k=1, H=Hm)
+        ridx, rd2 = orc.knn(P, Qp, k=1, H=Hm)
+        assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+    c.close()
