@@ -18,6 +18,6 @@ for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
             a = agg[k][r.get("Counter_Name", "?")]
             a[0] += float(r.get("Counter_Value", 0)); a[1] += 1
     for k, d in agg.items():
-        if not any(x in k for x in ("fscan", "knn1_scan", "normal_eq", "reject", "knnk")): continue
+        if not any(x in k for x in ("frec", "fscan", "fixup", "grid_nn", "icp_solve")): continue
         print(k, {c: f"{v/n:.4g}" for c, (v, n) in d.items()})
 PY
