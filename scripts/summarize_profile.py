@@ -26,7 +26,13 @@ def short(name):
     return n.split("<")[0]
 
 
-stats = glob.glob(str(src / "trace" / "**" / "*kernel_stats.csv"), recursive=True)
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: take the most recent run's file."""
+    files = glob.glob(pattern, recursive=True)
+    return [max(files, key=lambda f: Path(f).stat().st_mtime)] if files else []
+
+
+stats = newest(str(src / "trace" / "**" / "*kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], dst / "kernel_stats.csv")
 for f in ("bench_trace.json",):
@@ -35,7 +41,7 @@ for f in ("bench_trace.json",):
 
 per = collections.defaultdict(dict)
 for tagc, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    files = glob.glob(str(src / tagc / "**" / "*counter_collection.csv"), recursive=True)
+    files = newest(str(src / tagc / "**" / "*counter_collection.csv"))
     if not files:
         continue
     agg = collections.defaultdict(lambda: [0.0, 0])
