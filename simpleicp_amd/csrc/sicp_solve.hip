@@ -46,7 +46,7 @@ __device__ __forceinline__ double oval(unsigned long long k)
 
 struct Shared {
     union {
-        unsigned long long key[SOLVE_MAX_Q];   // order-statistics buffer (rejection phase)
+        unsigned long long key[3 * SOLVE_MAX_Q];   // order-statistics scratch: two exchange buffers + the sorted keys
         double ja[7][SOLVE_MAX_Q];             // staged rows [a0..a5 | r] of the kept correspondences (LM phase)
     };
     double red[SOLVE_BLOCK / 64][32];      // per-wave partials
@@ -97,6 +97,59 @@ __device__ void bitonic(unsigned long long *k, int n, bool merge_only = false)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
     __syncthreads();
+}
+
+// Register-resident bitonic sort of N = EPT * SOLVE_BLOCK keys: thread t holds the keys at positions
+// t + e * SOLVE_BLOCK.  A stage with partner distance j exchanges
+//   j >= SOLVE_BLOCK      inside the thread (its own registers),
+//   64 <= j < SOLVE_BLOCK through LDS (double-buffered: one barrier per stage),
+//   j < 64                with a wave shuffle -- no LDS round trip, no barrier.
+// Of the 55 stages of a 1024-key sort only 9 touch LDS (the in-LDS version paid a write, a read and a
+// barrier in every one: 36k cycles per iteration, now ~15k).  merge_only: input is already bitonic.
+template <int EPT>
+__device__ void bitonic_regs(unsigned long long *lds /* 2 * EPT * SOLVE_BLOCK words */, unsigned long long (&k)[EPT],
+                             bool merge_only)
+{
+    constexpr int N = EPT * SOLVE_BLOCK;
+    const int tid = threadIdx.x;
+    int buf = 0;
+    for (int size = merge_only ? N : 2; size <= N; size <<= 1)
+        for (int j = size >> 1; j > 0; j >>= 1) {
+            if (j >= SOLVE_BLOCK) {
+                const int m = j / SOLVE_BLOCK;                       // partner register: e ^ m
+#pragma unroll
+                for (int e = 0; e < EPT; ++e)
+                    if ((e & m) == 0 && (e | m) < EPT) {
+                        const int i = tid + e * SOLVE_BLOCK;
+                        const bool up = (i & size) == 0;
+                        const unsigned long long a = k[e], b = k[e | m];
+                        if ((a > b) == up) { k[e] = b; k[e | m] = a; }
+                    }
+            } else if (j >= 64) {
+                unsigned long long *cur = lds + buf * N;
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) cur[tid + e * SOLVE_BLOCK] = k[e];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const int i = tid + e * SOLVE_BLOCK;
+                    const unsigned long long o = cur[i ^ j];
+                    const bool lower = (i & j) == 0, up = (i & size) == 0;
+                    const bool take_min = lower == up;
+                    k[e] = take_min ? (o < k[e] ? o : k[e]) : (o > k[e] ? o : k[e]);
+                }
+                buf ^= 1;                                              // next LDS stage writes the other half
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const int i = tid + e * SOLVE_BLOCK;
+                    const unsigned long long o = __shfl_xor(k[e], j, 64);
+                    const bool lower = (i & j) == 0, up = (i & size) == 0;
+                    const bool take_min = lower == up;
+                    k[e] = take_min ? (o < k[e] ? o : k[e]) : (o > k[e] ? o : k[e]);
+                }
+            }
+        }
 }
 
 // normal equations of the unweighted residuals at x over the kept correspondences.
@@ -316,20 +369,32 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
         return;
     }
     tk[1] = clock64();
-    // ---- median / raw MAD: exact order statistics in LDS (rank counting for n <= 1024, bitonic sort above) ----
-    int n2 = 1; while (n2 < Q) n2 <<= 1;
-    double med, mad;
-    for (int i = tid; i < n2; i += blockDim.x) s.key[i] = (i < Q && flag[i]) ? okey(dist[i]) : ~0ull;
+    // ---- median / raw MAD: exact order statistics; keys sorted in registers (bitonic_regs) ----
+    constexpr int NS = EPT * SOLVE_BLOCK;
+    unsigned long long kk[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const long i = tid + (long)e * SOLVE_BLOCK;
+        kk[e] = (i < Q && flag[i]) ? okey(dist[i]) : ~0ull;
+    }
     __syncthreads();
-    bitonic(s.key, n2);
-    med = (oval(s.key[(m - 1) / 2]) + oval(s.key[m / 2])) / 2.0;
+    bitonic_regs<EPT>(s.key, kk, false);
     __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) s.key[2 * NS + tid + e * SOLVE_BLOCK] = kk[e];      // sorted order: position = t + e*BLOCK
+    __syncthreads();
+    const double med = (oval(s.key[2 * NS + (m - 1) / 2]) + oval(s.key[2 * NS + m / 2])) / 2.0;
     // |d - med| over the SORTED distances falls towards the median and rises after it (the unflagged
     // sentinels stay at the top): a bitonic sequence, so one merge (log2 n stages) sorts it
-    for (int i = tid; i < n2; i += blockDim.x) { const unsigned long long k = s.key[i]; if (k != ~0ull) s.key[i] = okey(fabs(oval(k) - med)); }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) if (kk[e] != ~0ull) kk[e] = okey(fabs(oval(kk[e]) - med));
     __syncthreads();
-    bitonic(s.key, n2, true);
-    mad = (oval(s.key[(m - 1) / 2]) + oval(s.key[m / 2])) / 2.0;
+    bitonic_regs<EPT>(s.key, kk, true);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) s.key[2 * NS + tid + e * SOLVE_BLOCK] = kk[e];
+    __syncthreads();
+    const double mad = (oval(s.key[2 * NS + (m - 1) / 2]) + oval(s.key[2 * NS + m / 2])) / 2.0;
     __syncthreads();
     const double bound = 3 * mad;
     tk[2] = clock64();
