@@ -471,7 +471,8 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
     // ---- pruned exact search on the static grid (rigid H only) ----
     Xf Hinv;
     const bool rigid = !H || rigid_inverse(*H, &Hinv);
-    const bool big = cl.n > 65536 || (double)cl.n * (double)Q > 1.0e9;
+    // the grid build hands 32-bit item counts to the device sort/scan primitives
+    const bool big = (cl.n > 65536 || (double)cl.n * (double)Q > 1.0e9) && cl.n < (1LL << 31);
     if (rigid && (c->knn1_mode == 3 || (c->knn1_mode == 0 && big))) {
         CHK(grid_build(c, slot));
         Grid &gr = cl.grid;
@@ -575,7 +576,8 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
 int knnk_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, int k, double *d2_out, int64_t *idx_out)
 {
     Cloud &cl = c->cloud[slot];
-    const bool big = cl.n > 65536 || (double)cl.n * (double)Q > 1.0e9;
+    // the grid build hands 32-bit item counts to the device sort/scan primitives
+    const bool big = (cl.n > 65536 || (double)cl.n * (double)Q > 1.0e9) && cl.n < (1LL << 31);
     if (c->knn1_mode == 3 || (c->knn1_mode == 0 && big)) {     // pruned search on the slot's grid
         CHK(grid_build(c, slot));
         Grid &gr = cl.grid;

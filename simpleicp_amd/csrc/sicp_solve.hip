@@ -27,10 +27,38 @@ __device__ __forceinline__ double pdist(double dx, double dy, double dz, float n
     const double a = dx * (double)nx, b = dy * (double)ny, c = dz * (double)nz;
     return (a + b) + c;
 }
+// value of v held by lane (lane ^ J), J < 64, without touching LDS: DPP quad_perm for J = 1, 2;
+// J = 4 = row_half_mirror (i^7) then quad reverse (i^3); J = 8 = row_mirror (i^15) then row_half_mirror;
+// J = 16 / 32 = gfx950's v_permlane16_swap / v_permlane32_swap.  (scripts/ubench/lane_xor.hip checks them.)
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_mov(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+template <int J>
+__device__ __forceinline__ unsigned lane_xor32(unsigned v)
+{
+    if constexpr (J == 1) return dpp_mov<0xB1>(v);
+    else if constexpr (J == 2) return dpp_mov<0x4E>(v);
+    else if constexpr (J == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));
+    else if constexpr (J == 8) return dpp_mov<0x141>(dpp_mov<0x140>(v));
+    else if constexpr (J == 16) { const v2u_t r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (threadIdx.x & 16) ? r.x : r.y; }
+    else { const v2u_t r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (threadIdx.x & 32) ? r.x : r.y; }
+}
+template <int J>
+__device__ __forceinline__ unsigned long long lane_xor64(unsigned long long v)
+{
+    const unsigned lo = lane_xor32<J>((unsigned)v), hi = lane_xor32<J>((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// wave-wide sum by a register-speed butterfly (every lane ends up with the total); the LDS-crossbar
+// shuffles (__shfl_down = ds_bpermute) cost ~250 cycles per step here, a DPP move a few
 __device__ __forceinline__ double wsum(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    v += __longlong_as_double((long long)lane_xor64<32>((unsigned long long)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)lane_xor64<16>((unsigned long long)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)lane_xor64<8>((unsigned long long)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)lane_xor64<4>((unsigned long long)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)lane_xor64<2>((unsigned long long)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)lane_xor64<1>((unsigned long long)__double_as_longlong(v)));
     return v;
 }
 __device__ __forceinline__ unsigned long long okey(double v)
@@ -100,56 +128,74 @@ __device__ void bitonic(unsigned long long *k, int n, bool merge_only = false)
 }
 
 // Register-resident bitonic sort of N = EPT * SOLVE_BLOCK keys: thread t holds the keys at positions
-// t + e * SOLVE_BLOCK.  A stage with partner distance j exchanges
-//   j >= SOLVE_BLOCK      inside the thread (its own registers),
-//   64 <= j < SOLVE_BLOCK through LDS (double-buffered: one barrier per stage),
-//   j < 64                with a wave shuffle -- no LDS round trip, no barrier.
+// t + e * SOLVE_BLOCK.  A stage with partner distance J exchanges
+//   J >= SOLVE_BLOCK      inside the thread (its own registers),
+//   64 <= J < SOLVE_BLOCK through LDS (double-buffered: one barrier per stage),
+//   J < 64                with DPP / permlane-swap register moves -- no LDS, no barrier.
 // Of the 55 stages of a 1024-key sort only 9 touch LDS (the in-LDS version paid a write, a read and a
-// barrier in every one: 36k cycles per iteration, now ~15k).  merge_only: input is already bitonic.
+// barrier in every one).  The network is unrolled at compile time (SIZE, J are template parameters) so
+// every lane exchange is a fixed instruction.  merge_only: the input already is bitonic.
+template <int EPT, int SIZE, int J>
+__device__ __forceinline__ void bitonic_stage(unsigned long long *lds, unsigned long long (&k)[EPT], int &buf)
+{
+    constexpr int N = EPT * SOLVE_BLOCK;
+    const int tid = threadIdx.x;
+    if constexpr (J >= SOLVE_BLOCK) {
+        constexpr int M = J / SOLVE_BLOCK;                       // partner register: e ^ M
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if ((e & M) == 0 && (e | M) < EPT) {
+                const int i = tid + e * SOLVE_BLOCK;
+                const bool up = (i & SIZE) == 0;
+                const unsigned long long a = k[e], b = k[e | M];
+                if ((a > b) == up) { k[e] = b; k[e | M] = a; }
+            }
+    } else if constexpr (J >= 64) {
+        unsigned long long *cur = lds + buf * N;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) cur[tid + e * SOLVE_BLOCK] = k[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + e * SOLVE_BLOCK;
+            const unsigned long long o = cur[i ^ J];
+            const bool take_min = ((i & J) == 0) == ((i & SIZE) == 0);
+            k[e] = take_min ? (o < k[e] ? o : k[e]) : (o > k[e] ? o : k[e]);
+        }
+        buf ^= 1;                                                  // next LDS stage writes the other half
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + e * SOLVE_BLOCK;
+            const unsigned long long o = lane_xor64<J>(k[e]);
+            const bool take_min = ((i & J) == 0) == ((i & SIZE) == 0);
+            k[e] = take_min ? (o < k[e] ? o : k[e]) : (o > k[e] ? o : k[e]);
+        }
+    }
+}
+
+template <int EPT, int SIZE, int J>
+__device__ __forceinline__ void bitonic_merge_steps(unsigned long long *lds, unsigned long long (&k)[EPT], int &buf)
+{
+    bitonic_stage<EPT, SIZE, J>(lds, k, buf);
+    if constexpr (J > 1) bitonic_merge_steps<EPT, SIZE, J / 2>(lds, k, buf);
+}
+
+template <int EPT, int SIZE>
+__device__ __forceinline__ void bitonic_sizes(unsigned long long *lds, unsigned long long (&k)[EPT], int &buf)
+{
+    bitonic_merge_steps<EPT, SIZE, SIZE / 2>(lds, k, buf);
+    if constexpr (SIZE < EPT * SOLVE_BLOCK) bitonic_sizes<EPT, SIZE * 2>(lds, k, buf);
+}
+
 template <int EPT>
 __device__ void bitonic_regs(unsigned long long *lds /* 2 * EPT * SOLVE_BLOCK words */, unsigned long long (&k)[EPT],
                              bool merge_only)
 {
     constexpr int N = EPT * SOLVE_BLOCK;
-    const int tid = threadIdx.x;
     int buf = 0;
-    for (int size = merge_only ? N : 2; size <= N; size <<= 1)
-        for (int j = size >> 1; j > 0; j >>= 1) {
-            if (j >= SOLVE_BLOCK) {
-                const int m = j / SOLVE_BLOCK;                       // partner register: e ^ m
-#pragma unroll
-                for (int e = 0; e < EPT; ++e)
-                    if ((e & m) == 0 && (e | m) < EPT) {
-                        const int i = tid + e * SOLVE_BLOCK;
-                        const bool up = (i & size) == 0;
-                        const unsigned long long a = k[e], b = k[e | m];
-                        if ((a > b) == up) { k[e] = b; k[e | m] = a; }
-                    }
-            } else if (j >= 64) {
-                unsigned long long *cur = lds + buf * N;
-#pragma unroll
-                for (int e = 0; e < EPT; ++e) cur[tid + e * SOLVE_BLOCK] = k[e];
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < EPT; ++e) {
-                    const int i = tid + e * SOLVE_BLOCK;
-                    const unsigned long long o = cur[i ^ j];
-                    const bool lower = (i & j) == 0, up = (i & size) == 0;
-                    const bool take_min = lower == up;
-                    k[e] = take_min ? (o < k[e] ? o : k[e]) : (o > k[e] ? o : k[e]);
-                }
-                buf ^= 1;                                              // next LDS stage writes the other half
-            } else {
-#pragma unroll
-                for (int e = 0; e < EPT; ++e) {
-                    const int i = tid + e * SOLVE_BLOCK;
-                    const unsigned long long o = __shfl_xor(k[e], j, 64);
-                    const bool lower = (i & j) == 0, up = (i & size) == 0;
-                    const bool take_min = lower == up;
-                    k[e] = take_min ? (o < k[e] ? o : k[e]) : (o > k[e] ? o : k[e]);
-                }
-            }
-        }
+    if (merge_only) bitonic_merge_steps<EPT, N, N / 2>(lds, k, buf);
+    else            bitonic_sizes<EPT, 2>(lds, k, buf);
 }
 
 // normal equations of the unweighted residuals at x over the kept correspondences.
