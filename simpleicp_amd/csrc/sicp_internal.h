@@ -17,7 +17,6 @@ constexpr int    FS_G      = 8;       // points between two slow-path checks of 
 constexpr int    QPAD      = 2048;    // query padding granule (covers R = 4 and R = 8 scan blocks)
 constexpr int    NE_BLOCK  = 256;
 constexpr int    NE_MAX_GRID = 1024;
-constexpr double SICP_PAD_COORD_V = 1.0e300;
 #define SICP_PAD_COORD 1.0e300
 
 // fused single-workgroup tail of the iteration (sicp_solve.hip)

@@ -22,10 +22,6 @@ exact code the GPU path runs.
 """
 from __future__ import annotations
 
-import ctypes
-
-import numpy as np
-
 from . import _lib
 
 
