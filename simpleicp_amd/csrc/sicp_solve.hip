@@ -103,30 +103,6 @@ __device__ void block_sum(Shared &s, const double (&v)[NV], double *dst)
     __syncthreads();
 }
 
-// in-LDS bitonic sort of n (power of two) keys, ascending; merge_only: the input already is a
-// bitonic sequence (falls, then rises), so the last log2(n) stages alone sort it.
-// Pair t of a stage with partner distance j touches elements inside one aligned 128-element chunk
-// whenever j <= 64, and wave w owns pairs 64w..64w+63 (+ multiples of the block size): those stages
-// need no workgroup barrier (a wave's LDS operations execute in order), only the j >= 128 ones do.
-__device__ void bitonic(unsigned long long *k, int n, bool merge_only = false)
-{
-    bool need_barrier = true;                 // the fill before the call was done by other waves
-    for (int size = merge_only ? n : 2; size <= n; size <<= 1)
-        for (int j = size >> 1; j > 0; j >>= 1) {
-            if (j >= 128 || need_barrier) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-            need_barrier = (j >= 128);
-            for (int t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l = i | j;
-                const bool up = (i & size) == 0;
-                const unsigned long long a = k[i], b = k[l];
-                if ((a > b) == up) { k[i] = b; k[l] = a; }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        }
-    __syncthreads();
-}
-
 // Register-resident bitonic sort of N = EPT * SOLVE_BLOCK keys: thread t holds the keys at positions
 // t + e * SOLVE_BLOCK.  A stage with partner distance J exchanges
 //   J >= SOLVE_BLOCK      inside the thread (its own registers),
