@@ -69,12 +69,12 @@ def synthetic_pair(n, seed_fix=0, seed_mov=1):
 
 
 def iterate(ctx, n_it, x, obs, ow):
-    evals, last = 0, None
-    for _ in range(n_it):
-        last = ctx.icp_iterate(x, obs, ow, 0.3, 1.0)
-        x = np.array(last.x[:])
-        evals += last.ne_evals
-    return x, evals, last
+    """n_it iterations of the hot path behind one ABI call (sicp_icp_run; min_change=0 never converges early)."""
+    if n_it <= 0:
+        return x, 0, None
+    res = ctx.icp_run(x, obs, ow, 0.3, 1.0, max_iterations=n_it, min_change=0.0)
+    assert len(res) == n_it
+    return np.array(res[-1].x[:]), sum(r.ne_evals for r in res), res[-1]
 
 
 def main():

@@ -129,6 +129,16 @@ typedef struct sicp_iter_result {
  * Levenberg-Marquardt on fused 6x6 normal-equation reductions with a host-side solve.     */
 int sicp_icp_iterate(sicp_ctx *ctx, const sicp_iter_params *params, sicp_iter_result *result);
 
+/* The whole iteration loop of simpleicp.py:184-261 in one call: repeats sicp_icp_iterate from
+ * params->x, feeding every estimate into the next iteration, freezing an automatic distance
+ * weight after the first iteration (simpleicp.py:229-234), until the reference's convergence test
+ * (simpleicp.py:356-379: change of mean AND of std(ddof 0) of the residuals, in percent, both
+ * < min_change; checked from the second iteration on) or max_iterations.  results[] receives one
+ * entry per executed iteration, *iterations_out their number.  On SICP_ERR_TOO_FEW the failing
+ * iteration's entry is filled (n_kept < 6) and counted. */
+int sicp_icp_run(sicp_ctx *ctx, const sicp_iter_params *params, int64_t max_iterations, double min_change,
+                 sicp_iter_result *results, int64_t *iterations_out);
+
 /* State of the LAST iteration, each (Q)-sized in query order, host-or-device, any NULL:
  *   pc2_idx  matched movable index (corrpts.py:135), dist  distance before optimisation
  *   (corrpts.py:195-211), keep  1 = survived both rejections, residual  unweighted residual

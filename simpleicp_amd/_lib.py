@@ -25,7 +25,7 @@ EXPORTS = [
     "sicp_abi_version", "sicp_last_error", "sicp_device_count", "sicp_ctx_create", "sicp_ctx_destroy",
     "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_size", "sicp_cloud_transform",
     "sicp_cloud_download", "sicp_knn", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
-    "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
+    "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
     "sicp_set_exchange", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_last_match_kernel",
     "sicp_xyz_count", "sicp_xyz_read", "sicp_xyz_write",
 ]
@@ -88,6 +88,7 @@ def load():
     L.sicp_estimate_normals.argtypes = [vp, cint, vp, i64, cint, vp, vp, vp]
     L.sicp_icp_setup.argtypes = [vp, vp, i64, vp, vp]
     L.sicp_icp_iterate.argtypes = [vp, C.POINTER(IterParams), C.POINTER(IterResult)]
+    L.sicp_icp_run.argtypes = [vp, C.POINTER(IterParams), i64, dbl, C.POINTER(IterResult), C.POINTER(i64)]
     L.sicp_icp_get_state.argtypes = [vp, vp, vp, vp, vp]
     L.sicp_icp_uncertainties.argtypes = [vp, vp]
     L.sicp_icp_normal_equations.argtypes = [vp, vp, vp]
@@ -240,6 +241,23 @@ class Context:
             err.result = R
             raise err
         return R
+
+    def icp_run(self, x, obs, obs_weight, min_planarity=0.3, distance_weight=1.0, max_iterations=100, min_change=1.0,
+                max_lm_steps=0):
+        """The whole loop in one ABI call (sicp_icp_run).  Returns the list of per-iteration IterResult;
+        raises BackendError (with `.results`) like icp_iterate when an iteration fails."""
+        P = IterParams((C.c_double * 6)(*x), (C.c_double * 6)(*obs), (C.c_double * 6)(*obs_weight),
+                       min_planarity, -1.0 if distance_weight is None else distance_weight, int(max_lm_steps))
+        n = int(max_iterations)
+        res = (IterResult * max(n, 1))()
+        done = C.c_int64()
+        rc = self._L.sicp_icp_run(self._h, C.byref(P), n, float(min_change), res, C.byref(done))
+        out = [res[i] for i in range(done.value)]
+        if rc != OK:
+            err = BackendError(self._L.sicp_last_error().decode(), rc)
+            err.results = out
+            raise err
+        return out
 
     def icp_state(self, pc2_idx=True, dist=True, keep=True, residual=True):
         Q = self._Q

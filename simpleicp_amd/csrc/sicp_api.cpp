@@ -1084,6 +1084,30 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
     return SICP_OK;
 }
 
+SICP_EXPORT int sicp_icp_run(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_iterations, double min_change,
+                             sicp_iter_result *results, int64_t *iterations_out)
+{
+    if (!c || !P0 || !results || !iterations_out) return fail(SICP_ERR_INVALID, "null argument");
+    *iterations_out = 0;
+    sicp_iter_params P = *P0;
+    auto change = [](double now, double before) {          // simpleicp.py:361-365
+        if (before == 0) return now == 0 ? 0.0 : std::numeric_limits<double>::infinity();
+        return std::fabs((now - before) / before * 100.0);
+    };
+    for (int64_t it = 0; it < max_iterations; ++it) {
+        sicp_iter_result &R = results[it];
+        const int rc = sicp_icp_iterate(c, &P, &R);
+        *iterations_out = it + 1;
+        if (rc != SICP_OK) return rc;
+        std::memcpy(P.x, R.x, sizeof P.x);
+        if (!(P.distance_weight > 0)) P.distance_weight = R.weight_used;
+        if (it > 0 && change(R.res_mean, results[it - 1].res_mean) < min_change &&
+            change(R.res_std, results[it - 1].res_std) < min_change)
+            break;
+    }
+    return SICP_OK;
+}
+
 SICP_EXPORT int sicp_icp_get_state(sicp_ctx *c, int64_t *pc2_idx, double *dist, uint8_t *keep, double *residual)
 {
     if (!c) return fail(SICP_ERR_INVALID, "null ctx");

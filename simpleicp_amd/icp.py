@@ -144,18 +144,32 @@ class SimpleICP:
         R = None
         it = -1
         _log.info("Start iterations ...")
-        for it in range(0, max_iterations):
+        def too_few(e):
+            if e.code == _lib.ERR_TOO_FEW:
+                raise SimpleICPException(str(e)) from None
+            raise e
+
+        # without debug dumps nothing on the host needs the intermediate states: the whole loop runs behind
+        # ONE ABI call (sicp_icp_run, same convergence test) and the per-iteration log is replayed below
+        whole = None
+        if not debug_dirpath:
+            try:
+                whole = ctx.icp_run(x, obs, ow, min_planarity, w, max_iterations, min_change)
+            except _lib.BackendError as e:
+                too_few(e)
+        for it in range(0, max_iterations if whole is None else len(whole)):
             if debug_dirpath:
                 if it == 0:
                     pc1.write_xyz(Path(debug_dirpath).joinpath(f"iteration{it:03d}_preoptim_pcfix.xyz"))
                 self._write_cloud(Path(debug_dirpath).joinpath(f"iteration{it:03d}_preoptim_pcmov.xyz"), X_mov, H)
             x_start = x.copy()
-            try:
-                R = ctx.icp_iterate(x, obs, ow, min_planarity, w)
-            except _lib.BackendError as e:
-                if e.code == _lib.ERR_TOO_FEW:
-                    raise SimpleICPException(str(e)) from None
-                raise
+            if whole is not None:
+                R = whole[it]
+            else:
+                try:
+                    R = ctx.icp_iterate(x, obs, ow, min_planarity, w)
+                except _lib.BackendError as e:
+                    too_few(e)
             if debug_dirpath:
                 self._write_correspondences(ctx, Path(debug_dirpath).joinpath(
                     f"iteration{it:03d}_preoptim_correspondences.xyz"), X_fix, X_mov, sel, H)

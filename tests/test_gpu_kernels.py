@@ -152,6 +152,36 @@ def test_iteration_vs_oracle(ctx, name, clouds):
     assert np.allclose(s[free], so[free], rtol=1e-9) and np.all(np.isnan(s[~free]))
 
 
+@pytest.mark.parametrize("name,w", [("dragon", 1.0), ("bunny", None)])
+def test_icp_run_equals_iterate_loop(ctx, name, w, clouds):
+    """sicp_icp_run (whole loop behind one call) == the same loop driven from the host through
+    sicp_icp_iterate: identical iteration count (same convergence test) and bit-identical results."""
+    from simpleicp_amd import _lib
+    g, files, kw = load_golden(name)
+    Xf, Xm = clouds(files[0]), clouds(files[1])
+    sel = g["sel_idx"]
+    ctx.upload(_lib.FIX, Xf)
+    ctx.upload(_lib.MOV, Xm)
+    ctx.icp_setup(sel, g["normals"], g["planarity"])
+    z = np.zeros(6)
+    x, ww, loop = z.copy(), w, []
+    for it in range(100):
+        R = ctx.icp_iterate(x, z, z, 0.3, ww)
+        loop.append(R)
+        x = np.array(R.x[:])
+        ww = R.weight_used if ww is None else ww
+        ch = lambda a, b: abs((a - b) / b * 100)
+        if it > 0 and ch(R.res_mean, loop[-2].res_mean) < 1 and ch(R.res_std, loop[-2].res_std) < 1:
+            break
+    whole = ctx.icp_run(z, z, z, 0.3, w, max_iterations=100, min_change=1.0)
+    assert len(whole) == len(loop) and (w is None or len(loop) == int(g["iterations"]))
+    for a, b in zip(whole, loop):
+        assert a.x[:] == b.x[:] and a.H[:] == b.H[:] and a.n_kept == b.n_kept and a.res_std == b.res_std
+        assert a.weight_used == b.weight_used
+    assert len(ctx.icp_run(z, z, z, max_iterations=3, min_change=0.0)) == 3
+    assert ctx.icp_run(z, z, z, max_iterations=0) == []
+
+
 def test_too_few_correspondences(ctx):
     from simpleicp_amd import _lib
     rng = np.random.default_rng(0)
@@ -165,6 +195,9 @@ def test_too_few_correspondences(ctx):
     with pytest.raises(_lib.BackendError) as e:
         ctx.icp_iterate(np.zeros(6), np.zeros(6), np.zeros(6))
     assert e.value.code == _lib.ERR_TOO_FEW and "Too few correspondences" in str(e.value)
+    with pytest.raises(_lib.BackendError) as e:
+        ctx.icp_run(np.zeros(6), np.zeros(6), np.zeros(6))
+    assert e.value.code == _lib.ERR_TOO_FEW and len(e.value.results) == 1 and e.value.results[0].n_kept < 6
 
 
 # ---- filtered scan (FP32 conservative filter + exact FP64 verification) == plain brute force ----
