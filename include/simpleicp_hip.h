@@ -63,6 +63,10 @@ int         sicp_ctx_device_name(sicp_ctx *ctx, char *buf, int buflen);
 /* Upload n points (host-or-device pointer) into slot SICP_FIX / SICP_MOV; replaces any
  * previous content.  index_base = global index of row 0 (0 unless the cloud is a shard). */
 int sicp_cloud_upload(sicp_ctx *ctx, int slot, const double *xyz, int64_t n, int64_t index_base);
+/* Same from three separate contiguous columns (how a DataFrame stores x, y, z once a column has been
+ * assigned, pointcloud.py:215-217): they are copied straight into the column-wise device layout. */
+int sicp_cloud_upload_columns(sicp_ctx *ctx, int slot, const double *x, const double *y, const double *z, int64_t n,
+                              int64_t index_base);
 int sicp_cloud_size(sicp_ctx *ctx, int slot, int64_t *n_out);
 /* PointCloud.transform_by_H (pointcloud.py:205-217): in-place, contract (T).  */
 int sicp_cloud_transform(sicp_ctx *ctx, int slot, const double H[16]);

@@ -23,7 +23,7 @@ MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1
 
 EXPORTS = [
     "sicp_abi_version", "sicp_last_error", "sicp_device_count", "sicp_ctx_create", "sicp_ctx_destroy",
-    "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_size", "sicp_cloud_transform",
+    "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_upload_columns", "sicp_cloud_size", "sicp_cloud_transform",
     "sicp_cloud_download", "sicp_knn", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
     "sicp_set_exchange", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_last_match_kernel",
@@ -81,6 +81,7 @@ def load():
     L.sicp_ctx_destroy.argtypes = [vp]
     L.sicp_ctx_device_name.argtypes = [vp, C.c_char_p, cint]
     L.sicp_cloud_upload.argtypes = [vp, cint, vp, i64, i64]
+    L.sicp_cloud_upload_columns.argtypes = [vp, cint, vp, vp, vp, i64, i64]
     L.sicp_cloud_size.argtypes = [vp, cint, C.POINTER(i64)]
     L.sicp_cloud_transform.argtypes = [vp, cint, vp]
     L.sicp_cloud_download.argtypes = [vp, cint, vp]
@@ -186,6 +187,15 @@ class Context:
         if tuple(xyz.shape) != (n, 3):
             raise ValueError("cloud must have shape (n, 3)")
         self._chk(self._L.sicp_cloud_upload(self._h, slot, _ptr(xyz), n, int(index_base)))
+
+    def upload_columns(self, slot, x, y, z, index_base=0):
+        """x, y, z: contiguous float64 vectors of one length (no (n,3) gather on the host)."""
+        cols = [_f64(np.asarray(v)) for v in (x, y, z)]
+        n = len(cols[0])
+        if any(v.ndim != 1 or len(v) != n for v in cols):
+            raise ValueError("x, y, z must be vectors of the same length")
+        self._chk(self._L.sicp_cloud_upload_columns(self._h, slot, _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2]), n,
+                                                    int(index_base)))
 
     def size(self, slot):
         n = C.c_int64()

@@ -730,30 +730,62 @@ SICP_EXPORT int sicp_ctx_device_name(sicp_ctx *c, char *buf, int buflen)
 }
 
 // ------------------------------------------------------------------------------------------
-SICP_EXPORT int sicp_cloud_upload(sicp_ctx *c, int slot, const double *xyz, int64_t n, int64_t index_base)
+namespace {
+// shared by the two upload flavours: validates, sizes the padded SoA arrays
+int upload_begin(sicp_ctx *c, int slot, int64_t n, int64_t index_base)
 {
     CHK(check_slot(c, slot, false));
-    if (!xyz || n <= 0) return fail(SICP_ERR_INVALID, "cloud must have at least one point");
+    if (n <= 0) return fail(SICP_ERR_INVALID, "cloud must have at least one point");
     if (n >= (int64_t)0xffffffffLL) return fail(SICP_ERR_INVALID, "at most 2^32-2 points per GPU shard");
     HIPCHK(hipSetDevice(c->device));
     Cloud &cl = c->cloud[slot];
     cl.n = n; cl.npad = round_up(n, TILE_PTS); cl.idx_base = index_base;
     cl.grid.valid = false;
     CHK(cl.xyz.reserve((size_t)3 * cl.npad));
-    CHK(c->stage.reserve((size_t)3 * n));
-    HIPCHK(hipMemcpyAsync(c->stage.p, xyz, (size_t)3 * n * sizeof(double), hipMemcpyDefault, c->stream));
-    launch_aos_to_soa(c->stream, c->stage.p, n, cl.npad, cl.x(), cl.y(), cl.z());
-    HIPCHK(hipGetLastError());
-    // largest norm, for the filtered scan's rounding-error bound
+    return SICP_OK;
+}
+
+// ... and finishes: largest norm, for the filtered scan's rounding-error bound
+int upload_end(sicp_ctx *c, int slot)
+{
+    Cloud &cl = c->cloud[slot];
     unsigned long long *d_bits = (unsigned long long *)(c->small.p + 40);
     HIPCHK(hipMemsetAsync(d_bits, 0, sizeof(unsigned long long), c->stream));
-    launch_max_norm2(c->stream, cl.x(), cl.y(), cl.z(), n, d_bits);
+    launch_max_norm2(c->stream, cl.x(), cl.y(), cl.z(), cl.n, d_bits);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_small + 40, d_bits, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     CHK(sync(c));
     cl.rmax = std::sqrt(c->h_small[40]) * (1.0 + 1e-12);
     if (slot == SICP_MOV) c->have_prev_match = false;
     return SICP_OK;
+}
+}  // namespace
+
+SICP_EXPORT int sicp_cloud_upload(sicp_ctx *c, int slot, const double *xyz, int64_t n, int64_t index_base)
+{
+    if (!xyz) return fail(SICP_ERR_INVALID, "xyz is null");
+    CHK(upload_begin(c, slot, n, index_base));
+    Cloud &cl = c->cloud[slot];
+    CHK(c->stage.reserve((size_t)3 * n));
+    HIPCHK(hipMemcpyAsync(c->stage.p, xyz, (size_t)3 * n * sizeof(double), hipMemcpyDefault, c->stream));
+    launch_aos_to_soa(c->stream, c->stage.p, n, cl.npad, cl.x(), cl.y(), cl.z());
+    HIPCHK(hipGetLastError());
+    return upload_end(c, slot);
+}
+
+SICP_EXPORT int sicp_cloud_upload_columns(sicp_ctx *c, int slot, const double *x, const double *y, const double *z, int64_t n,
+                                          int64_t index_base)
+{
+    if (!x || !y || !z) return fail(SICP_ERR_INVALID, "x / y / z is null");
+    CHK(upload_begin(c, slot, n, index_base));
+    Cloud &cl = c->cloud[slot];
+    // the device layout is column-wise already: three copies straight into place, no staging, no transpose
+    HIPCHK(hipMemcpyAsync(cl.x(), x, (size_t)n * sizeof(double), hipMemcpyDefault, c->stream));
+    HIPCHK(hipMemcpyAsync(cl.y(), y, (size_t)n * sizeof(double), hipMemcpyDefault, c->stream));
+    HIPCHK(hipMemcpyAsync(cl.z(), z, (size_t)n * sizeof(double), hipMemcpyDefault, c->stream));
+    launch_pad_fill(c->stream, cl.x(), cl.y(), cl.z(), n, cl.npad);
+    HIPCHK(hipGetLastError());
+    return upload_end(c, slot);
 }
 
 SICP_EXPORT int sicp_cloud_size(sicp_ctx *c, int slot, int64_t *n_out)

@@ -56,6 +56,12 @@ __global__ void k_aos_to_soa(const double *__restrict__ aos, long n, long npad,
     else       { x[i] = SICP_PAD_COORD; y[i] = SICP_PAD_COORD; z[i] = SICP_PAD_COORD; }
 }
 
+__global__ void k_pad_fill(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z, long n, long npad)
+{
+    const long i = n + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npad) { x[i] = SICP_PAD_COORD; y[i] = SICP_PAD_COORD; z[i] = SICP_PAD_COORD; }
+}
+
 __global__ void k_soa_to_aos(const double *__restrict__ x, const double *__restrict__ y,
                              const double *__restrict__ z, long n, double *__restrict__ aos)
 {
@@ -1003,6 +1009,10 @@ void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, d
 void launch_aos_to_soa(hipStream_t s, const double *aos, long n, long npad, double *x, double *y, double *z)
 {
     hipLaunchKernelGGL(k_aos_to_soa, dim3(cdiv(npad, 256)), dim3(256), 0, s, aos, n, npad, x, y, z);
+}
+void launch_pad_fill(hipStream_t s, double *x, double *y, double *z, long n, long npad)
+{
+    if (npad > n) hipLaunchKernelGGL(k_pad_fill, dim3(cdiv(npad - n, 256)), dim3(256), 0, s, x, y, z, n, npad);
 }
 void launch_soa_to_aos(hipStream_t s, const double *x, const double *y, const double *z, long n, double *aos)
 {

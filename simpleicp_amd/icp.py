@@ -99,25 +99,25 @@ class SimpleICP:
         ow = np.array(rbp_observation_weights, dtype=float)
         H = H_from_params(obs)
 
-        # both clouds go to HBM once and stay there
-        X_fix = pc1.X
-        ctx.upload(_lib.FIX, X_fix)
-        X_mov = pc2.X
+        # both clouds go to HBM once and stay there (straight from the frames' storage: no host gather)
+        fix_rows = pc1._upload(ctx, _lib.FIX)
         if sharded:
             rank, world = dist.rank_world()
-            lo, hi = dist.shard_bounds(len(X_mov), rank, world)
-            ctx.upload(_lib.MOV, X_mov[lo:hi], index_base=lo)
+            lo, hi = dist.shard_bounds(pc2.num_points, rank, world)
+            pc2._upload(ctx, _lib.MOV, lo, hi, index_base=lo)
             ctx.set_exchange(dist.make_exchange(ctx), rank, world,
                              gn_shard=correspondences >= 262144 or os.environ.get("SICP_GN_SHARD") == "1")
         else:
-            ctx.upload(_lib.MOV, X_mov)
+            pc2._upload(ctx, _lib.MOV)
             ctx.set_exchange(None, 0, 1)
+        if debug_dirpath:
+            X_fix, X_mov = pc1.X, pc2.X
 
         if np.isfinite(max_overlap_distance):
             _log.info("Consider partial overlap of point clouds ...")
             cur = pc1.idx_selected
             if len(cur):
-                idx = self._nn_in_movable(ctx, X_fix[cur], H, float(max_overlap_distance), sharded)
+                idx = self._nn_in_movable(ctx, fix_rows(cur), H, float(max_overlap_distance), sharded)
                 pc1.idx_selected = cur[idx >= 0]
             if not pc1.num_selected_points > 0:
                 raise SimpleICPException(
@@ -128,14 +128,14 @@ class SimpleICP:
 
         _log.info("Select points for correspondences in fixed point cloud ...")
         pc1.select_n_points(correspondences)
-        selected_orig = pc1["selected"].to_numpy().copy()
+        # (simpleicp.py:174,254 save and restore pc1's selection around every iteration because the
+        # reference's rejections edit it; here the masks live on the device and pc1 is never touched)
         sel = pc1.idx_selected
 
         if not set(_ATTRS).issubset(pc1.columns):
             _log.info("Estimate normals of selected points ...")
-            pc1.estimate_normals(neighbors, _ctx=ctx, _uploaded=True)
-        normals = np.column_stack([np.asarray(pc1[c].to_numpy(), dtype=np.float32)[sel] for c in _ATTRS[:3]])
-        planarity = np.asarray(pc1["planarity"].to_numpy(), dtype=np.float32)[sel]
+            pc1.estimate_normals(neighbors, _ctx=ctx, _uploaded=True, _sel=sel)
+        normals, planarity = pc1._attributes_of(sel)
         ctx.icp_setup(sel, normals, planarity)
 
         x = obs.copy()
@@ -178,7 +178,6 @@ class SimpleICP:
             x = np.array(R.x[:])
             H = np.array(R.H[:]).reshape(4, 4)
             stats.append((int(R.n_kept), R.res_mean, R.res_std))
-            pc1["selected"] = selected_orig                  # simpleicp.py:254
 
             if it > 0 and self._converged(stats[it], stats[it - 1], min_change):
                 _log.info("Convergence criteria fulfilled -> stop iteration!")
@@ -208,14 +207,14 @@ class SimpleICP:
 
         # final transformation of the caller's movable cloud (simpleicp.py:316)
         if sharded:
-            ctx.upload(_lib.MOV, X_mov)
-        pc2.transform_by_H(H, _ctx=ctx, _slot=_lib.MOV)
+            pc2._upload(ctx, _lib.MOV)
+        X_new = pc2._transform(H, ctx, _lib.MOV)
         if debug_dirpath:
             pc2.write_xyz(Path(debug_dirpath).joinpath(f"iteration{it:03d}_postoptim_pcmov.xyz"))
 
         self.last_run_info = {"iterations": it + 1, "stats": stats, "seconds": time.time() - t_start}
         _log.info(f"Finished in {time.time() - t_start:.3f} seconds!")
-        return H, pc2.X, rbp, residuals
+        return H, X_new, rbp, residuals
 
     # --------------------------------------------------------------------------------------
     def _nn_in_movable(self, ctx, queries, H, max_dist, sharded):

@@ -20,6 +20,12 @@ import pandas as pd
 from . import _lib, backend
 
 _XYZ = ["x", "y", "z"]
+_ATTRS = ("nx", "ny", "nz", "planarity")
+
+try:                                       # O(selected) construction of the sparse attribute columns
+    from pandas._libs.sparse import IntIndex as _IntIndex
+except ImportError:                        # pragma: no cover - falls back to the dense constructor
+    _IntIndex = None
 
 
 class PointCloudException(Exception):
@@ -70,6 +76,49 @@ class PointCloud(pd.DataFrame):
     def X(self) -> np.ndarray:
         """(n,3) float64 copy of the coordinates."""
         return self[_XYZ].to_numpy()
+
+    def _xyz_buffers(self):
+        """The coordinates WITHOUT a host copy where the frame's storage allows it (10 M points = 240 MB):
+        ("aos", (n,3) C-contiguous read-only view) for a frame still backed by the caller's (n,3) array,
+        ("soa", (x, y, z) contiguous vectors) once columns have been assigned; else a gathered copy."""
+        cols = [self[c].to_numpy() for c in _XYZ]
+        n = len(cols[0])
+        if n == 0 or any(c.dtype != np.float64 or c.ndim != 1 for c in cols):
+            return "aos", self.X
+        ptr = [c.__array_interface__["data"][0] for c in cols]
+        if all(c.strides == (24,) for c in cols) and ptr[1] == ptr[0] + 8 and ptr[2] == ptr[0] + 16:
+            return "aos", np.lib.stride_tricks.as_strided(cols[0], (n, 3), (24, 8), writeable=False)
+        if all(c.strides == (8,) for c in cols):
+            return "soa", cols
+        return "aos", self.X
+
+    def _upload(self, ctx, slot, lo=0, hi=None, index_base=0):
+        """Rows [lo, hi) into the library's slot; returns a row getter ``rows(idx) -> (len(idx),3)``."""
+        kind, buf = self._xyz_buffers()
+        hi = self._num_points if hi is None else hi
+        if kind == "aos":
+            ctx.upload(slot, buf[lo:hi], index_base=index_base)
+            return lambda idx: buf[idx]
+        ctx.upload_columns(slot, buf[0][lo:hi], buf[1][lo:hi], buf[2][lo:hi], index_base=index_base)
+        return lambda idx: np.column_stack([b[idx] for b in buf])
+
+    def _attributes_of(self, idx):
+        """(normals (len(idx),3) f32, planarity f32) of the rows ``idx`` (sorted) -- O(len(idx)) on the
+        sparse columns estimate_normals creates, dense fallback for columns a caller assigned."""
+        out = []
+        for c in _ATTRS:
+            arr = self[c].array
+            if isinstance(arr, pd.arrays.SparseArray) and np.isnan(arr.fill_value) and hasattr(arr.sp_index, "indices"):
+                pos_all = arr.sp_index.indices
+                v = np.full(len(idx), np.nan, dtype=np.float32)
+                if len(pos_all):
+                    pos = np.minimum(np.searchsorted(pos_all, idx), len(pos_all) - 1)
+                    hit = pos_all[pos] == idx
+                    v[hit] = np.asarray(arr.sp_values, dtype=np.float32)[pos[hit]]
+                out.append(v)
+            else:
+                out.append(np.asarray(self[c].to_numpy(), dtype=np.float32)[idx])
+        return np.column_stack(out[:3]), out[3]
 
     @property
     def X_selected(self) -> np.ndarray:
@@ -127,31 +176,47 @@ class PointCloud(pd.DataFrame):
         self.idx_selected = cur[idx[:, 0] >= 0]
 
     # ---- attributes (pointcloud.py:173-203) ---------------------------------------------
-    def estimate_normals(self, neighbors: int, _ctx=None, _uploaded=False) -> None:
+    def estimate_normals(self, neighbors: int, _ctx=None, _uploaded=False, _sel=None) -> None:
         """Normal vector + planarity of every SELECTED point from its `neighbors` nearest
         points among ALL points (itself included)."""
         ctx = _ctx or backend.get_context()
         if not _uploaded:
-            ctx.upload(_lib.FIX, self.X)
-        sel = self.idx_selected
-        cols = {c: np.full(self._num_points, np.nan, dtype=np.float32) for c in ("nx", "ny", "nz", "planarity")}
+            self._upload(ctx, _lib.FIX)
+        sel = self.idx_selected if _sel is None else _sel
+        vals = {c: np.empty(0, dtype=np.float32) for c in _ATTRS}
         if len(sel):
             nv, pl = ctx.estimate_normals(_lib.FIX, sel, int(neighbors))
-            cols["nx"][sel], cols["ny"][sel], cols["nz"][sel] = nv[:, 0], nv[:, 1], nv[:, 2]
-            cols["planarity"][sel] = pl
-        for c, v in cols.items():
-            self[c] = pd.arrays.SparseArray(v)
+            vals = {"nx": nv[:, 0], "ny": nv[:, 1], "nz": nv[:, 2], "planarity": pl}
+        for c, v in vals.items():
+            self[c] = self._sparse_column(sel, v)
+
+    def _sparse_column(self, idx, values):
+        """float32 sparse column, NaN everywhere but ``values`` at the (sorted) rows ``idx`` -- what
+        ``SparseArray(dense)`` gives (NaN results are not stored either), without touching n elements."""
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        if _IntIndex is not None and self._num_points < 2**31:
+            ok = ~np.isnan(values)
+            return pd.arrays.SparseArray(values[ok], sparse_index=_IntIndex(self._num_points, idx[ok].astype(np.int32)),
+                                         fill_value=np.nan, dtype=pd.SparseDtype(np.float32, np.nan))
+        dense = np.full(self._num_points, np.nan, dtype=np.float32)
+        dense[idx] = values
+        return pd.arrays.SparseArray(dense)
 
     # ---- geometry (pointcloud.py:205-217) -----------------------------------------------
     def transform_by_H(self, H: np.ndarray, _ctx=None, _slot=None) -> None:
         """x,y,z <- (H @ [x y z 1]^T)[:3]  in place."""
-        ctx = _ctx or backend.get_context()
-        slot = _lib.MOV if _slot is None else _slot
-        if _slot is None:
-            ctx.upload(slot, self.X)
+        self._transform(H, _ctx, _slot)
+
+    def _transform(self, H, ctx=None, slot=None) -> np.ndarray:
+        """transform_by_H; hands back the (n,3) array of new coordinates it downloaded (= self.X)."""
+        ctx = ctx or backend.get_context()
+        if slot is None:
+            slot = _lib.MOV
+            self._upload(ctx, slot)
         ctx.transform(slot, np.asarray(H, dtype=np.float64))
         Xt = ctx.download(slot)
         self["x"], self["y"], self["z"] = Xt[:, 0], Xt[:, 1], Xt[:, 2]
+        return Xt
 
     # ---- I/O (pointcloud.py:219-226) ------------------------------------------------------
     def write_xyz(self, file: Path):

@@ -77,6 +77,23 @@ def test_knnk_bit_exact(ctx, n, q, k):
     assert np.array_equal(d2, rd2)
 
 
+def test_upload_columns_equals_upload(ctx):
+    """Column-wise upload (a frame whose x, y, z were assigned) fills the same device cloud as the (n,3) one."""
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(11)
+    for n in (1, 1023, 1024, 70_001):
+        X = rng.normal(size=(n, 3)) * 50
+        q = rng.normal(size=(64, 3)) * 50
+        ctx.upload(_lib.MOV, X)
+        ref = ctx.knn(_lib.MOV, q, k=1)
+        ctx.upload_columns(_lib.MOV, X[:, 0].copy(), X[:, 1].copy(), X[:, 2].copy())
+        assert ctx.size(_lib.MOV) == n and np.array_equal(ctx.download(_lib.MOV), X)
+        got = ctx.knn(_lib.MOV, q, k=1)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    with pytest.raises(ValueError):
+        ctx.upload_columns(_lib.MOV, np.zeros(3), np.zeros(4), np.zeros(3))
+
+
 def test_transform_bit_exact(ctx):
     from simpleicp_amd import _lib
     rng = np.random.default_rng(2)

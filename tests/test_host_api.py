@@ -150,3 +150,54 @@ def test_argument_checks_need_no_gpu():
                     ({"rbp_observation_weights": (np.inf,) * 6}, "At least one element")]:
         with pytest.raises(SimpleICPException, match=msg):
             icp.run(**kw)
+
+
+def test_pointcloud_storage_views_need_no_copy():
+    """What run() uploads: the frame's own storage (zero-copy view of the caller's (n,3) array, or the three
+    column vectors once columns were assigned) -- always the same numbers as the copying ``X``."""
+    from simpleicp_amd import PointCloud
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(1000, 3))
+    pc = PointCloud(X, columns=["x", "y", "z"])
+    kind, buf = pc._xyz_buffers()
+    assert kind == "aos" and buf.flags.c_contiguous and np.shares_memory(buf, X) and not buf.flags.writeable
+    assert np.array_equal(buf, pc.X) and not np.shares_memory(pc.X, X)
+    pc["x"], pc["y"], pc["z"] = X[:, 2] * 2, X[:, 0], X[:, 1]           # like transform_by_H
+    kind, buf = pc._xyz_buffers()
+    assert kind == "soa" and all(b.flags.c_contiguous for b in buf)
+    assert np.array_equal(np.column_stack(buf), pc.X)
+    pc3 = PointCloud(pd.DataFrame({"z": X[:, 2], "x": X[:, 0].astype(np.float32), "y": X[:, 1]}))
+    kind, buf = pc3._xyz_buffers()                                       # float32 column: gathered, converted copy
+    assert kind == "aos" and buf.dtype == np.float64 and np.array_equal(buf, pc3.X)
+    pc4 = PointCloud(np.asfortranarray(X), columns=["x", "y", "z"])
+    kind, buf = pc4._xyz_buffers()
+    assert np.array_equal(np.column_stack(buf) if kind == "soa" else buf, X)
+
+
+def test_sparse_attribute_columns_equal_dense_construction():
+    """estimate_normals' columns built in O(selected) == SparseArray(dense NaN-filled vector) (pointcloud.py:199-203),
+    and reading them back at the selected rows in O(selected) == the dense read."""
+    from simpleicp_amd import PointCloud
+    n = 5000
+    pc = PointCloud(np.zeros((n, 3)), columns=["x", "y", "z"])
+    sel = np.unique(np.round(np.linspace(0, n - 1, 37)).astype(np.int64))
+    rng = np.random.default_rng(0)
+    vals = {c: rng.normal(size=len(sel)).astype(np.float32) for c in ("nx", "ny", "nz", "planarity")}
+    vals["planarity"][5] = np.nan                                        # a degenerate neighbourhood
+    for c, v in vals.items():
+        pc[c] = pc._sparse_column(sel, v)
+        dense = np.full(n, np.nan, np.float32)
+        dense[sel] = v
+        ref = pd.arrays.SparseArray(dense)
+        assert pc[c].dtype == ref.dtype == pd.SparseDtype(np.float32, np.nan)
+        assert np.array_equal(pc[c].array.sp_index.indices, ref.sp_index.indices)
+        assert np.array_equal(pc[c].array.sp_values, ref.sp_values)
+        assert np.array_equal(pc[c].to_numpy(), dense.astype(pc[c].to_numpy().dtype), equal_nan=True)
+    for idx in (sel, sel[::3], np.array([0, 1, 2, n - 1]), np.empty(0, np.int64)):
+        nv, pl = pc._attributes_of(idx)
+        assert nv.dtype == pl.dtype == np.float32 and nv.shape == (len(idx), 3)
+        for j, c in enumerate(("nx", "ny", "nz")):
+            assert np.array_equal(nv[:, j], pc[c].to_numpy().astype(np.float32)[idx], equal_nan=True)
+        assert np.array_equal(pl, pc["planarity"].to_numpy().astype(np.float32)[idx], equal_nan=True)
+    pc["nx"] = np.arange(n, dtype=np.float64)                            # a caller-assigned dense column
+    assert np.array_equal(pc._attributes_of(sel)[0][:, 0], np.arange(n, dtype=np.float32)[sel])
