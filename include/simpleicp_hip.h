@@ -86,6 +86,14 @@ int sicp_cloud_download(sicp_ctx *ctx, int slot, double *xyz_out);
 int sicp_knn(sicp_ctx *ctx, int slot, const double *q_xyz, int64_t Q, int k,
              const double *H, double max_dist, int64_t *idx_out, double *d2_out);
 
+/* PointCloud.select_in_range (pointcloud.py:149-171) between two RESIDENT clouds -- the partial-overlap
+ * pre-pass of SimpleICP.run (simpleicp.py:155-170) without moving a coordinate over the host link:
+ * in_range_out[i] = 1 iff the nearest neighbour of point sel_idx[i] of cloud `query_slot` (of point i, Q
+ * ignored, when sel_idx is NULL) among cloud `search_slot` transformed by H (NULL = identity) is closer
+ * than max_range (strict, like cKDTree's distance_upper_bound).  Job-wide when an exchange is set. */
+int sicp_select_in_range(sicp_ctx *ctx, int query_slot, int search_slot, const int64_t *sel_idx, int64_t Q,
+                         const double *H, double max_range, uint8_t *in_range_out);
+
 /* PointCloud.estimate_normals (pointcloud.py:173-203) for the rows sel_idx (LOCAL rows of
  * `slot`): k-NN among ALL points of the slot (self included), sample covariance (/(k-1)),
  * symmetric eigen-decomposition in fp64; normal = eigenvector of the smallest eigenvalue

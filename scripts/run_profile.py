@@ -1,6 +1,6 @@
 """End-to-end wall time of SimpleICP.run() on the bench workload (10 M-vs-10 M synthetic surface), split
 by ABI call: where a caller's time goes once the iterations themselves cost microseconds.
-    python scripts/run_profile.py [n_points] [correspondences]"""
+    python scripts/run_profile.py [n_points] [correspondences] [max_overlap_distance]"""
 import cProfile, pstats, sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -9,6 +9,7 @@ from simpleicp_amd import PointCloud, SimpleICP, _lib
 
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 Q = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1000
+OVERLAP = float(sys.argv[3]) if len(sys.argv) > 3 else np.inf       # max_overlap_distance (finite: the pre-pass runs)
 Xf, Xm, H_true = bench.synthetic_pair(N)
 acc = {}
 
@@ -25,7 +26,7 @@ def timed(name):
     setattr(_lib.Context, name, wrap)
 
 
-for m in ("upload", "download", "transform", "knn", "estimate_normals", "icp_setup", "icp_run", "icp_iterate",
+for m in ("upload", "download", "transform", "knn", "select_in_range", "estimate_normals", "icp_setup", "icp_run", "icp_iterate",
           "icp_state", "icp_uncertainties"):
     timed(m)
 
@@ -40,7 +41,7 @@ for rep in range(2):                      # second pass = warm (context, allocat
     pr = cProfile.Profile()
     t0 = time.perf_counter()
     pr.enable()
-    H, X_t, rbp, res = icp.run(correspondences=Q, max_overlap_distance=np.inf)
+    H, X_t, rbp, res = icp.run(correspondences=Q, max_overlap_distance=OVERLAP)
     pr.disable()
     t_run = time.perf_counter() - t0
     print(f"--- pass {rep}: PointCloud() x2 {t_pc:.3f} s, run() {t_run:.3f} s, {icp.last_run_info['iterations']} iterations, "

@@ -24,7 +24,7 @@ MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1
 EXPORTS = [
     "sicp_abi_version", "sicp_last_error", "sicp_device_count", "sicp_ctx_create", "sicp_ctx_destroy",
     "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_upload_columns", "sicp_cloud_size", "sicp_cloud_transform",
-    "sicp_cloud_download", "sicp_knn", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
+    "sicp_cloud_download", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
     "sicp_set_exchange", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_last_match_kernel",
     "sicp_xyz_count", "sicp_xyz_read", "sicp_xyz_write",
@@ -86,6 +86,7 @@ def load():
     L.sicp_cloud_transform.argtypes = [vp, cint, vp]
     L.sicp_cloud_download.argtypes = [vp, cint, vp]
     L.sicp_knn.argtypes = [vp, cint, vp, i64, cint, vp, dbl, vp, vp]
+    L.sicp_select_in_range.argtypes = [vp, cint, cint, vp, i64, vp, dbl, vp]
     L.sicp_estimate_normals.argtypes = [vp, cint, vp, i64, cint, vp, vp, vp]
     L.sicp_icp_setup.argtypes = [vp, vp, i64, vp, vp]
     L.sicp_icp_iterate.argtypes = [vp, C.POINTER(IterParams), C.POINTER(IterResult)]
@@ -219,6 +220,18 @@ class Context:
         Hc = None if H is None else _f64(H).reshape(16)
         self._chk(self._L.sicp_knn(self._h, slot, _ptr(q), Q, int(k), _ptr(Hc), float(max_dist), _ptr(idx), _ptr(d2)))
         return idx, d2
+
+    def select_in_range(self, query_slot, search_slot, sel=None, H=None, max_range=np.inf):
+        """bool mask over `sel` (all points of query_slot when None): nearest neighbour in search_slot (under H)
+        closer than max_range -- both clouds already resident (sicp_select_in_range)."""
+        if sel is not None:
+            sel = np.ascontiguousarray(sel, dtype=np.int64)
+        Q = self.size(query_slot) if sel is None else len(sel)
+        out = np.empty(Q, dtype=np.uint8)
+        Hp = None if H is None else _f64(H).reshape(16)
+        self._chk(self._L.sicp_select_in_range(self._h, query_slot, search_slot, _ptr(sel), Q, _ptr(Hp), float(max_range),
+                                               _ptr(out)))
+        return out.view(np.bool_)
 
     def estimate_normals(self, slot, sel_idx, k, want_nn=False):
         sel = np.ascontiguousarray(sel_idx, dtype=np.int64)

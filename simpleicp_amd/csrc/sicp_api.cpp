@@ -856,6 +856,49 @@ SICP_EXPORT int sicp_knn(sicp_ctx *c, int slot, const double *q_xyz, int64_t Q, 
     return sync(c);
 }
 
+SICP_EXPORT int sicp_select_in_range(sicp_ctx *c, int query_slot, int search_slot, const int64_t *sel_idx, int64_t Q,
+                                     const double *H, double max_range, uint8_t *in_range_out)
+{
+    CHK(check_slot(c, query_slot, true));
+    CHK(check_slot(c, search_slot, true));
+    if (!in_range_out) return fail(SICP_ERR_INVALID, "in_range_out is null");
+    if (query_slot == search_slot) return fail(SICP_ERR_INVALID, "query and search slot must differ");
+    if (std::isnan(max_range) || max_range < 0) return fail(SICP_ERR_INVALID, "max_range must be >= 0");
+    Cloud &qc = c->cloud[query_slot];
+    if (!sel_idx) Q = qc.n;
+    if (Q <= 0) return fail(SICP_ERR_INVALID, "Q must be > 0");
+    if (qc.idx_base != 0) return fail(SICP_ERR_INVALID, "the query cloud must not be a shard");
+    HIPCHK(hipSetDevice(c->device));
+    const long qpad = round_up(Q, QPAD);
+    CHK(c->kq.reserve((size_t)3 * qpad));
+    CHK(c->k_d2.reserve((size_t)Q));
+    CHK(c->k_idx.reserve((size_t)Q));
+    DevBuf<int64_t> sel; DevBuf<uint8_t> mask;
+    int rc = mask.reserve(Q);
+    if (rc == SICP_OK && sel_idx) rc = sel.reserve(Q);
+    auto body = [&]() -> int {
+        if (sel_idx) {
+            for (int64_t i = 0; i < Q; ++i)
+                if (sel_idx[i] < 0 || sel_idx[i] >= qc.n) return fail(SICP_ERR_INVALID, "sel_idx[%lld] out of range", (long long)i);
+            HIPCHK(hipMemcpyAsync(sel.p, sel_idx, (size_t)Q * sizeof(int64_t), hipMemcpyDefault, c->stream));
+        }
+        launch_gather_queries(c->stream, qc.x(), qc.y(), qc.z(), sel_idx ? sel.p : nullptr, Q, qpad, c->kq.p, c->kq.p + qpad,
+                              c->kq.p + 2 * qpad);
+        Xf X;
+        if (H) H16_to_Xf(H, &X);
+        CHK(knn1_device(c, search_slot, c->kq.p, Q, qpad, H ? &X : nullptr, max_range, nullptr, c->k_d2.p, c->k_idx.p, nullptr));
+        CHK(exchange_best(c, c->k_d2.p, c->k_idx.p, nullptr, Q));
+        launch_found_mask(c->stream, c->k_idx.p, Q, mask.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(in_range_out, mask.p, (size_t)Q, hipMemcpyDefault, c->stream));
+        return sync(c);
+    };
+    if (rc == SICP_OK) rc = body();
+    (void)hipStreamSynchronize(c->stream);
+    sel.release(); mask.release();
+    return rc;
+}
+
 SICP_EXPORT int sicp_estimate_normals(sicp_ctx *c, int slot, const int64_t *sel_idx, int64_t Q, int k, float *normals_out,
                                       float *planarity_out, int64_t *nn_idx_out)
 {

@@ -65,6 +65,7 @@ hipError_t reject_by_sort(hipStream_t s, const double *dist, const uint8_t *flag
                           unsigned long long *keys_a, unsigned long long *keys_b, void *tmp, size_t tmp_bytes,
                           unsigned long long *small);
 void launch_aos_to_soa(hipStream_t s, const double *aos, long n, long npad, double *x, double *y, double *z);
+void launch_found_mask(hipStream_t s, const int64_t *idx, long Q, uint8_t *out);
 void launch_pad_fill(hipStream_t s, double *x, double *y, double *z, long n, long npad);
 void launch_soa_to_aos(hipStream_t s, const double *x, const double *y, const double *z, long n, double *aos);
 void launch_transform(hipStream_t s, double *x, double *y, double *z, long n, const Xf &H);

@@ -87,8 +87,15 @@ __global__ void k_gather_queries(const double *__restrict__ x, const double *__r
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= qpad) return;
-    if (i < Q) { const int64_t s = sel[i]; qx[i] = x[s]; qy[i] = y[s]; qz[i] = z[s]; }
+    if (i < Q) { const int64_t s = sel ? sel[i] : (int64_t)i; qx[i] = x[s]; qy[i] = y[s]; qz[i] = z[s]; }
     else       { qx[i] = 0.0; qy[i] = 0.0; qz[i] = 0.0; }
+}
+
+// select_in_range's verdict (pointcloud.py:165-169): a neighbour exists below the strict bound
+__global__ void k_found_mask(const int64_t *__restrict__ idx, long Q, uint8_t *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Q) out[i] = idx[i] >= 0 ? 1 : 0;
 }
 
 __global__ void k_aos_queries(const double *__restrict__ aos, long Q, long qpad,
@@ -1026,6 +1033,10 @@ void launch_gather_queries(hipStream_t s, const double *x, const double *y, cons
                            long Q, long qpad, double *qx, double *qy, double *qz)
 {
     hipLaunchKernelGGL(k_gather_queries, dim3(cdiv(qpad, 256)), dim3(256), 0, s, x, y, z, sel, Q, qpad, qx, qy, qz);
+}
+void launch_found_mask(hipStream_t s, const int64_t *idx, long Q, uint8_t *out)
+{
+    if (Q > 0) hipLaunchKernelGGL(k_found_mask, dim3(cdiv(Q, 256)), dim3(256), 0, s, idx, Q, out);
 }
 void launch_aos_queries(hipStream_t s, const double *aos, long Q, long qpad, double *qx, double *qy, double *qz)
 {

@@ -22,21 +22,29 @@ exact code the GPU path runs.
 """
 from __future__ import annotations
 
+import sys
+
 from . import _lib
 
 
+def _td():
+    """torch.distributed if the caller's process has imported it -- a process group cannot have been
+    initialised otherwise, and a single-GPU run() must not pay (seconds) for importing torch."""
+    return sys.modules.get("torch.distributed")
+
+
 def is_distributed() -> bool:
+    td = _td()
     try:
-        import torch.distributed as td
-        return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+        return bool(td) and td.is_available() and td.is_initialized() and td.get_world_size() > 1
     except Exception:  # noqa: BLE001
         return False
 
 
 def is_initialized() -> bool:
+    td = _td()
     try:
-        import torch.distributed as td
-        return td.is_available() and td.is_initialized()
+        return bool(td) and td.is_available() and td.is_initialized()
     except Exception:  # noqa: BLE001
         return False
 

@@ -100,7 +100,7 @@ class SimpleICP:
         H = H_from_params(obs)
 
         # both clouds go to HBM once and stay there (straight from the frames' storage: no host gather)
-        fix_rows = pc1._upload(ctx, _lib.FIX)
+        pc1._upload(ctx, _lib.FIX)
         if sharded:
             rank, world = dist.rank_world()
             lo, hi = dist.shard_bounds(pc2.num_points, rank, world)
@@ -117,8 +117,10 @@ class SimpleICP:
             _log.info("Consider partial overlap of point clouds ...")
             cur = pc1.idx_selected
             if len(cur):
-                idx = self._nn_in_movable(ctx, fix_rows(cur), H, float(max_overlap_distance), sharded)
-                pc1.idx_selected = cur[idx >= 0]
+                # both clouds are resident already: only the verdicts cross the host link
+                near = ctx.select_in_range(_lib.FIX, _lib.MOV, None if len(cur) == pc1.num_points else cur, H,
+                                           float(max_overlap_distance))
+                pc1.idx_selected = cur[near]
             if not pc1.num_selected_points > 0:
                 raise SimpleICPException(
                     "Point clouds do not overlap within max_overlap_distance = "
@@ -217,12 +219,6 @@ class SimpleICP:
         return H, X_new, rbp, residuals
 
     # --------------------------------------------------------------------------------------
-    def _nn_in_movable(self, ctx, queries, H, max_dist, sharded):
-        """1-NN index (or -1) of `queries` in the H-transformed movable cloud (job-wide when an
-        exchange is registered: the library all-gathers the shard winners itself)."""
-        idx, _ = ctx.knn(_lib.MOV, queries, k=1, H=H, max_dist=max_dist)
-        return idx[:, 0]
-
     @staticmethod
     def _converged(new, old, min_change) -> bool:
         """simpleicp.py:356-379 on (n, mean, std) triples."""

@@ -172,8 +172,10 @@ class PointCloud(pd.DataFrame):
         cur = self.idx_selected
         if len(cur) == 0:
             return
-        idx, _ = ctx.knn(_lib.MOV, self.X_selected, k=1, max_dist=float(max_range))
-        self.idx_selected = cur[idx[:, 0] >= 0]
+        self._upload(ctx, _lib.FIX)
+        near = ctx.select_in_range(_lib.FIX, _lib.MOV, None if len(cur) == self._num_points else cur,
+                                   max_range=float(max_range))
+        self.idx_selected = cur[near]
 
     # ---- attributes (pointcloud.py:173-203) ---------------------------------------------
     def estimate_normals(self, neighbors: int, _ctx=None, _uploaded=False, _sel=None) -> None:

@@ -63,6 +63,32 @@ def test_knn1_upper_bound_strict(ctx):
     assert np.isinf(d2[1, 0])
 
 
+@pytest.mark.parametrize("nf,nm", [(3, 3), (900, 40_000), (30_000, 60_000)])
+def test_select_in_range_between_resident_clouds(ctx, nf, nm):
+    """sicp_select_in_range (both clouds resident, only the verdicts come back) == the oracle's bounded 1-NN
+    from the same points handed over as host queries; strict bound; all points or a subset."""
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(nf + nm)
+    F = rng.uniform(-20, 20, (nf, 3))
+    M = rng.uniform(-20, 20, (nm, 3))
+    M[: nm // 3, 0] += 25.0                               # part of the searched cloud out of reach
+    ctx.upload(_lib.FIX, F)
+    ctx.upload(_lib.MOV, M)
+    r = 1.5 if nm > 1000 else 12.0
+    for H in (None, _H(2)):
+        want = orc.knn(M, F, k=1, H=H, max_dist=r)[0][:, 0] >= 0
+        got = ctx.select_in_range(_lib.FIX, _lib.MOV, None, H, r)
+        assert got.dtype == np.bool_ and np.array_equal(got, want) and (nf < 100 or 0 < want.sum() < nf)
+        sel = np.unique(rng.integers(0, nf, max(1, nf // 3)))
+        assert np.array_equal(ctx.select_in_range(_lib.FIX, _lib.MOV, sel, H, r), want[sel])
+    assert not ctx.select_in_range(_lib.FIX, _lib.MOV, None, None, 0.0).any()
+    assert ctx.select_in_range(_lib.FIX, _lib.MOV, None, None, np.inf).all()
+    with pytest.raises(_lib.BackendError):
+        ctx.select_in_range(_lib.FIX, _lib.MOV, np.array([nf]), None, 1.0)
+    with pytest.raises(_lib.BackendError):
+        ctx.select_in_range(_lib.MOV, _lib.MOV, None, None, 1.0)
+
+
 @pytest.mark.parametrize("n,q,k", [(20, 5, 2), (5000, 300, 10), (5000, 300, 16), (30_000, 1100, 40),
                                    (3000, 64, 70), (100, 3, 100), (50, 4, 60)])
 def test_knnk_bit_exact(ctx, n, q, k):
