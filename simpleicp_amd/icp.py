@@ -113,15 +113,16 @@ class SimpleICP:
         if debug_dirpath:
             X_fix, X_mov = pc1.X, pc2.X
 
+        sel = pc1.idx_selected            # carried along: every flatnonzero over the mask is a pass over N_f
         if np.isfinite(max_overlap_distance):
             _log.info("Consider partial overlap of point clouds ...")
-            cur = pc1.idx_selected
-            if len(cur):
+            if len(sel):
                 # both clouds are resident already: only the verdicts cross the host link
-                near = ctx.select_in_range(_lib.FIX, _lib.MOV, None if len(cur) == pc1.num_points else cur, H,
+                near = ctx.select_in_range(_lib.FIX, _lib.MOV, None if len(sel) == pc1.num_points else sel, H,
                                            float(max_overlap_distance))
-                pc1.idx_selected = cur[near]
-            if not pc1.num_selected_points > 0:
+                sel = sel[near]
+                pc1.idx_selected = sel
+            if not len(sel) > 0:
                 raise SimpleICPException(
                     "Point clouds do not overlap within max_overlap_distance = "
                     f"{max_overlap_distance:.5f}! Consider increasing the value of "
@@ -129,10 +130,9 @@ class SimpleICP:
                 )
 
         _log.info("Select points for correspondences in fixed point cloud ...")
-        pc1.select_n_points(correspondences)
+        sel = pc1.select_n_points(correspondences, _cur=sel)
         # (simpleicp.py:174,254 save and restore pc1's selection around every iteration because the
         # reference's rejections edit it; here the masks live on the device and pc1 is never touched)
-        sel = pc1.idx_selected
 
         if not set(_ATTRS).issubset(pc1.columns):
             _log.info("Estimate normals of selected points ...")

@@ -153,13 +153,16 @@ class PointCloud(pd.DataFrame):
         """Keeps the currently selected points whose index is in ``indices``."""
         self.idx_selected = np.intersect1d(self.idx_selected, indices)
 
-    def select_n_points(self, n: int) -> None:
+    def select_n_points(self, n: int, _cur=None):
         """Equidistant sub-sampling of the current selection (np.round = half-to-even;
-        duplicates collapse, so fewer than n points may remain) -- pointcloud.py:132-147."""
-        cur = self.idx_selected
+        duplicates collapse, so fewer than n points may remain) -- pointcloud.py:132-147.
+        (Internal callers pass the selection they already hold and get the new one back.)"""
+        cur = self.idx_selected if _cur is None else _cur
         if len(cur) > n:
             pos = np.round(np.linspace(0, len(cur) - 1, n)).astype(int)
-            self.idx_selected = cur[pos]
+            cur = np.unique(cur[pos])
+            self.idx_selected = cur
+        return cur if _cur is not None else None
 
     def select_in_range(self, X: np.ndarray, max_range: float, _ctx=None, _slot=None) -> None:
         """Keeps selected points whose nearest neighbour in X is closer than max_range
