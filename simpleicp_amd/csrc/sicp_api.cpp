@@ -269,6 +269,23 @@ void collect_ready(sicp_ctx *c)
     c->pending.resize(w);
 }
 
+// Kernels that hand a few doubles to the host write them into pinned + mapped memory and then publish a
+// sequence number there: polling that word sees the result a few microseconds before the end-of-kernel
+// signal and spares a copy + hipStreamSynchronize per hand-over.  Falls back to a stream wait.
+int wait_ticket(sicp_ctx *c, const double *flag_word, double seq)
+{
+    volatile const double *flag = flag_word;
+    bool seen = false;
+    for (long spin = 0; spin < 4000000L; ++spin) {
+        if (*flag == seq) { seen = true; break; }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) return sync(c);
+    if (c->timing) collect_ready(c);
+    return SICP_OK;
+}
+
 struct Timed {
     sicp_ctx *c; EventPair ev; bool on;
     Timed(sicp_ctx *ctx, int kernel) : c(ctx), on(ctx->timing)
@@ -630,12 +647,20 @@ int normal_eq_host(sicp_ctx *c, const double x[6], bool write_resid, bool allow_
         hi = std::min<long>(c->Q, lo + per);
     }
     double *d_out = c->small.p + 8;
+    double *h_ne = c->h_small + 128;                      // pinned: [0..29] sums, [31] ticket
+    const double seq = (double)(++c->solve_seq);
     {
         Timed t(c, SICP_K_NORMALEQ);
         launch_normal_eq(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->m_p2.p, c->keep.p,
-                         lo, hi, H12, dR, c->ne_partial.p, c->ticket.p, d_out, write_resid ? c->resid.p : nullptr);
+                         lo, hi, H12, dR, c->ne_partial.p, c->ticket.p, d_out, write_resid ? c->resid.p : nullptr,
+                         shard ? nullptr : h_ne, seq);
     }
     HIPCHK(hipGetLastError());
+    if (!shard) {
+        CHK(wait_ticket(c, h_ne + 31, seq));
+        std::memcpy(out, h_ne, 30 * sizeof(double));
+        return SICP_OK;
+    }
     if (shard) {
         if (c->xfn(c->xuser, SICP_XCHG_SUM_F64, d_out, nullptr, nullptr, 30) != 0)
             return fail(SICP_ERR_EXCHANGE, "exchange callback (SUM_F64) failed");
@@ -687,7 +712,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
         return fail(SICP_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, arch.c_str());
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipStreamCreate failed"); }
-    if (hipHostMalloc((void **)&c->h_small, 128 * sizeof(double), hipHostMallocMapped) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipHostMalloc failed"); }
+    if (hipHostMalloc((void **)&c->h_small, 256 * sizeof(double), hipHostMallocMapped) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipHostMalloc failed"); }
     int rc = c->small.reserve(128);
     if (rc == SICP_OK) rc = c->ne_partial.reserve((size_t)NE_MAX_GRID * 32);
     if (rc == SICP_OK) rc = c->ticket.reserve(4);
@@ -1003,23 +1028,11 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
         }
         HIPCHK(hipGetLastError());
         const auto h2 = std::chrono::steady_clock::now();
-        // the kernel publishes a ticket in pinned memory once its results are there: poll it (a few us
-        // sooner than the end-of-kernel signal); fall back to a stream wait if it does not show up
-        {
-            volatile double *flag = c->h_small + 64 + 55;
-            bool seen = false;
-            for (long spin = 0; spin < 4000000L; ++spin) {
-                if (*flag == A.seq) { seen = true; break; }
-                __builtin_ia32_pause();
-            }
-            std::atomic_thread_fence(std::memory_order_acquire);
-            if (htrace) {
-                const auto h3 = std::chrono::steady_clock::now();
-                auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-                std::fprintf(stderr, "[host] match launch %.1f us, solve launch %.1f us, wait %.1f us\n", us(h0, h1), us(h1, h2), us(h2, h3));
-            }
-            if (!seen) CHK(sync(c));
-            else if (c->timing) collect_ready(c);
+        CHK(wait_ticket(c, c->h_small + 64 + 55, A.seq));
+        if (htrace) {
+            const auto h3 = std::chrono::steady_clock::now();
+            auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            std::fprintf(stderr, "[host] match launch %.1f us, solve launch %.1f us, wait %.1f us\n", us(h0, h1), us(h1, h2), us(h2, h3));
         }
         const double *o = c->h_small + 64;
         R->n_queries = Q; R->n_planar = (int64_t)o[0]; R->median = o[1]; R->mad = o[2]; R->n_kept = (int64_t)o[3];
@@ -1058,7 +1071,7 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
                      c->m_idx.p, Q, X, (float)P->min_planarity, c->dist.p, c->flag.p);
     {
         Timed t(c, SICP_K_SELECT);
-        if (Q > 16384) {
+        if (Q > REJECT_MAX_Q) {
             // one workgroup cannot chew a million distances: exact order statistics by device radix sort
             const size_t tb = reject_sort_temp_bytes(Q);
             CHK(c->g_tmp.reserve(tb + 256));
@@ -1071,15 +1084,16 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
             launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p);
         }
     }
-    launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4);
+    double *h_st = c->h_small + 160;                      // pinned: [0..3] rejection, [4..6] n / mean / std, [15] ticket
+    double seq = (double)(++c->solve_seq);
+    launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4, c->small.p, h_st, seq);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_small, c->small.p, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    CHK(sync(c));
+    CHK(wait_ticket(c, h_st + 15, seq));
     R->n_queries = Q;
-    R->n_planar = (int64_t)c->h_small[0];
-    R->median = c->h_small[1]; R->mad = c->h_small[2];
-    R->n_kept = (int64_t)c->h_small[3];
-    R->dist_mean = c->h_small[5]; R->dist_std = c->h_small[6];
+    R->n_planar = (int64_t)h_st[0];
+    R->median = h_st[1]; R->mad = h_st[2];
+    R->n_kept = (int64_t)h_st[3];
+    R->dist_mean = h_st[5]; R->dist_std = h_st[6];
     c->have_iter = true;
     std::memcpy(c->last_x, P->x, sizeof c->last_x);
     if (R->n_kept < 6) {
@@ -1143,11 +1157,11 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
     // ---- residuals at the optimum (optimization.py:117-124) + their mean/std (simpleicp.py:356-379) ----
     CHK(normal_eq_host(c, x, true, false, ne)); R->ne_evals++;
     cost = objective(ne, w, x, obs, ow);
-    launch_stats(c->stream, c->resid.p, c->keep.p, Q, c->small.p + 4);
+    seq = (double)(++c->solve_seq);
+    launch_stats(c->stream, c->resid.p, c->keep.p, Q, c->small.p + 4, nullptr, h_st, seq);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_small + 4, c->small.p + 4, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    CHK(sync(c));
-    R->res_mean = c->h_small[5]; R->res_std = c->h_small[6];
+    CHK(wait_ticket(c, h_st + 15, seq));
+    R->res_mean = h_st[5]; R->res_std = h_st[6];
     R->cost = cost;
     std::memcpy(R->x, x, sizeof x);
     params_to_H12(x, R->H);

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "sicp_internal.h"
+#include "sicp_lanes.h"
 
 namespace sicp {
 
@@ -164,10 +165,8 @@ __global__ __launch_bounds__(256) void k_grid_nn(
                 b = cell_start[row + lo[0]];
                 len = cell_start[row + hi[0] + 1] - b;
             }
-            uint32_t incl = len;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
-            const uint32_t total = __shfl(incl, 63, 64);
+            const uint32_t incl = wscan_u32(len);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             // four flat candidates per lane per round: their (row, offset) searches and coordinate loads
             // are independent, so four memory round trips overlap (wave-uniform trip count: the
             // shuffles need all lanes)
@@ -204,13 +203,15 @@ __global__ __launch_bounds__(256) void k_grid_nn(
                 }
             }
         }
-        // wave-wide lexicographic (d2, original index) minimum
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double od = __shfl_xor(best, off, 64);
-            const uint32_t oi = __shfl_xor(bidx, off, 64), op = __shfl_xor(bpos, off, 64);
-            if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; bpos = op; }
+        // wave-wide lexicographic (d2, original index) minimum: DPP butterfly, every lane ends up with it
+#define SICP_LEXMIN_STEP(J)                                                                       \
+        {                                                                                         \
+            const double od = lane_xor_f64<J>(best);                                              \
+            const uint32_t oi = lane_xor32<J>(bidx), op = lane_xor32<J>(bpos);                    \
+            if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; bpos = op; }      \
         }
+        SICP_LEXMIN_STEP(32) SICP_LEXMIN_STEP(16) SICP_LEXMIN_STEP(8) SICP_LEXMIN_STEP(4) SICP_LEXMIN_STEP(2) SICP_LEXMIN_STEP(1)
+#undef SICP_LEXMIN_STEP
         const bool found = bidx != 0xffffffffu;
         const double r_eff = (r - slack) / (1.0 + 1e-12);
         if (found && sqrt(best) <= r_eff) break;          // nothing outside the ball can beat or tie it

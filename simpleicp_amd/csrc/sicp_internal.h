@@ -14,6 +14,7 @@ constexpr int    TILE_PTS  = 1024;    // cloud points staged in LDS per step (24
 constexpr int    FS_TILE   = 512;     // points per LDS tile of the filtered scan (float4: 8 KiB, x2 buffers)
 constexpr int    FS_R      = 8;       // queries per lane of the filtered scan
 constexpr int    FS_G      = 8;       // points between two slow-path checks of the filtered scan
+constexpr int    REJECT_MAX_Q = 16384;   // single-workgroup rejection: its uint64 keys live in LDS (128 KB)
 constexpr int    QPAD      = 2048;    // query padding granule (covers R = 4 and R = 8 scan blocks)
 constexpr int    NE_BLOCK  = 256;
 constexpr int    NE_MAX_GRID = 1024;
@@ -104,10 +105,12 @@ void launch_postmatch(hipStream_t s, const double *qx, const double *qy, const d
                       const float *planarity, const double *p2, const int64_t *idx, long Q, const Xf &H,
                       float min_planarity, double *dist, uint8_t *flag);
 void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4);
-void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3);
+void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3, const double *also4 = nullptr,
+                  double *host_out = nullptr, double seq = 0.0);
 int  ne_grid_for(long count);
 void launch_normal_eq(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
                       const double *p2, const uint8_t *keep, long lo, long hi, const double H12[12], const double dR[27],
-                      double *partial, unsigned *ticket, double *out30, double *resid);
+                      double *partial, unsigned *ticket, double *out30, double *resid, double *host_out = nullptr,
+                      double seq = 0.0);
 
 }  // namespace sicp

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "sicp_internal.h"
+#include "sicp_lanes.h"
 
 namespace sicp {
 
@@ -37,12 +38,8 @@ __device__ __forceinline__ double plane_dist(double dx, double dy, double dz, fl
     return (a + b) + c;
 }
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
+// (every lane gets the total; DPP butterfly, see sicp_lanes.h -- a __shfl_down chain costs ~1500 cycles)
+__device__ __forceinline__ double wave_sum(double v) { return wsum(v); }
 
 // ------------------------------------------------------------------------------------
 // cloud upload: AoS (n,3) -> padded SoA                       PointCloud ctor, pointcloud.py:15-49
@@ -734,9 +731,14 @@ __global__ void k_postmatch(const double *__restrict__ qx, const double *__restr
 // K6: median / raw-MAD rejection      corrpts.py:165-188  (np.median: mean of the two
 // middle values for even counts; scipy median_abs_deviation with scale = 1.0)
 //
-// One 1024-lane workgroup, everything in a single launch: exact order statistics by
-// 8-bit-digit radix selection on the order-preserving uint64 image of the doubles
-// (8 passes per rank, LDS histogram + wave scan), then the keep mask and its count.
+// One 1024-lane workgroup, one launch, Q <= REJECT_MAX_Q: the order-preserving uint64 images of the
+// flagged distances are staged in LDS ONCE (128 KB of the CU's 160 KB; unflagged rows hold an
+// all-ones sentinel that sorts last) and every later pass reads LDS, not L2.  Exact order statistics by
+// 8-bit-digit radix selection (8 passes: LDS histogram + wave scan); the SECOND middle value of an even
+// count costs one more pass (how many keys <= the first, and the smallest key above it) instead of
+// eight.  Distances share sign/exponent bytes, so whole waves hit one histogram bin in the early
+// passes: lanes with the leader's bin are counted by ballot and added once (two rounds), the rest add
+// individually -- without this the pass serialises ~Q atomics on one LDS word.
 // out[0]=m (planarity survivors) out[1]=median out[2]=mad out[3]=n_kept
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t ord_key(double v)
@@ -750,99 +752,144 @@ __device__ __forceinline__ double ord_val(uint64_t k)
     return __longlong_as_double((long long)b);
 }
 
-// selects the element of rank `rank` (0-based) among flagged values f(d[i]); ABSDEV: f = |d - center|
-template <bool ABSDEV>
-__device__ double radix_select(const double *__restrict__ d, const uint8_t *__restrict__ flag, long Q,
-                               long rank, double center, unsigned *hist /*[256]*/, unsigned long long *sh /*[2]*/)
+struct RejectShared {
+    uint64_t key[REJECT_MAX_Q];
+    unsigned hist[256];
+    unsigned long long sh[4];
+};
+
+// key of rank `rank` (0-based) among the n LDS keys
+__device__ uint64_t lds_radix_select(RejectShared &S, int n, long rank)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     uint64_t prefix = 0;
     for (int pass = 0; pass < 8; ++pass) {
         const int shift = 56 - 8 * pass;
-        if (tid < 256) hist[tid] = 0;
+        if (tid < 256) S.hist[tid] = 0;
         __syncthreads();
-        for (long i = tid; i < Q; i += blockDim.x) {
-            if (!flag[i]) continue;
-            const double v = ABSDEV ? fabs(d[i] - center) : d[i];
-            const uint64_t k = ord_key(v);
-            if (pass == 0 || (k >> (shift + 8)) == (prefix >> (shift + 8)))
-                atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+        for (int base = 0; base < n; base += 1024) {           // wave-uniform trip count (ballots below)
+            const int i = base + tid;
+            const uint64_t k = i < n ? S.key[i] : 0;
+            bool act = i < n && (pass == 0 || (k >> (shift + 8)) == (prefix >> (shift + 8)));
+            const unsigned bin = (unsigned)(k >> shift) & 255u;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned long long am = __ballot(act);
+                if (am == 0) break;
+                const int leader = __ffsll((long long)am) - 1;
+                const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+                const unsigned long long same = __ballot(act && bin == b0);
+                if (lane == leader) atomicAdd(&S.hist[b0], (unsigned)__popcll(same));
+                act = act && bin != b0;
+            }
+            if (act) atomicAdd(&S.hist[bin], 1u);
         }
         __syncthreads();
         if (tid < 64) {
             // wave 0: lane l owns bins 4l..4l+3
-            const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const unsigned h0 = S.hist[4 * tid], h1 = S.hist[4 * tid + 1], h2 = S.hist[4 * tid + 2], h3 = S.hist[4 * tid + 3];
             const unsigned mine = h0 + h1 + h2 + h3;
-            unsigned incl = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned t = __shfl_up(incl, off, 64);
-                if (tid >= off) incl += t;
-            }
+            const unsigned incl = wscan_u32(mine);
             const unsigned long long excl = incl - mine;
             const unsigned long long r = (unsigned long long)rank;
             if (r >= excl && r < excl + mine) {
                 unsigned long long acc = excl; int bin = 4 * tid;
                 if (r >= acc + h0) { acc += h0; bin++; if (r >= acc + h1) { acc += h1; bin++; if (r >= acc + h2) { acc += h2; bin++; } } }
-                sh[0] = (unsigned long long)bin;
-                sh[1] = r - acc;
+                S.sh[0] = (unsigned long long)bin;
+                S.sh[1] = r - acc;
             }
         }
         __syncthreads();
-        prefix |= ((uint64_t)sh[0]) << shift;
-        rank = (long)sh[1];
+        prefix |= ((uint64_t)S.sh[0]) << shift;
+        rank = (long)S.sh[1];
         __syncthreads();
     }
-    return ord_val(prefix);
+    return prefix;
+}
+
+// key of rank r+1 given ka = the key of rank r: ka again if enough keys are <= ka, else the smallest key above it
+__device__ uint64_t lds_next_rank(RejectShared &S, int n, long r, uint64_t ka)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) { S.sh[2] = 0; S.sh[3] = ~0ull; }
+    __syncthreads();
+    unsigned long long le = 0, nxt = ~0ull;
+    for (int i = tid; i < n; i += 1024) {
+        const uint64_t k = S.key[i];
+        if (k <= ka) le += 1; else nxt = k < nxt ? k : nxt;
+    }
+    le = wsum_u64(le);
+    { unsigned long long o;
+      o = lane_xor64<32>(nxt); nxt = o < nxt ? o : nxt;  o = lane_xor64<16>(nxt); nxt = o < nxt ? o : nxt;
+      o = lane_xor64<8>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<4>(nxt);  nxt = o < nxt ? o : nxt;
+      o = lane_xor64<2>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<1>(nxt);  nxt = o < nxt ? o : nxt; }
+    if (lane == 0) { atomicAdd(&S.sh[2], le); atomicMin(&S.sh[3], nxt); }
+    __syncthreads();
+    const uint64_t kb = ((long)S.sh[2] >= r + 2) ? ka : (uint64_t)S.sh[3];
+    __syncthreads();
+    return kb;
 }
 
 __global__ __launch_bounds__(1024) void k_reject(const double *__restrict__ dist, const uint8_t *__restrict__ flag,
                                                  long Q, uint8_t *__restrict__ keep, double *__restrict__ out)
 {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned long long sh[2];
-    __shared__ unsigned long long cnt;
-    const int tid = threadIdx.x;
-    if (tid == 0) cnt = 0;
+    __shared__ RejectShared S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = (int)Q;
+    if (tid == 0) S.sh[2] = 0;
     __syncthreads();
     unsigned long long local = 0;
-    for (long i = tid; i < Q; i += blockDim.x) local += flag[i] ? 1 : 0;
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if ((tid & 63) == 0 && local) atomicAdd(&cnt, local);
+    for (int i = tid; i < n; i += 1024) {
+        const bool f = flag[i] != 0;
+        S.key[i] = f ? ord_key(dist[i]) : ~0ull;
+        local += f ? 1 : 0;
+    }
+    local = wsum_u64(local);
+    if (lane == 0 && local) atomicAdd(&S.sh[2], local);
     __syncthreads();
-    const long m = (long)cnt;
+    const long m = (long)S.sh[2];
     __syncthreads();
     if (m == 0) {
-        for (long i = tid; i < Q; i += blockDim.x) keep[i] = 0;
+        for (int i = tid; i < n; i += 1024) keep[i] = 0;
         if (tid == 0) { out[0] = 0; out[1] = __builtin_nan(""); out[2] = __builtin_nan(""); out[3] = 0; }
         return;
     }
-    const double a = radix_select<false>(dist, flag, Q, (m - 1) / 2, 0.0, hist, sh);
-    const double b = (m & 1) ? a : radix_select<false>(dist, flag, Q, m / 2, 0.0, hist, sh);
-    const double med = (a + b) / 2.0;
-    const double c = radix_select<true>(dist, flag, Q, (m - 1) / 2, med, hist, sh);
-    const double e = (m & 1) ? c : radix_select<true>(dist, flag, Q, m / 2, med, hist, sh);
-    const double mad = (c + e) / 2.0;
+    const uint64_t ka = lds_radix_select(S, n, (m - 1) / 2);
+    const uint64_t kb = (m & 1) ? ka : lds_next_rank(S, n, (m - 1) / 2, ka);
+    const double med = (ord_val(ka) + ord_val(kb)) / 2.0;
+    for (int i = tid; i < n; i += 1024) {
+        const uint64_t k = S.key[i];
+        if (k != ~0ull) S.key[i] = ord_key(fabs(ord_val(k) - med));
+    }
+    __syncthreads();
+    const uint64_t kc = lds_radix_select(S, n, (m - 1) / 2);
+    const uint64_t ke = (m & 1) ? kc : lds_next_rank(S, n, (m - 1) / 2, kc);
+    const double mad = (ord_val(kc) + ord_val(ke)) / 2.0;
     const double bound = 3 * mad;
-    if (tid == 0) cnt = 0;
+    if (tid == 0) S.sh[2] = 0;
     __syncthreads();
     local = 0;
-    for (long i = tid; i < Q; i += blockDim.x) {
-        const uint8_t kq = (flag[i] && fabs(dist[i] - med) <= bound) ? 1 : 0;
+    for (int i = tid; i < n; i += 1024) {
+        const uint64_t k = S.key[i];
+        const uint8_t kq = (k != ~0ull && ord_val(k) <= bound) ? 1 : 0;      // key = |d - med| of a flagged row
         keep[i] = kq; local += kq;
     }
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if ((tid & 63) == 0 && local) atomicAdd(&cnt, local);
+    local = wsum_u64(local);
+    if (lane == 0 && local) atomicAdd(&S.sh[2], local);
     __syncthreads();
-    if (tid == 0) { out[0] = (double)m; out[1] = med; out[2] = mad; out[3] = (double)cnt; }
+    if (tid == 0) { out[0] = (double)m; out[1] = med; out[2] = mad; out[3] = (double)S.sh[2]; }
 }
 
 // ------------------------------------------------------------------------------------
 // masked mean / population std (two-pass, np.std ddof=0)     simpleicp.py:233-234,356-379
 // single workgroup; out[0]=n out[1]=mean out[2]=std
 // ------------------------------------------------------------------------------------
+// host_out (nullable, pinned + mapped): [0..3] = also4 (the rejection's m / median / mad / n_kept, written by the
+// launch before on this stream), [4..6] = n / mean / std, then the completion ticket [15] = seq -- the host polls it
+// instead of paying a copy + stream synchronisation.
 __global__ __launch_bounds__(1024) void k_stats(const double *__restrict__ v, const uint8_t *__restrict__ keep,
-                                                long Q, double *__restrict__ out)
+                                                long Q, double *__restrict__ out, const double *__restrict__ also4,
+                                                double *__restrict__ host_out, double seq)
 {
     __shared__ double red[16];
     __shared__ double bc[2];
@@ -868,7 +915,14 @@ __global__ __launch_bounds__(1024) void k_stats(const double *__restrict__ v, co
     __syncthreads();
     if (tid == 0) {
         double t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
-        out[0] = cnt; out[1] = mean; out[2] = sqrt(t / cnt);
+        const double sd = sqrt(t / cnt);
+        out[0] = cnt; out[1] = mean; out[2] = sd;
+        if (host_out) {
+            if (also4) { host_out[0] = also4[0]; host_out[1] = also4[1]; host_out[2] = also4[2]; host_out[3] = also4[3]; }
+            host_out[4] = cnt; host_out[5] = mean; host_out[6] = sd;
+            __threadfence_system();
+            __hip_atomic_store(host_out + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -894,7 +948,8 @@ __global__ __launch_bounds__(NE_BLOCK) void k_normal_eq(
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
     const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep,
     long lo, long hi, NeArgs A, double *__restrict__ partial /*[grid][32]*/, unsigned *__restrict__ ticket,
-    double *__restrict__ out /*[30]*/, double *__restrict__ resid /* nullable, (Q) */)
+    double *__restrict__ out /*[30]*/, double *__restrict__ resid /* nullable, (Q) */,
+    double *__restrict__ host_out /* nullable, pinned + mapped: [0..29] = out, ticket [31] = seq */, double seq)
 {
     __shared__ double red[NE_BLOCK / 64][32];
     __shared__ int is_last;
@@ -963,8 +1018,17 @@ __global__ __launch_bounds__(NE_BLOCK) void k_normal_eq(
             double s = 0;
             for (unsigned b = 0; b < gridDim.x; ++b) s += partial[(long)b * 32 + tid];
             out[tid] = s;
+            if (host_out) host_out[tid] = s;
         }
         if (tid == 0) *ticket = 0;   // re-arm for the next launch on this stream
+        if (host_out) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                     // is_last is block-uniform
+            if (tid == 0) {
+                __threadfence_system();
+                __hip_atomic_store(host_out + 31, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
@@ -1213,9 +1277,10 @@ void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long 
     hipLaunchKernelGGL(k_reject, dim3(1), dim3(1024), 0, s, dist, flag, Q, keep, out4);
 }
 
-void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3)
+void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3, const double *also4,
+                  double *host_out, double seq)
 {
-    hipLaunchKernelGGL(k_stats, dim3(1), dim3(1024), 0, s, v, keep, Q, out3);
+    hipLaunchKernelGGL(k_stats, dim3(1), dim3(1024), 0, s, v, keep, Q, out3, also4, host_out, seq);
 }
 
 int ne_grid_for(long count)
@@ -1228,13 +1293,13 @@ int ne_grid_for(long count)
 
 void launch_normal_eq(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
                       const double *p2, const uint8_t *keep, long lo, long hi, const double H12[12], const double dR[27],
-                      double *partial, unsigned *ticket, double *out30, double *resid)
+                      double *partial, unsigned *ticket, double *out30, double *resid, double *host_out, double seq)
 {
     NeArgs A;
     for (int i = 0; i < 12; ++i) A.H.m[i] = H12[i];
     for (int i = 0; i < 27; ++i) A.dR[i] = dR[i];
     hipLaunchKernelGGL(k_normal_eq, dim3(ne_grid_for(hi - lo)), dim3(NE_BLOCK), 0, s, qx, qy, qz, normals, p2, keep, lo,
-                       hi, A, partial, ticket, out30, resid);
+                       hi, A, partial, ticket, out30, resid, host_out, seq);
 }
 
 }  // namespace sicp

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "sicp_internal.h"
+#include "sicp_lanes.h"
 
 namespace sicp {
 
@@ -26,40 +27,6 @@ __device__ __forceinline__ double pdist(double dx, double dy, double dz, float n
 {
     const double a = dx * (double)nx, b = dy * (double)ny, c = dz * (double)nz;
     return (a + b) + c;
-}
-// value of v held by lane (lane ^ J), J < 64, without touching LDS: DPP quad_perm for J = 1, 2;
-// J = 4 = row_half_mirror (i^7) then quad reverse (i^3); J = 8 = row_mirror (i^15) then row_half_mirror;
-// J = 16 / 32 = gfx950's v_permlane16_swap / v_permlane32_swap.  (scripts/ubench/lane_xor.hip checks them.)
-typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_mov(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
-template <int J>
-__device__ __forceinline__ unsigned lane_xor32(unsigned v)
-{
-    if constexpr (J == 1) return dpp_mov<0xB1>(v);
-    else if constexpr (J == 2) return dpp_mov<0x4E>(v);
-    else if constexpr (J == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));
-    else if constexpr (J == 8) return dpp_mov<0x141>(dpp_mov<0x140>(v));
-    else if constexpr (J == 16) { const v2u_t r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (threadIdx.x & 16) ? r.x : r.y; }
-    else { const v2u_t r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (threadIdx.x & 32) ? r.x : r.y; }
-}
-template <int J>
-__device__ __forceinline__ unsigned long long lane_xor64(unsigned long long v)
-{
-    const unsigned lo = lane_xor32<J>((unsigned)v), hi = lane_xor32<J>((unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-// wave-wide sum by a register-speed butterfly (every lane ends up with the total); the LDS-crossbar
-// shuffles (__shfl_down = ds_bpermute) cost ~250 cycles per step here, a DPP move a few
-__device__ __forceinline__ double wsum(double v)
-{
-    v += __longlong_as_double((long long)lane_xor64<32>((unsigned long long)__double_as_longlong(v)));
-    v += __longlong_as_double((long long)lane_xor64<16>((unsigned long long)__double_as_longlong(v)));
-    v += __longlong_as_double((long long)lane_xor64<8>((unsigned long long)__double_as_longlong(v)));
-    v += __longlong_as_double((long long)lane_xor64<4>((unsigned long long)__double_as_longlong(v)));
-    v += __longlong_as_double((long long)lane_xor64<2>((unsigned long long)__double_as_longlong(v)));
-    v += __longlong_as_double((long long)lane_xor64<1>((unsigned long long)__double_as_longlong(v)));
-    return v;
 }
 __device__ __forceinline__ unsigned long long okey(double v)
 {
