@@ -2,7 +2,7 @@
 library's own HIP events report.   python scripts/q_sweep.py [n_points] [Q ...]"""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 from simpleicp_amd import _lib
 

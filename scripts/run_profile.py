@@ -3,7 +3,7 @@ by ABI call: where a caller's time goes once the iterations themselves cost micr
     python scripts/run_profile.py [n_points] [correspondences] [max_overlap_distance]"""
 import cProfile, pstats, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 from simpleicp_amd import PointCloud, SimpleICP, _lib
 

@@ -1086,7 +1086,7 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
     }
     double *h_st = c->h_small + 160;                      // pinned: [0..3] rejection, [4..6] n / mean / std, [15] ticket
     double seq = (double)(++c->solve_seq);
-    launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4, c->small.p, h_st, seq);
+    launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4, c->small.p, h_st, seq, c->ne_partial.p, c->ticket.p);
     HIPCHK(hipGetLastError());
     CHK(wait_ticket(c, h_st + 15, seq));
     R->n_queries = Q;
@@ -1158,7 +1158,7 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
     CHK(normal_eq_host(c, x, true, false, ne)); R->ne_evals++;
     cost = objective(ne, w, x, obs, ow);
     seq = (double)(++c->solve_seq);
-    launch_stats(c->stream, c->resid.p, c->keep.p, Q, c->small.p + 4, nullptr, h_st, seq);
+    launch_stats(c->stream, c->resid.p, c->keep.p, Q, c->small.p + 4, nullptr, h_st, seq, c->ne_partial.p, c->ticket.p);
     HIPCHK(hipGetLastError());
     CHK(wait_ticket(c, h_st + 15, seq));
     R->res_mean = h_st[5]; R->res_std = h_st[6];

@@ -18,6 +18,7 @@ constexpr int    REJECT_MAX_Q = 16384;   // single-workgroup rejection: its uint
 constexpr int    QPAD      = 2048;    // query padding granule (covers R = 4 and R = 8 scan blocks)
 constexpr int    NE_BLOCK  = 256;
 constexpr int    NE_MAX_GRID = 1024;
+constexpr long   STATS_MB_MIN_Q = 16384;  // above: mean / std over many workgroups (two launches) instead of one CU
 #define SICP_PAD_COORD 1.0e300
 
 // fused single-workgroup tail of the iteration (sicp_solve.hip)
@@ -106,7 +107,7 @@ void launch_postmatch(hipStream_t s, const double *qx, const double *qy, const d
                       float min_planarity, double *dist, uint8_t *flag);
 void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4);
 void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3, const double *also4 = nullptr,
-                  double *host_out = nullptr, double seq = 0.0);
+                  double *host_out = nullptr, double seq = 0.0, double *partial = nullptr, unsigned *ticket = nullptr);
 int  ne_grid_for(long count);
 void launch_normal_eq(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
                       const double *p2, const uint8_t *keep, long lo, long hi, const double H12[12], const double dR[27],

@@ -11,6 +11,7 @@
 //   queries    : SoA  qx|qy|qz [qpad] float64, qpad = Q rounded up to 1024.
 //   partials   : [nchunks][qpad] (d2 f64, idx u32) -- one row per chunk of the scanned cloud.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include "sicp_internal.h"
@@ -926,6 +927,64 @@ __global__ __launch_bounds__(1024) void k_stats(const double *__restrict__ v, co
     }
 }
 
+// The same statistics over many workgroups (Q in the 10^5..10^6 range, where one CU would spend hundreds of
+// microseconds streaming the vector twice): PHASE 0 = count and mean, PHASE 1 = deviation from that mean
+// (two-pass like np.std).  Block partials are folded by the last block to arrive (agent-scope ticket, as in
+// k_normal_eq), lanes striding over the blocks + a butterfly: a fixed order for a given grid.
+template <int PHASE>
+__global__ __launch_bounds__(256) void k_stats_mb(const double *__restrict__ v, const uint8_t *__restrict__ keep, long Q,
+                                                  double *__restrict__ out, double *__restrict__ partial /*[2][NE_MAX_GRID]*/,
+                                                  unsigned *__restrict__ ticket, const double *__restrict__ also4,
+                                                  double *__restrict__ host_out, double seq)
+{
+    __shared__ double red[4][2];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const double mean = PHASE == 1 ? out[1] : 0.0;
+    double a = 0, b = 0;
+    for (long i = (long)blockIdx.x * 256 + tid; i < Q; i += (long)gridDim.x * 256)
+        if (keep[i]) {
+            if (PHASE == 0) { a += v[i]; b += 1; }
+            else { const double e = v[i] - mean; a += e * e; }
+        }
+    a = wsum(a); b = wsum(b);
+    if (lane == 0) { red[wid][0] = a; red[wid][1] = b; }
+    __syncthreads();
+    if (tid < 2) partial[(long)tid * NE_MAX_GRID + blockIdx.x] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (t == gridDim.x - 1) ? 1 : 0;
+        if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!is_last) return;
+    if (wid < 2) {
+        double s = 0;
+        for (unsigned blk = lane; blk < gridDim.x; blk += 64) s += partial[(long)wid * NE_MAX_GRID + blk];
+        s = wsum(s);
+        if (lane == 0) red[0][wid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        *ticket = 0;
+        if (PHASE == 0) { out[0] = red[0][1]; out[1] = red[0][0] / red[0][1]; }
+        else {
+            const double cnt = out[0], sd = sqrt(red[0][0] / cnt);
+            out[2] = sd;
+            if (host_out) {
+                if (also4) { host_out[0] = also4[0]; host_out[1] = also4[1]; host_out[2] = also4[2]; host_out[3] = also4[3]; }
+                host_out[4] = cnt; host_out[5] = out[1]; host_out[6] = sd;
+                __threadfence_system();
+                __hip_atomic_store(host_out + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // K7: fused residual + rejection mask + 6x6 normal-equation reduction
 //     optimization.py:172-288 (residual), c++/src/corrpts.cpp:110-156 (row layout twin)
@@ -947,7 +1006,7 @@ struct NeArgs {
 __global__ __launch_bounds__(NE_BLOCK) void k_normal_eq(
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
     const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep,
-    long lo, long hi, NeArgs A, double *__restrict__ partial /*[grid][32]*/, unsigned *__restrict__ ticket,
+    long lo, long hi, NeArgs A, double *__restrict__ partial /*[30][NE_MAX_GRID]*/, unsigned *__restrict__ ticket,
     double *__restrict__ out /*[30]*/, double *__restrict__ resid /* nullable, (Q) */,
     double *__restrict__ host_out /* nullable, pinned + mapped: [0..29] = out, ticket [31] = seq */, double seq)
 {
@@ -999,7 +1058,7 @@ __global__ __launch_bounds__(NE_BLOCK) void k_normal_eq(
         double s = 0;
 #pragma unroll
         for (int w = 0; w < NE_BLOCK / 64; ++w) s += red[w][tid];
-        partial[(long)blockIdx.x * 32 + tid] = s;
+        partial[(long)tid * NE_MAX_GRID + blockIdx.x] = s;       // column-major: the fold below reads it coalesced
     }
     // publish this block's partial, then take a ticket (guide G16: stores -> vmcnt(0) ->
     // barrier -> one-lane agent release -> ticket; last arriver: agent acquire -> plain loads)
@@ -1014,11 +1073,13 @@ __global__ __launch_bounds__(NE_BLOCK) void k_normal_eq(
     }
     __syncthreads();
     if (is_last) {
-        if (tid < 30) {
+        // fold the block partials: wave w takes columns w, w+4, ...; its lanes stride over the blocks and a
+        // butterfly adds them up -- a fixed order for a given grid, and no 1024-long dependent chain
+        for (int col = wid; col < 30; col += NE_BLOCK / 64) {
             double s = 0;
-            for (unsigned b = 0; b < gridDim.x; ++b) s += partial[(long)b * 32 + tid];
-            out[tid] = s;
-            if (host_out) host_out[tid] = s;
+            for (unsigned b = lane; b < gridDim.x; b += 64) s += partial[(long)col * NE_MAX_GRID + b];
+            s = wsum(s);
+            if (lane == 0) { out[col] = s; if (host_out) host_out[col] = s; }
         }
         if (tid == 0) *ticket = 0;   // re-arm for the next launch on this stream
         if (host_out) {
@@ -1278,8 +1339,14 @@ void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long 
 }
 
 void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3, const double *also4,
-                  double *host_out, double seq)
+                  double *host_out, double seq, double *partial, unsigned *ticket)
 {
+    if (partial && ticket && Q > STATS_MB_MIN_Q) {
+        const int g = (int)std::min<long>(NE_MAX_GRID, (Q + 1023) / 1024);
+        hipLaunchKernelGGL(k_stats_mb<0>, dim3(g), dim3(256), 0, s, v, keep, Q, out3, partial, ticket, also4, host_out, seq);
+        hipLaunchKernelGGL(k_stats_mb<1>, dim3(g), dim3(256), 0, s, v, keep, Q, out3, partial, ticket, also4, host_out, seq);
+        return;
+    }
     hipLaunchKernelGGL(k_stats, dim3(1), dim3(1024), 0, s, v, keep, Q, out3, also4, host_out, seq);
 }
 

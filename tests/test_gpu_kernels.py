@@ -370,6 +370,9 @@ def test_large_q_iteration_multi_kernel_path(ctx):
         assert R.n_kept == o["n"] and R.median == o["median"] and R.mad == o["mad"]
         x = np.array(R.x[:])
         assert np.abs(x - o["x"]).max() < 1e-9
+        # multi-workgroup two-pass statistics (count / mean / population std) against numpy's
+        assert abs(R.dist_mean - dist[keep].mean()) < 1e-15 and abs(R.dist_std - dist[keep].std()) < 1e-14
+        assert abs(R.res_mean - resid[keep].mean()) < 1e-15 and abs(R.res_std - resid[keep].std()) < 1e-14
 
 
 @pytest.mark.parametrize("variant,cap", [("inline", None), ("record", 1), ("record", None)])
