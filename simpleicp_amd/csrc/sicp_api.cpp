@@ -205,7 +205,7 @@ struct sicp_ctx {
     int knn1_mode = 0;             // SICP_KNN1 = exact | filter | grid: force one 1-NN flavour (A/B + tests); 0 = auto
     DevBuf<uint32_t> g_keys, g_vals, g_keys2, g_counts;   // grid build scratch
     DevBuf<unsigned char> g_tmp;
-    DevBuf<unsigned long long> rj_keys;   // sort-based rejection scratch (2Q)
+    DevBuf<unsigned long long> rj_keys;   // large-Q rejection scratch: Q keys + the selection state
     bool have_prev_match = false;  // m_p2 holds last iteration's winners (bound source)
     int last_match_kernel = 0;     // 0 exact scan, 1 filtered scan (inline), 2 grid, 3 filtered scan (record + fix-up)
     // ICP state (selected fixed points and per-iteration products)
@@ -1072,14 +1072,13 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
     {
         Timed t(c, SICP_K_SELECT);
         if (Q > REJECT_MAX_Q) {
-            // one workgroup cannot chew a million distances: exact order statistics by device radix sort
-            const size_t tb = reject_sort_temp_bytes(Q);
-            CHK(c->g_tmp.reserve(tb + 256));
-            CHK(c->rj_keys.reserve((size_t)2 * Q));
+            // one workgroup cannot chew a million distances: exact order statistics by multi-workgroup radix selection
+            const size_t sb = (reject_select_scratch_bytes() + 7) / 8;
+            CHK(c->rj_keys.reserve((size_t)Q + sb));
             unsigned long long *small = (unsigned long long *)(c->small.p + 56);
-            if (reject_by_sort(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->rj_keys.p, c->rj_keys.p + Q,
-                               c->g_tmp.p, tb, small) != hipSuccess)
-                return fail(SICP_ERR_HIP, "sort-based rejection failed");
+            if (reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->rj_keys.p, c->rj_keys.p + Q,
+                                 small) != hipSuccess)
+                return fail(SICP_ERR_HIP, "rejection by radix selection failed");
         } else {
             launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p);
         }

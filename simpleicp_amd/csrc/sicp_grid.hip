@@ -13,6 +13,7 @@
 // bit (tests compare the two on full-size inputs).  The reference instead rebuilds a cKDTree on
 // the transformed cloud every iteration (corrpts.py:131, simpleicp.py:188-202).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
@@ -336,47 +337,46 @@ __device__ __forceinline__ double oval64(unsigned long long k)
     return __longlong_as_double((long long)b);
 }
 
+// one atomic per BLOCK: 16 k waves adding to one word serialise in L2 for hundreds of microseconds at Q = 1 M
+__device__ __forceinline__ void block_add_u64(unsigned long long c, unsigned long long *dst)
+{
+    __shared__ unsigned long long part[4];
+    c = wsum_u64(c);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = (part[0] + part[1]) + (part[2] + part[3]);
+        if (t) atomicAdd(dst, t);
+    }
+}
+
 // keys of flagged distances (or of |d - med| when center != null), ~0 for the rest; counts the flagged
-__global__ void k_reject_keys(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
-                              const double *__restrict__ center, unsigned long long *__restrict__ keys,
-                              unsigned long long *__restrict__ count)
+__global__ __launch_bounds__(256) void k_reject_keys(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
+                                                     const double *__restrict__ center, unsigned long long *__restrict__ keys,
+                                                     unsigned long long *__restrict__ count)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long c = 0;
-    if (i < Q) {
+    const double ctr = center ? center[0] : 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < Q; i += (long)gridDim.x * 256) {
         const bool f = flag[i] != 0;
-        const double v = center ? fabs(dist[i] - center[0]) : dist[i];
+        const double v = center ? fabs(dist[i] - ctr) : dist[i];
         keys[i] = f ? okey(v) : ~0ull;
-        c = f ? 1 : 0;
+        c += f ? 1 : 0;
     }
-    if (count) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-        if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
-    }
+    if (count) block_add_u64(c, count);
 }
 
-// np.median of the m smallest sorted keys -> dst[0]
-__global__ void k_reject_median(const unsigned long long *__restrict__ sorted, const unsigned long long *__restrict__ count,
-                                double *__restrict__ dst)
+__global__ __launch_bounds__(256) void k_reject_keep(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
+                                                     const double *__restrict__ med_mad, uint8_t *__restrict__ keep,
+                                                     unsigned long long *__restrict__ kept)
 {
-    const long m = (long)count[0];
-    dst[0] = m > 0 ? (oval64(sorted[(m - 1) / 2]) + oval64(sorted[m / 2])) / 2.0 : __builtin_nan("");
-}
-
-__global__ void k_reject_keep(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
-                              const double *__restrict__ med_mad, uint8_t *__restrict__ keep,
-                              unsigned long long *__restrict__ kept)
-{
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long c = 0;
-    if (i < Q) {
-        const uint8_t k = (flag[i] && fabs(dist[i] - med_mad[0]) <= 3 * med_mad[1]) ? 1 : 0;
-        keep[i] = k; c = k;
+    const double med = med_mad[0], bound = 3 * med_mad[1];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < Q; i += (long)gridDim.x * 256) {
+        const uint8_t k = (flag[i] && fabs(dist[i] - med) <= bound) ? 1 : 0;
+        keep[i] = k; c += k;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(kept, c);
+    block_add_u64(c, kept);
 }
 
 __global__ void k_reject_finish(const unsigned long long *__restrict__ counts /*[0]=m,[1]=kept*/,
@@ -385,33 +385,151 @@ __global__ void k_reject_finish(const unsigned long long *__restrict__ counts /*
     out4[0] = (double)counts[0]; out4[1] = med_mad[0]; out4[2] = med_mad[1]; out4[3] = (double)counts[1];
 }
 
-size_t reject_sort_temp_bytes(long Q)
+// ---- exact order statistics over many workgroups: 11-bit-digit radix selection ------------------------
+// State (device): st[0] = key prefix selected so far, st[1] = rank inside it, st[2] = #keys <= the selected
+// key, st[3] = smallest key above it; hist = 2048 global bins; one ticket.  Every pass is one launch: each
+// block histograms the keys that still match the prefix in LDS (wave-aggregated: distances share their
+// sign/exponent bits, so whole waves hit one bin in the early passes), adds its non-empty bins to the
+// global histogram, and the LAST block to arrive picks the bin holding the rank, extends the prefix and
+// clears the histogram for the next launch.  Six passes (5 x 11 + 9 bits) read the keys six times --
+// against two full 64-bit device sorts before (0.75 ms at Q = 1 M).
+constexpr int RSEL_BINS = 2048;
+struct RselState { unsigned long long st[8]; unsigned hist[RSEL_BINS]; unsigned ticket; };
+
+__device__ __forceinline__ bool last_block_arrives(unsigned *ticket, int *is_last_lds)
 {
-    size_t t = 0;
-    unsigned long long *p = nullptr;
-    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, t, p, p, (int)Q, 0, 64, (hipStream_t)0);
-    return t;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *is_last_lds = (t == gridDim.x - 1) ? 1 : 0;
+        if (*is_last_lds) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    return *is_last_lds != 0;
 }
 
-// scratch: keys_a, keys_b (Q u64 each), tmp (reject_sort_temp_bytes), small (4 u64/doubles: m, kept, med, mad)
-hipError_t reject_by_sort(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
-                          unsigned long long *keys_a, unsigned long long *keys_b, void *tmp, size_t tmp_bytes,
-                          unsigned long long *small)
+__global__ __launch_bounds__(256) void k_rsel_pass(const unsigned long long *__restrict__ keys, long Q, int pass,
+                                                   RselState *__restrict__ S, const unsigned long long *__restrict__ count)
+{
+    __shared__ unsigned hist[RSEL_BINS];
+    __shared__ unsigned scan[4];               // wave totals of the last block's prefix scan
+    __shared__ int is_last;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int shift = pass < 5 ? 53 - 11 * pass : 0, bits = pass < 5 ? 11 : 9;
+    const unsigned mask = (1u << bits) - 1u;
+    const unsigned long long prefix = S->st[0];
+    for (int i = tid; i < RSEL_BINS; i += 256) hist[i] = 0;
+    __syncthreads();
+    const long stride = (long)gridDim.x * 256;
+    for (long base = (long)blockIdx.x * 256; base < Q; base += stride) {        // wave-uniform trip count
+        const long i = base + tid;
+        const unsigned long long k = i < Q ? keys[i] : ~0ull;
+        bool act = k != ~0ull && (pass == 0 || (k >> (shift + bits)) == (prefix >> (shift + bits)));
+        const unsigned bin = (unsigned)(k >> shift) & mask;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned long long am = __ballot(act);
+            if (am == 0) break;
+            const int leader = __ffsll((long long)am) - 1;
+            const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+            const unsigned long long same = __ballot(act && bin == b0);
+            if (lane == leader) atomicAdd(&hist[b0], (unsigned)__popcll(same));
+            act = act && bin != b0;
+        }
+        if (act) atomicAdd(&hist[bin], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < RSEL_BINS; i += 256) if (hist[i]) atomicAdd(&S->hist[i], hist[i]);
+    if (!last_block_arrives(&S->ticket, &is_last)) return;
+    // thread t owns bins 8t..8t+7 of the complete histogram
+    unsigned h[8], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h[j] = S->hist[8 * tid + j]; mine += h[j]; S->hist[8 * tid + j] = 0; }
+    // exclusive prefix of the 256 per-thread counts: DPP scan inside each wave + the three wave totals before it
+    const unsigned incl = wscan_u32(mine);
+    if (lane == 63) scan[tid >> 6] = incl;
+    if (tid == 0) S->ticket = 0;
+    const long m = (long)count[0];
+    const unsigned long long rank = pass == 0 ? (unsigned long long)((m - 1) / 2) : S->st[1];   // (read by all BEFORE the
+    __syncthreads();                                                                            //  owner of the bin rewrites it)
+    unsigned before = 0;
+    for (int w = 0; w < (tid >> 6); ++w) before += scan[w];
+    const unsigned excl = before + incl - mine;
+    unsigned long long acc = excl;
+    if (m > 0 && rank >= acc && rank < acc + mine) {
+        int j = 0;
+        while (rank >= acc + h[j]) { acc += h[j]; ++j; }
+        S->st[0] = prefix | ((unsigned long long)(8 * tid + j) << shift);
+        S->st[1] = rank - acc;
+        if (pass == 5) { S->st[2] = 0; S->st[3] = ~0ull; }
+    }
+}
+
+// second middle value + their mean: dst[0] = np.median of the keys' values (NaN when there are none)
+__global__ __launch_bounds__(256) void k_rsel_finish(const unsigned long long *__restrict__ keys, long Q,
+                                                     RselState *__restrict__ S, const unsigned long long *__restrict__ count,
+                                                     double *__restrict__ dst)
+{
+    __shared__ int is_last;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long ka = S->st[0];
+    unsigned long long le = 0, nxt = ~0ull;
+    for (long i = (long)blockIdx.x * 256 + tid; i < Q; i += (long)gridDim.x * 256) {
+        const unsigned long long k = keys[i];
+        if (k <= ka) le += 1; else nxt = k < nxt ? k : nxt;
+    }
+    le = wsum_u64(le);
+    { unsigned long long o;
+      o = lane_xor64<32>(nxt); nxt = o < nxt ? o : nxt;  o = lane_xor64<16>(nxt); nxt = o < nxt ? o : nxt;
+      o = lane_xor64<8>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<4>(nxt);  nxt = o < nxt ? o : nxt;
+      o = lane_xor64<2>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<1>(nxt);  nxt = o < nxt ? o : nxt; }
+    __shared__ unsigned long long ple[4], pnx[4];
+    if (lane == 0) { ple[tid >> 6] = le; pnx[tid >> 6] = nxt; }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long tl = (ple[0] + ple[1]) + (ple[2] + ple[3]);
+        unsigned long long tn = pnx[0];
+        for (int w = 1; w < 4; ++w) tn = pnx[w] < tn ? pnx[w] : tn;
+        if (tl) atomicAdd(&S->st[2], tl);
+        if (tn != ~0ull) atomicMin(&S->st[3], tn);
+    }
+    if (!last_block_arrives(&S->ticket, &is_last)) return;
+    if (tid == 0) {
+        const long m = (long)count[0];
+        const long r = (m - 1) / 2;
+        const unsigned long long kb = ((m & 1) || (long)S->st[2] >= r + 2) ? ka : S->st[3];
+        dst[0] = m > 0 ? (oval64(ka) + oval64(kb)) / 2.0 : __builtin_nan("");
+        S->st[0] = 0; S->st[1] = 0; S->ticket = 0;
+    }
+}
+
+size_t reject_select_scratch_bytes() { return sizeof(RselState); }
+
+// scratch: keys (Q u64), state (reject_select_scratch_bytes), small (4 u64/doubles: m, kept, med, mad)
+hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
+                            unsigned long long *keys, void *state, unsigned long long *small)
 {
     unsigned long long *counts = small;            // [0] m, [1] kept
     double *med_mad = (double *)(small + 2);       // [0] median, [1] mad
+    RselState *S = (RselState *)state;
     hipError_t e = hipMemsetAsync(small, 0, 4 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    const unsigned g = cdiv(Q, 256);
-    hipLaunchKernelGGL(k_reject_keys, dim3(g), dim3(256), 0, s, dist, flag, Q, (const double *)nullptr, keys_a, counts);
-    e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys_a, keys_b, (int)Q, 0, 64, s);
+    e = hipMemsetAsync(state, 0, sizeof(RselState), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_reject_median, dim3(1), dim3(1), 0, s, keys_b, counts, med_mad);
-    hipLaunchKernelGGL(k_reject_keys, dim3(g), dim3(256), 0, s, dist, flag, Q, (const double *)med_mad, keys_a,
-                       (unsigned long long *)nullptr);
-    e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys_a, keys_b, (int)Q, 0, 64, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_reject_median, dim3(1), dim3(1), 0, s, keys_b, counts, med_mad + 1);
+    const unsigned g = (unsigned)std::min<long>(2048, (Q + 255) / 256);
+    const unsigned gs = (unsigned)std::min<long>(512, (Q + 1023) / 1024);
+    for (int stat = 0; stat < 2; ++stat) {
+        hipLaunchKernelGGL(k_reject_keys, dim3(g), dim3(256), 0, s, dist, flag, Q, stat ? (const double *)med_mad : nullptr, keys,
+                           stat ? (unsigned long long *)nullptr : counts);
+        for (int pass = 0; pass < 6; ++pass)
+            hipLaunchKernelGGL(k_rsel_pass, dim3(gs), dim3(256), 0, s, (const unsigned long long *)keys, Q, pass, S,
+                               (const unsigned long long *)counts);
+        hipLaunchKernelGGL(k_rsel_finish, dim3(gs), dim3(256), 0, s, (const unsigned long long *)keys, Q, S,
+                           (const unsigned long long *)counts, med_mad + stat);
+    }
     hipLaunchKernelGGL(k_reject_keep, dim3(g), dim3(256), 0, s, dist, flag, Q, (const double *)med_mad, keep, counts + 1);
     hipLaunchKernelGGL(k_reject_finish, dim3(1), dim3(1), 0, s, counts, (const double *)med_mad, out4);
     return hipGetLastError();

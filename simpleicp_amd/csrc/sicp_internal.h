@@ -62,10 +62,9 @@ void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, d
 void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int k, const GridGeom &G,
                      const uint32_t *cell_start, const double *sx, const double *sy, const double *sz, const uint32_t *sidx,
                      double rmax, int64_t idx_base, double *d2_out, int64_t *idx_out);
-size_t reject_sort_temp_bytes(long Q);
-hipError_t reject_by_sort(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
-                          unsigned long long *keys_a, unsigned long long *keys_b, void *tmp, size_t tmp_bytes,
-                          unsigned long long *small);
+size_t reject_select_scratch_bytes();
+hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
+                            unsigned long long *keys, void *state, unsigned long long *small);
 void launch_aos_to_soa(hipStream_t s, const double *aos, long n, long npad, double *x, double *y, double *z);
 void launch_found_mask(hipStream_t s, const int64_t *idx, long Q, uint8_t *out);
 void launch_pad_fill(hipStream_t s, double *x, double *y, double *z, long n, long npad);

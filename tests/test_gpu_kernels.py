@@ -348,15 +348,19 @@ def test_grid_knn_equals_brute_force(ctx_filter, n, q, k):
     assert np.array_equal(d2, rd2)
 
 
-def test_large_q_iteration_multi_kernel_path(ctx):
-    """Q > 16384: sort-based rejection + multi-block reductions + host LM must agree with the oracle."""
+@pytest.mark.parametrize("quantised,odd", [(False, False), (True, False), (False, True)])
+def test_large_q_iteration_multi_kernel_path(ctx, quantised, odd):
+    """Q > 16384: multi-workgroup radix selection (median / MAD, even and odd counts, duplicate distances from a
+    quantised cloud) + multi-block reductions + host LM must agree with the oracle."""
     from simpleicp_amd import _lib
     rng = np.random.default_rng(8)
     n = 60_000
     P = _surface(n, 21)
     x_true = np.array([0.002, -0.001, 0.003, 0.05, -0.03, 0.02])
     Xm = orc.transform(np.linalg.inv(orc.params_to_H(x_true)), P + rng.normal(0, 0.01, P.shape))
-    sel = np.arange(0, n, 2)                                  # Q = 30000
+    if quantised:
+        P, Xm = np.round(P, 2), np.round(Xm, 2)
+    sel = np.arange(0, n - (1 if odd else 0), 2)[: 30000 - (1 if odd else 0)]     # Q = 30000 / 29999
     ctx.upload(_lib.FIX, P)
     ctx.upload(_lib.MOV, Xm)
     nv, pl = ctx.estimate_normals(_lib.FIX, sel, 10)
