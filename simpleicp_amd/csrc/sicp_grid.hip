@@ -327,8 +327,8 @@ __global__ __launch_bounds__(256) void k_grid_knn(
 }
 
 // ------------------------------------------------------------------------------------
-// median / raw-MAD rejection for LARGE Q (corrpts.py:165-188): exact order statistics by two
-// device radix sorts (hipCUB) of the order-preserving uint64 image of the distances, everything
+// median / raw-MAD rejection for LARGE Q (corrpts.py:165-188): exact order statistics by radix
+// SELECTION over many workgroups on the order-preserving uint64 image of the distances, everything
 // chained on the stream without a host round trip.  out4 = (m, median, mad, n_kept) like k_reject.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ double oval64(unsigned long long k)
