@@ -224,6 +224,8 @@ struct sicp_ctx {
     double last_ne[30] = {0};      // normal equations at last_x (fused path caches them)
     bool have_last_ne = false;
     int solve_mode = 0;            // SICP_SOLVE = fused | host (A/B + tests); 0 = auto
+    bool host_trace = false;       // SICP_HOST_TRACE: per-iteration host timings on stderr
+    bool solve_trace = false;      // SICP_SOLVE_TRACE: the fused kernel's cycle counters on stderr
     long solve_seq = 0;            // completion tickets of the fused kernel
     // exchange
     sicp_exchange_fn xfn = nullptr;
@@ -720,6 +722,8 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
     if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : 0;
     if (const char *e = std::getenv("SICP_FSCAN_CAP")) c->fscan_cap = std::atol(e);
+    c->host_trace = std::getenv("SICP_HOST_TRACE") != nullptr;
+    c->solve_trace = std::getenv("SICP_SOLVE_TRACE") != nullptr;
     if (const char *e = std::getenv("SICP_SOLVE")) c->solve_mode = !std::strcmp(e, "fused") ? 1 : !std::strcmp(e, "host") ? 2 : 0;
     if (const char *e = std::getenv("SICP_KNN1"))
         c->knn1_mode = !std::strcmp(e, "exact") ? 1 : !std::strcmp(e, "filter") ? 2 : !std::strcmp(e, "grid") ? 3 : 0;
@@ -997,7 +1001,7 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
         if (std::isfinite(P->obs_weight[j])) freeidx[nfree++] = j;
     }
 
-    const bool htrace = std::getenv("SICP_HOST_TRACE") != nullptr;
+    const bool htrace = c->host_trace;
     const auto h0 = std::chrono::steady_clock::now();
     // ---- match: simpleicp.py:188-202, corrpts.py:124-137 (transform fused into the scan) ----
     double H12[12];
@@ -1058,11 +1062,11 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
         std::memcpy(c->last_ow, P->obs_weight, sizeof c->last_ow);
         std::memcpy(c->last_ne, o + 20, sizeof c->last_ne);
         c->have_last_ne = true;
-        if (std::getenv("SICP_SOLVE_TRACE"))
+        if (c->solve_trace) {
             std::fprintf(stderr, "[solve] cycles: dist %.0f sort %.0f stats %.0f lm %.0f (%lld evals, %lld steps, 6x6 solves %.0f) final %.0f\n",
                          o[50], o[51], o[52], o[53], (long long)R->ne_evals, (long long)R->lm_steps, o[56], o[54]);
-        if (std::getenv("SICP_SOLVE_TRACE"))
             std::fprintf(stderr, "[eval]  cycles over all evals: rows %.0f barrier %.0f sums %.0f barrier %.0f\n", o[57], o[58], o[59], o[60]);
+        }
         return SICP_OK;
     }
     c->have_last_ne = false;
