@@ -153,12 +153,14 @@ class SimpleICP:
 
         # without debug dumps nothing on the host needs the intermediate states: the whole loop runs behind
         # ONE ABI call (sicp_icp_run, same convergence test) and the per-iteration log is replayed below
-        whole = None
+        whole, failed = None, None
         if not debug_dirpath:
             try:
                 whole = ctx.icp_run(x, obs, ow, min_planarity, w, max_iterations, min_change)
             except _lib.BackendError as e:
-                too_few(e)
+                if e.code != _lib.ERR_TOO_FEW:
+                    raise
+                whole, failed = e.results[:-1], e          # log the iterations before the failing one first
         for it in range(0, max_iterations if whole is None else len(whole)):
             if debug_dirpath:
                 if it == 0:
@@ -190,6 +192,9 @@ class SimpleICP:
                           f"{'std(residuals)':>15s}")
                 _log.info(f"{'orig:0':>9s} | {int(R.n_kept):15d} | {R.dist_mean:15.4f} | {R.dist_std:15.4f}")
             _log.info(f"{it + 1:9d} | {stats[it][0]:15d} | {stats[it][1]:15.4f} | {stats[it][2]:15.4f}")
+
+        if failed is not None:
+            too_few(failed)
 
         rbp = RigidBodyParameters()
         rbp.set_parameter_attributes_from_list("observed_value", list(obs))
