@@ -224,6 +224,8 @@ struct sicp_ctx {
     double last_ne[30] = {0};      // normal equations at last_x (fused path caches them)
     bool have_last_ne = false;
     int solve_mode = 0;            // SICP_SOLVE = fused | host (A/B + tests); 0 = auto
+    double grid_target = 16.0;     // points per occupied grid cell the cell size aims at (SICP_GRID_TARGET overrides;
+                                   // measured flat from 12 to 32, 5-20 % slower below 8: fewer, longer rows win)
     bool host_trace = false;       // SICP_HOST_TRACE: per-iteration host timings on stderr
     bool solve_trace = false;      // SICP_SOLVE_TRACE: the fused kernel's cycle counters on stderr
     long solve_seq = 0;            // completion tickets of the fused kernel
@@ -381,7 +383,7 @@ int grid_build(sicp_ctx *c, int slot)
         if (!(ex[a] >= 0) || !std::isfinite(ex[a])) return fail(SICP_ERR_INVALID, "cloud has non-finite coordinates");
         if (ex[a] > 0) { vol *= ex[a]; ++deff; }
     }
-    const double target = 8.0;                       // points per occupied cell
+    const double target = c->grid_target;            // points per occupied cell
     const long cap = 1L << 27;                       // dense cell array cap (512 MiB of offsets)
     double h = deff ? std::pow(vol * target / (double)n, 1.0 / deff) : 1.0;
     if (!(h > 0) || !std::isfinite(h)) h = 1.0;
@@ -727,6 +729,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
     if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : 0;
     if (const char *e = std::getenv("SICP_FSCAN_CAP")) c->fscan_cap = std::atol(e);
+    if (const char *e = std::getenv("SICP_GRID_TARGET")) { const double t = std::atof(e); if (t >= 0.25 && t <= 1024) c->grid_target = t; }
     c->host_trace = std::getenv("SICP_HOST_TRACE") != nullptr;
     c->solve_trace = std::getenv("SICP_SOLVE_TRACE") != nullptr;
     if (const char *e = std::getenv("SICP_SOLVE")) c->solve_mode = !std::strcmp(e, "fused") ? 1 : !std::strcmp(e, "host") ? 2 : 0;
