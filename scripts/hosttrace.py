@@ -1,5 +1,5 @@
-import sys, time, numpy as np
-sys.path.insert(0,'/root/repo')
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from simpleicp_amd import _lib
 N=10_000_000; Q=1000
