@@ -792,6 +792,10 @@ int upload_end(sicp_ctx *c, int slot)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_small + 40, d_bits, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     CHK(sync(c));
+    if (!std::isfinite(c->h_small[40])) {
+        cl.n = 0;                                    // like cKDTree (pointcloud.py:161,185): no search structure over NaN / inf
+        return fail(SICP_ERR_INVALID, "cloud has non-finite coordinates (NaN / inf, or |p|^2 overflows a double)");
+    }
     cl.rmax = std::sqrt(c->h_small[40]) * (1.0 + 1e-12);
     if (slot == SICP_MOV) c->have_prev_match = false;
     return SICP_OK;

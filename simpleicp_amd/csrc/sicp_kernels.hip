@@ -466,10 +466,10 @@ __global__ void k_max_norm2(const double *__restrict__ x, const double *__restri
     double m = 0.0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const double v = fma(z[i], z[i], fma(y[i], y[i], x[i] * x[i]));
-        m = v > m ? v : m;                                  // NaN never wins
+        m = (v > m || v != v) ? v : m;                      // a NaN sticks: the upload rejects non-finite clouds
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(m, off, 64); m = o > m ? o : m; }
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(m, off, 64); m = (o > m || o != o) ? o : m; }
     if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
 }
 

@@ -120,6 +120,25 @@ def test_upload_columns_equals_upload(ctx):
         ctx.upload_columns(_lib.MOV, np.zeros(3), np.zeros(4), np.zeros(3))
 
 
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_non_finite_clouds_are_rejected_at_upload(ctx, bad):
+    """cKDTree refuses NaN / inf data (pointcloud.py:161,185 would raise); so does the upload, either flavour,
+    and the slot is left empty instead of holding a cloud no search can be trusted on."""
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(0)
+    for n in (10, 200_000):                                   # small (scan paths) and large (grid path)
+        X = rng.normal(size=(n, 3))
+        X[n // 2, 1] = bad
+        with pytest.raises(_lib.BackendError, match="non-finite"):
+            ctx.upload(_lib.MOV, X)
+        with pytest.raises(_lib.BackendError, match="empty"):
+            ctx.knn(_lib.MOV, X[:2] * 0, k=1)
+        with pytest.raises(_lib.BackendError, match="non-finite"):
+            ctx.upload_columns(_lib.MOV, X[:, 0].copy(), X[:, 1].copy(), X[:, 2].copy())
+    ctx.upload(_lib.MOV, rng.normal(size=(10, 3)))           # and the slot is usable again
+    assert ctx.knn(_lib.MOV, np.zeros((1, 3)), k=1)[0][0, 0] >= 0
+
+
 def test_transform_bit_exact(ctx):
     from simpleicp_amd import _lib
     rng = np.random.default_rng(2)
