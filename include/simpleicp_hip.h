@@ -72,6 +72,15 @@ int sicp_cloud_size(sicp_ctx *ctx, int slot, int64_t *n_out);
 int sicp_cloud_transform(sicp_ctx *ctx, int slot, const double H[16]);
 /* PointCloud.X (pointcloud.py:81-84): (n,3) row-major copy out. */
 int sicp_cloud_download(sicp_ctx *ctx, int slot, double *xyz_out);
+/* The `planarity` column of a cloud that has one (CorrPts.reject_wrt_planarity also tests the MOVABLE cloud's
+ * planarity of every matched point when pc2 carries that column, corrpts.py:158-163; NaN fails the test).
+ * Only consulted for SICP_MOV by the iteration.  The column is indexed by GLOBAL point index and has n_global
+ * entries (= the cloud size unless the cloud is a shard: every rank then holds the whole column, 4 B per point).
+ *   rows == NULL : planarity is the dense column, m == n_global
+ *   rows != NULL : m (row, value) pairs, NaN everywhere else (how estimate_normals leaves it: sparse)
+ *   planarity == NULL : the cloud has no such column (also the state after every upload of the slot). */
+int sicp_cloud_set_planarity(sicp_ctx *ctx, int slot, const int64_t *rows, const float *planarity, int64_t m,
+                             int64_t n_global);
 
 /* ---- nearest neighbours ------------------------------------------------------------- */
 /* What the reference asks of scipy.spatial.cKDTree(...).query(q, k, p=2[, distance_upper_bound])

@@ -70,10 +70,41 @@ def store_cloud(name):
     return X
 
 
-def run_case(name, f1, f2, kwargs):
+# Chained runs: the movable cloud of the recorded run is the FIXED cloud of an earlier run, so it carries the
+# sparse nx / ny / nz / planarity columns and (first case) a partial `selected` mask -- the two things
+# CorrPts.match / reject_wrt_planarity read from pc2 (corrpts.py:131-135, 158-163).
+#   name: (stage-1 fixed = recorded run's MOVABLE, stage-1 movable = recorded run's FIXED (fresh copy),
+#          stage-1 kwargs, select_all_points() on the carried cloud before the recorded run, recorded kwargs)
+CHAIN_CASES = {
+    "dragon_chain": ("dragon1.xyz", "dragon2.xyz", {}, False, {}),
+    "bunny_chain": ("bunny_part1.xyz", "bunny_part2.xyz", {"max_overlap_distance": 1, "correspondences": 30000},
+                    True, {"max_overlap_distance": 1}),
+}
+
+
+def run_chain_case(name, fa, fb, kw1, select_all, kw2):
+    Xa, Xb = store_cloud(fa), store_cloud(fb)
+    carried = ref.PointCloud(Xa, columns=["x", "y", "z"])
+    icp = ref.SimpleICP(verbose=False)
+    icp.add_point_clouds(carried, ref.PointCloud(Xb.copy(), columns=["x", "y", "z"]))
+    icp.run(**kw1)
+    assert np.array_equal(carried.X, Xa) and "planarity" in carried      # the fixed cloud is never moved
+    if select_all:
+        carried.select_all_points()
+    return run_case(name, fb, fa, kw2, pc_mov=carried)
+
+
+def run_case(name, f1, f2, kwargs, pc_mov=None):
     X_fix, X_mov = store_cloud(f1), store_cloud(f2)
     pc_fix = ref.PointCloud(X_fix, columns=["x", "y", "z"])
-    pc_mov = ref.PointCloud(X_mov.copy(), columns=["x", "y", "z"])
+    mov_extra = {}
+    if pc_mov is None:
+        pc_mov = ref.PointCloud(X_mov.copy(), columns=["x", "y", "z"])
+    else:
+        pl = pc_mov["planarity"].to_numpy()
+        rows = np.flatnonzero(~np.isnan(pl))
+        mov_extra = {"mov_sel_idx": pc_mov.idx_selected.astype(np.int64), "mov_planarity_rows": rows.astype(np.int64),
+                     "mov_planarity_vals": pl[rows].astype(np.float32)}
     trace = []
 
     orig_match = ref_corrpts.CorrPts.match
@@ -140,6 +171,7 @@ def run_case(name, f1, f2, kwargs):
         "log": np.array(buf.getvalue()),
         "kwargs": np.array(repr(kwargs)),
         "files": np.array([f1, f2]),
+        **mov_extra,
     }
     for i, t in enumerate(trace):
         for k, v in t.items():
@@ -172,6 +204,9 @@ def main():
         print(f"{name}: {len(trace)} iterations, final n={len(trace[-1]['kept_pc1_idx'])}")
         if name == "bunny":
             check_readme_kat(H, rbp, text)
+    for name, (fa, fb, kw1, select_all, kw2) in CHAIN_CASES.items():
+        H, rbp, text, trace = run_chain_case(name, fa, fb, kw1, select_all, kw2)
+        print(f"{name}: {len(trace)} iterations, final n={len(trace[-1]['kept_pc1_idx'])}")
 
 
 if __name__ == "__main__":

@@ -154,14 +154,29 @@ def load_cloud(name):
     return q.astype(np.float64) / 1e4
 
 
-def icp_iteration(X_mov, p1, n1, planarity, x_prev, x0, w, obs, ow, min_planarity):
+def icp_iteration(X_mov, p1, n1, planarity, x_prev, x0, w, obs, ow, min_planarity, mov_sel=None, planarity_mov=None):
     """One ICP iteration per simpleicp.py:184-250 with the oracle's deterministic
-    brute-force match.  Returns dict(nn, dist, keep, n, median, mad, x, residuals)."""
+    brute-force match.  Returns dict(nn, dist, keep, n, median, mad, x, residuals).
+      mov_sel        rows of X_mov that are `selected` (corrpts.py:131-135 searches pc2.X_selected only and maps
+                     the hits back through pc2.idx_selected); None = all
+      planarity_mov  (len(X_mov),) float32 `planarity` column of the movable cloud, NaN where absent
+                     (corrpts.py:158-163: a correspondence also needs pc2's planarity >= min_planarity when pc2
+                     has that column); None = pc2 has no such column"""
     H = params_to_H(x_prev)
-    nn, _ = knn(X_mov, p1, k=1, H=H)
-    nn = nn[:, 0]
+    if mov_sel is None:
+        nn, _ = knn(X_mov, p1, k=1, H=H)
+        nn = nn[:, 0]
+    else:
+        mov_sel = np.asarray(mov_sel, dtype=np.int64)
+        nn, _ = knn(_c(X_mov)[mov_sel], p1, k=1, H=H)
+        nn = mov_sel[nn[:, 0]]
     p2 = _c(X_mov)[nn]
     dist = point_to_plane(p1, n1, p2, H)
+    if planarity_mov is not None:
+        # both filters are row filters applied one after the other: a row survives iff both columns pass
+        # (float32 compare, NaN fails) -- fold pc2's verdict into the planarity handed to orc_reject
+        ok2 = np.asarray(planarity_mov, dtype=np.float32)[nn] >= np.float32(min_planarity)
+        planarity = np.where(ok2, np.asarray(planarity, dtype=np.float32), np.float32(np.nan))
     keep, n, med, mad = reject(dist, planarity, min_planarity)
     if w is None:
         w = 1.0 / (np.std(dist[keep]) ** 2)

@@ -24,7 +24,7 @@ MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1
 EXPORTS = [
     "sicp_abi_version", "sicp_last_error", "sicp_device_count", "sicp_ctx_create", "sicp_ctx_destroy",
     "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_upload_columns", "sicp_cloud_size", "sicp_cloud_transform",
-    "sicp_cloud_download", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
+    "sicp_cloud_download", "sicp_cloud_set_planarity", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
     "sicp_set_exchange", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_last_match_kernel",
     "sicp_xyz_count", "sicp_xyz_read", "sicp_xyz_write",
@@ -85,6 +85,7 @@ def load():
     L.sicp_cloud_size.argtypes = [vp, cint, C.POINTER(i64)]
     L.sicp_cloud_transform.argtypes = [vp, cint, vp]
     L.sicp_cloud_download.argtypes = [vp, cint, vp]
+    L.sicp_cloud_set_planarity.argtypes = [vp, cint, vp, vp, i64, i64]
     L.sicp_knn.argtypes = [vp, cint, vp, i64, cint, vp, dbl, vp, vp]
     L.sicp_select_in_range.argtypes = [vp, cint, cint, vp, i64, vp, dbl, vp]
     L.sicp_estimate_normals.argtypes = [vp, cint, vp, i64, cint, vp, vp, vp]
@@ -210,6 +211,20 @@ class Context:
         out = np.empty((self.size(slot), 3))
         self._chk(self._L.sicp_cloud_download(self._h, slot, _ptr(out)))
         return out
+
+    def set_planarity(self, slot, planarity=None, rows=None, n_global=None):
+        """The cloud's `planarity` column (corrpts.py:158-163 tests the movable cloud's too): a dense float32 vector
+        by global point index, or (rows, values) pairs with NaN elsewhere; None = no such column."""
+        if planarity is None:
+            self._chk(self._L.sicp_cloud_set_planarity(self._h, slot, None, None, 0, 0))
+            return
+        pl = np.ascontiguousarray(planarity, dtype=np.float32)
+        r = None if rows is None else np.ascontiguousarray(rows, dtype=np.int64)
+        if r is not None and len(r) != len(pl):
+            raise ValueError("rows and planarity must have the same length")
+        n = int(n_global if n_global is not None else (len(pl) if r is None else self.size(slot)))
+        dummy = np.zeros(1, np.float32)
+        self._chk(self._L.sicp_cloud_set_planarity(self._h, slot, _ptr(r), _ptr(pl if len(pl) else dummy), len(pl), n))
 
     # -- nearest neighbours --
     def knn(self, slot, q_xyz, k=1, H=None, max_dist=np.inf):

@@ -97,6 +97,8 @@ struct Cloud {
     int64_t n = 0, npad = 0, idx_base = 0;
     double rmax = 0.0;    // largest point norm (error bounds of the filtered / grid searches)
     Grid grid;
+    DevBuf<float> pl;     // `planarity` column by GLOBAL index (pl_n entries; 0 = the cloud has no such column)
+    int64_t pl_n = 0;
     DevBuf<double> xyz;   // x[npad] | y[npad] | z[npad]
     const double *x() const { return xyz.p; }
     const double *y() const { return xyz.p + npad; }
@@ -350,6 +352,22 @@ int check_slot(sicp_ctx *c, int slot, bool need_data)
     if (!c) return fail(SICP_ERR_INVALID, "null ctx");
     if (slot != SICP_FIX && slot != SICP_MOV) return fail(SICP_ERR_INVALID, "slot must be SICP_FIX or SICP_MOV");
     if (need_data && c->cloud[slot].n <= 0) return fail(SICP_ERR_INVALID, "cloud slot %d is empty", slot);
+    return SICP_OK;
+}
+
+// rows handed over the ABI index device gathers: every one must be a row of the cloud (host-or-device pointer)
+int check_rows(const int64_t *rows, int64_t m, int64_t n, const char *what)
+{
+    hipPointerAttribute_t at;
+    std::vector<int64_t> tmp;
+    if (hipPointerGetAttributes(&at, rows) == hipSuccess && at.type == hipMemoryTypeDevice) {
+        tmp.resize((size_t)m);
+        HIPCHK(hipMemcpy(tmp.data(), rows, (size_t)m * sizeof(int64_t), hipMemcpyDeviceToHost));
+        rows = tmp.data();
+    } else (void)hipGetLastError();                       // plain host memory is "invalid value" to the query: not an error
+    for (int64_t i = 0; i < m; ++i)
+        if (rows[i] < 0 || rows[i] >= n) return fail(SICP_ERR_INVALID, "%s[%lld] = %lld is not a row of the cloud (%lld points)", what,
+                                                     (long long)i, (long long)rows[i], (long long)n);
     return SICP_OK;
 }
 
@@ -746,7 +764,7 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    for (auto &cl : c->cloud) { cl.xyz.release(); cl.grid.cell_start.release(); cl.grid.sidx.release(); cl.grid.sxyz.release(); }
+    for (auto &cl : c->cloud) { cl.xyz.release(); cl.pl.release(); cl.grid.cell_start.release(); cl.grid.sidx.release(); cl.grid.sxyz.release(); }
     c->g_keys.release(); c->g_vals.release(); c->g_keys2.release(); c->g_counts.release(); c->g_tmp.release(); c->rj_keys.release();
     c->stage.release(); c->part_d2.release(); c->part_idx.release(); c->kq.release(); c->k_d2.release();
     c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->hit_cnt.release(); c->hit_list.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
@@ -778,6 +796,7 @@ int upload_begin(sicp_ctx *c, int slot, int64_t n, int64_t index_base)
     Cloud &cl = c->cloud[slot];
     cl.n = n; cl.npad = round_up(n, TILE_PTS); cl.idx_base = index_base;
     cl.grid.valid = false;
+    cl.pl_n = 0;                                       // a new cloud has no planarity column until one is set
     CHK(cl.xyz.reserve((size_t)3 * cl.npad));
     return SICP_OK;
 }
@@ -852,6 +871,40 @@ SICP_EXPORT int sicp_cloud_transform(sicp_ctx *c, int slot, const double H[16])
     return sync(c);
 }
 
+SICP_EXPORT int sicp_cloud_set_planarity(sicp_ctx *c, int slot, const int64_t *rows, const float *planarity, int64_t m,
+                                         int64_t n_global)
+{
+    CHK(check_slot(c, slot, true));
+    Cloud &cl = c->cloud[slot];
+    if (!planarity) { cl.pl_n = 0; return SICP_OK; }
+    if (n_global < cl.idx_base + cl.n) return fail(SICP_ERR_INVALID, "n_global is smaller than the cloud");
+    if (m < 0 || (!rows && m != n_global)) return fail(SICP_ERR_INVALID, "a dense planarity column needs n_global values");
+    HIPCHK(hipSetDevice(c->device));
+    CHK(cl.pl.reserve((size_t)n_global));
+    if (!rows) {
+        HIPCHK(hipMemcpyAsync(cl.pl.p, planarity, (size_t)m * sizeof(float), hipMemcpyDefault, c->stream));
+        cl.pl_n = n_global;
+        return sync(c);
+    }
+    CHK(check_rows(rows, m, n_global, "planarity rows"));
+    DevBuf<int64_t> d_rows; DevBuf<float> d_vals;
+    int rc = d_rows.reserve((size_t)std::max<int64_t>(m, 1));
+    if (rc == SICP_OK) rc = d_vals.reserve((size_t)std::max<int64_t>(m, 1));
+    auto body = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(d_rows.p, rows, (size_t)m * sizeof(int64_t), hipMemcpyDefault, c->stream));
+        HIPCHK(hipMemcpyAsync(d_vals.p, planarity, (size_t)m * sizeof(float), hipMemcpyDefault, c->stream));
+        launch_fill_f32(c->stream, cl.pl.p, n_global, std::numeric_limits<float>::quiet_NaN());
+        launch_scatter_f32(c->stream, cl.pl.p, d_rows.p, d_vals.p, m);
+        HIPCHK(hipGetLastError());
+        return sync(c);
+    };
+    if (rc == SICP_OK) rc = body();
+    (void)hipStreamSynchronize(c->stream);
+    d_rows.release(); d_vals.release();
+    if (rc == SICP_OK) cl.pl_n = n_global;
+    return rc;
+}
+
 SICP_EXPORT int sicp_cloud_download(sicp_ctx *c, int slot, double *xyz_out)
 {
     CHK(check_slot(c, slot, true));
@@ -919,8 +972,7 @@ SICP_EXPORT int sicp_select_in_range(sicp_ctx *c, int query_slot, int search_slo
     if (rc == SICP_OK && sel_idx) rc = sel.reserve(Q);
     auto body = [&]() -> int {
         if (sel_idx) {
-            for (int64_t i = 0; i < Q; ++i)
-                if (sel_idx[i] < 0 || sel_idx[i] >= qc.n) return fail(SICP_ERR_INVALID, "sel_idx[%lld] out of range", (long long)i);
+            CHK(check_rows(sel_idx, Q, qc.n, "sel_idx"));
             HIPCHK(hipMemcpyAsync(sel.p, sel_idx, (size_t)Q * sizeof(int64_t), hipMemcpyDefault, c->stream));
         }
         launch_gather_queries(c->stream, qc.x(), qc.y(), qc.z(), sel_idx ? sel.p : nullptr, Q, qpad, c->kq.p, c->kq.p + qpad,
@@ -949,6 +1001,7 @@ SICP_EXPORT int sicp_estimate_normals(sicp_ctx *c, int slot, const int64_t *sel_
     if (k < 2) return fail(SICP_ERR_INVALID, "neighbors must be >= 2");
     Cloud &cl = c->cloud[slot];
     if (k > cl.n) return fail(SICP_ERR_INVALID, "neighbors (%d) exceeds the number of points (%lld)", k, (long long)cl.n);
+    CHK(check_rows(sel_idx, Q, cl.n, "sel_idx"));
     HIPCHK(hipSetDevice(c->device));
     const long qpad = round_up(Q, QPAD);
     CHK(c->kq.reserve((size_t)3 * qpad));
@@ -984,6 +1037,7 @@ SICP_EXPORT int sicp_icp_setup(sicp_ctx *c, const int64_t *sel_idx, int64_t Q, c
     if (Q <= 0) return fail(SICP_ERR_INVALID, "Q must be > 0");
     HIPCHK(hipSetDevice(c->device));
     Cloud &cl = c->cloud[SICP_FIX];
+    CHK(check_rows(sel_idx, Q, cl.n, "sel_idx"));
     c->Q = Q; c->qpad = round_up(Q, QPAD);
     CHK(c->q.reserve((size_t)3 * c->qpad));
     CHK(c->normals.reserve((size_t)3 * Q)); CHK(c->planarity.reserve(Q));
@@ -1034,6 +1088,8 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
         A.min_planarity = (float)P->min_planarity;
         A.max_steps = P->max_lm_steps > 0 ? (int)P->max_lm_steps : 100;
         A.Q = Q;
+        A.pl2 = c->cloud[SICP_MOV].pl_n > 0 ? c->cloud[SICP_MOV].pl.p : nullptr;
+        A.pl2_n = c->cloud[SICP_MOV].pl_n;
         A.seq = (double)(++c->solve_seq);
         const auto h1 = std::chrono::steady_clock::now();
         double *d_out = c->h_small + 64;      // pinned + mapped: the kernel's 56 result doubles land on the host directly
@@ -1084,7 +1140,8 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
     c->have_last_ne = false;
     // ---- distances + rejections: corrpts.py:139-211 ----
     launch_postmatch(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, c->m_p2.p,
-                     c->m_idx.p, Q, X, (float)P->min_planarity, c->dist.p, c->flag.p);
+                     c->m_idx.p, Q, X, (float)P->min_planarity, c->cloud[SICP_MOV].pl_n > 0 ? c->cloud[SICP_MOV].pl.p : nullptr,
+                     c->cloud[SICP_MOV].pl_n, c->dist.p, c->flag.p);
     {
         Timed t(c, SICP_K_SELECT);
         if (Q > REJECT_MAX_Q) {

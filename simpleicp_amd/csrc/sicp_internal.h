@@ -33,10 +33,14 @@ struct SolveArgs {
     float min_planarity;
     int max_steps;
     long Q;
+    const float *pl2;           // movable cloud's planarity column by GLOBAL index (corrpts.py:158-163), or null
+    long pl2_n;
 };
 void launch_icp_solve(hipStream_t st, const double *qx, const double *qy, const double *qz, const float *normals,
                       const float *planarity, const double *p2, const int64_t *idx, const SolveArgs &A, double *dist,
                       uint8_t *flag, uint8_t *keep, double *resid, double *out);
+void launch_fill_f32(hipStream_t s, float *dst, long n, float v);
+void launch_scatter_f32(hipStream_t s, float *dst, const int64_t *rows, const float *vals, long m);
 
 // uniform grid over a cloud in its own frame (sicp_grid.hip)
 struct GridGeom { double mn[3]; double h, inv_h; int dim[3]; };
@@ -103,7 +107,7 @@ void launch_normals(hipStream_t s, const double *px, const double *py, const dou
                     int64_t idx_base, float *normals, float *planarity);
 void launch_postmatch(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
                       const float *planarity, const double *p2, const int64_t *idx, long Q, const Xf &H,
-                      float min_planarity, double *dist, uint8_t *flag);
+                      float min_planarity, const float *pl2, long pl2_n, double *dist, uint8_t *flag);
 void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4);
 void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3, const double *also4 = nullptr,
                   double *host_out = nullptr, double seq = 0.0, double *partial = nullptr, unsigned *ticket = nullptr);

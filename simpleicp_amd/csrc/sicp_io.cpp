@@ -48,8 +48,15 @@ inline bool starts_number(const char *s, const char *e)
 {
     while (s < e && (*s == ' ' || *s == '\t' || *s == '\r')) ++s;
     if (s >= e) return false;
-    const char c = *s;
-    return (c >= '0' && c <= '9') || c == '-' || c == '+' || c == '.';
+    char c = *s;
+    if ((c >= '0' && c <= '9') || c == '.') return true;
+    if (c == '-' || c == '+') { if (++s >= e) return false; c = *s; if ((c >= '0' && c <= '9') || c == '.') return true; }
+    // "nan" / "inf" rows are data for np.genfromtxt (and for strtod), not headers
+    if (e - s >= 3) {
+        const char a = (char)(s[0] | 0x20), b = (char)(s[1] | 0x20), d = (char)(s[2] | 0x20);
+        if ((a == 'n' && b == 'a' && d == 'n') || (a == 'i' && b == 'n' && d == 'f')) return true;
+    }
+    return false;
 }
 
 // [b, e) snapped to whole lines of the mapping
@@ -80,15 +87,16 @@ int64_t parse_rows(const Mapped &m, size_t b, size_t e, double *out)
     int64_t rows = 0;
     const char *s = m.p + b, *end = m.p + e;
     char buf[512];
+    std::string longline;
     while (s < end) {
         const char *nl = (const char *)memchr(s, '\n', (size_t)(end - s));
         const char *le = nl ? nl : end;
         if (starts_number(s, le)) {
             // strtod needs a terminator: lines are short, copy (also protects the unterminated last line)
-            size_t len = (size_t)(le - s);
-            if (len >= sizeof buf) len = sizeof buf - 1;
-            memcpy(buf, s, len); buf[len] = 0;
+            const size_t len = (size_t)(le - s);
             char *p = buf;
+            if (len < sizeof buf) { memcpy(buf, s, len); buf[len] = 0; }
+            else { longline.assign(s, len); p = &longline[0]; }      // e.g. "%.3f" of 1e300: hundreds of digits
             for (int c = 0; c < 3; ++c) {
                 char *q;
                 const double v = strtod(p, &q);
@@ -161,7 +169,7 @@ SICP_EXPORT int sicp_xyz_read(const char *path, double *xyz_out, int64_t capacit
 // default) separated by single spaces; `header` (may be NULL) is written verbatim as the first line.
 SICP_EXPORT int sicp_xyz_write(const char *path, const double *data, int64_t n, int cols, int decimals, const char *header, int threads)
 {
-    if (!path || (!data && n > 0) || cols < 1 || cols > 16) return sicp_io_fail(SICP_ERR_INVALID, "bad arguments");
+    if (!path || (!data && n > 0) || cols < 1 || cols > 16 || decimals > 64) return sicp_io_fail(SICP_ERR_INVALID, "bad arguments");
     FILE *f = fopen(path, "wb");
     if (!f) return sicp_io_fail(SICP_ERR_INVALID, "cannot open %s for writing", path);
     if (header) { fputs(header, f); fputc('\n', f); }
@@ -178,11 +186,21 @@ SICP_EXPORT int sicp_xyz_write(const char *path, const double *data, int64_t n, 
                 if (b >= e) return;
                 std::string &s = bufs[t];
                 s.reserve((size_t)(e - b) * cols * 14);
-                char tmp[64];
+                // "%.3f" of 1e308 has 309 integer digits: the stack buffer covers every double at the
+                // decimals the callers use; anything longer goes through a heap buffer of the exact size
+                char tmp[384];
+                std::vector<char> big;
                 for (int64_t i = b; i < e; ++i)
                     for (int c = 0; c < cols; ++c) {
-                        const int len = snprintf(tmp, sizeof tmp, fmt, data[i * cols + c]);
-                        s.append(tmp, (size_t)len);
+                        const double v = data[i * cols + c];
+                        const int len = snprintf(tmp, sizeof tmp, fmt, v);
+                        if (len < 0) continue;
+                        if ((size_t)len < sizeof tmp) s.append(tmp, (size_t)len);
+                        else {
+                            big.resize((size_t)len + 1);
+                            snprintf(big.data(), big.size(), fmt, v);
+                            s.append(big.data(), (size_t)len);
+                        }
                         s.push_back(c + 1 < cols ? ' ' : '\n');
                     }
             });

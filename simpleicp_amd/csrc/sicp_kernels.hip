@@ -718,14 +718,29 @@ __global__ void k_postmatch(const double *__restrict__ qx, const double *__restr
                             const double *__restrict__ qz, const float *__restrict__ normals,
                             const float *__restrict__ planarity, const double *__restrict__ p2,
                             const int64_t *__restrict__ idx, long Q, Xf H, float min_planarity,
-                            double *__restrict__ dist, uint8_t *__restrict__ flag)
+                            const float *__restrict__ pl2 /* movable cloud's column by global index, or null */,
+                            long pl2_n, double *__restrict__ dist, uint8_t *__restrict__ flag)
 {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
     double X, Y, Z;
     xform(H, p2[3 * q], p2[3 * q + 1], p2[3 * q + 2], X, Y, Z);
     dist[q] = plane_dist(X - qx[q], Y - qy[q], Z - qz[q], normals[3 * q], normals[3 * q + 1], normals[3 * q + 2]);
-    flag[q] = (idx[q] >= 0 && planarity[q] >= min_planarity) ? 1 : 0;
+    const int64_t m = idx[q];
+    bool f = m >= 0 && planarity[q] >= min_planarity;
+    if (f && pl2) f = m < pl2_n && pl2[m] >= min_planarity;          // corrpts.py:158-163 (NaN fails)
+    flag[q] = f ? 1 : 0;
+}
+
+__global__ void k_fill_f32(float *__restrict__ dst, long n, float v)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+__global__ void k_scatter_f32(float *__restrict__ dst, const int64_t *__restrict__ rows, const float *__restrict__ vals, long m)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) dst[rows[i]] = vals[i];
 }
 
 // ------------------------------------------------------------------------------------
@@ -1327,10 +1342,19 @@ void launch_normals(hipStream_t s, const double *px, const double *py, const dou
 
 void launch_postmatch(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
                       const float *planarity, const double *p2, const int64_t *idx, long Q, const Xf &H,
-                      float min_planarity, double *dist, uint8_t *flag)
+                      float min_planarity, const float *pl2, long pl2_n, double *dist, uint8_t *flag)
 {
     hipLaunchKernelGGL(k_postmatch, dim3(cdiv(Q, 256)), dim3(256), 0, s, qx, qy, qz, normals, planarity, p2, idx, Q, H,
-                       min_planarity, dist, flag);
+                       min_planarity, pl2, pl2_n, dist, flag);
+}
+
+void launch_fill_f32(hipStream_t s, float *dst, long n, float v)
+{
+    if (n > 0) hipLaunchKernelGGL(k_fill_f32, dim3(cdiv(n, 256)), dim3(256), 0, s, dst, n, v);
+}
+void launch_scatter_f32(hipStream_t s, float *dst, const int64_t *rows, const float *vals, long m)
+{
+    if (m > 0) hipLaunchKernelGGL(k_scatter_f32, dim3(cdiv(m, 256)), dim3(256), 0, s, dst, rows, vals, m);
 }
 
 void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4)

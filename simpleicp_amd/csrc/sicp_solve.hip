@@ -340,7 +340,10 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_icp_solve(
             double X, Y, Z;
             xfm(A.H, C.px[e], C.py[e], C.pz[e], X, Y, Z);
             dist[i] = pdist(X - C.qx[e], Y - C.qy[e], Z - C.qz[e], C.nx[e], C.ny[e], C.nz[e]);
-            const uint8_t f = (idx[i] >= 0 && planarity[i] >= A.min_planarity) ? 1 : 0;
+            const int64_t mi = idx[i];
+            bool fb = mi >= 0 && planarity[i] >= A.min_planarity;
+            if (fb && A.pl2) fb = mi < A.pl2_n && A.pl2[mi] >= A.min_planarity;      // corrpts.py:158-163 (NaN fails)
+            const uint8_t f = fb ? 1 : 0;
             flag[i] = f; cnt[0] += f;
         }
     }

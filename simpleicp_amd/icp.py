@@ -101,15 +101,39 @@ class SimpleICP:
 
         # both clouds go to HBM once and stay there (straight from the frames' storage: no host gather)
         pc1._upload(ctx, _lib.FIX)
+        # CorrPts.match searches pc2.X_selected only and maps the hits through pc2.idx_selected (corrpts.py:131-135);
+        # a movable cloud with a partial `selected` mask (e.g. the fixed cloud of an earlier run) is uploaded as
+        # that subset, after the overlap pre-pass, which looks at ALL its points (simpleicp.py:157: pc2.X)
+        partial = not bool(pc2["selected"].to_numpy().all())
+        msel = pc2.idx_selected if partial else None
+        if partial and not len(msel):
+            raise SimpleICPException("The movable point cloud has no selected points.")
+        n_search = len(msel) if partial else pc2.num_points
+        rank, world = dist.rank_world() if sharded else (0, 1)
+
+        def upload_movable(rows=None):
+            n = pc2.num_points if rows is None else len(rows)
+            lo, hi = dist.shard_bounds(n, rank, world)
+            pc2._upload(ctx, _lib.MOV, lo, hi, index_base=lo, rows=rows)
+
+        upload_movable()
         if sharded:
-            rank, world = dist.rank_world()
-            lo, hi = dist.shard_bounds(pc2.num_points, rank, world)
-            pc2._upload(ctx, _lib.MOV, lo, hi, index_base=lo)
             ctx.set_exchange(dist.make_exchange(ctx), rank, world,
                              gn_shard=correspondences >= 262144 or os.environ.get("SICP_GN_SHARD") == "1")
         else:
-            pc2._upload(ctx, _lib.MOV)
             ctx.set_exchange(None, 0, 1)
+        try:
+            return self._run_uploaded(ctx, sharded, msel, n_search, upload_movable, t_start, obs, ow, H,
+                                      correspondences, neighbors, min_planarity, max_overlap_distance, min_change,
+                                      max_iterations, distance_weights, debug_dirpath)
+        finally:
+            # the exchange callback lives on the process-wide context: a later standalone PointCloud operator must not
+            # issue a collective the other ranks never join
+            ctx.set_exchange(None, 0, 1)
+
+    def _run_uploaded(self, ctx, sharded, msel, n_search, upload_movable, t_start, obs, ow, H, correspondences, neighbors,
+                      min_planarity, max_overlap_distance, min_change, max_iterations, distance_weights, debug_dirpath):
+        pc1, pc2 = self.pc1, self.pc2
         if debug_dirpath:
             X_fix, X_mov = pc1.X, pc2.X
 
@@ -138,6 +162,12 @@ class SimpleICP:
             _log.info("Estimate normals of selected points ...")
             pc1.estimate_normals(neighbors, _ctx=ctx, _uploaded=True, _sel=sel)
         normals, planarity = pc1._attributes_of(sel)
+        if msel is not None:
+            upload_movable(msel)                 # from here on the searched cloud is pc2's selected subset
+        if "planarity" in pc2.columns:
+            # reject_wrt_planarity tests pc2's column as well when it exists (corrpts.py:158-163; NaN fails)
+            rows, vals = pc2._planarity_pairs(msel)
+            ctx.set_planarity(_lib.MOV, vals, rows=rows, n_global=n_search)
         ctx.icp_setup(sel, normals, planarity)
 
         x = obs.copy()
@@ -176,7 +206,7 @@ class SimpleICP:
                     too_few(e)
             if debug_dirpath:
                 self._write_correspondences(ctx, Path(debug_dirpath).joinpath(
-                    f"iteration{it:03d}_preoptim_correspondences.xyz"), X_fix, X_mov, sel, H)
+                    f"iteration{it:03d}_preoptim_correspondences.xyz"), X_fix, X_mov if msel is None else X_mov[msel], sel, H)
             if w is None:
                 w = R.weight_used                            # frozen after iteration 0 (simpleicp.py:229-234)
             x = np.array(R.x[:])
@@ -212,8 +242,8 @@ class SimpleICP:
 
         self._log_result(H, rbp)
 
-        # final transformation of the caller's movable cloud (simpleicp.py:316)
-        if sharded:
+        # final transformation of the caller's movable cloud (simpleicp.py:316): all of its points
+        if sharded or msel is not None:
             pc2._upload(ctx, _lib.MOV)
         X_new = pc2._transform(H, ctx, _lib.MOV)
         if debug_dirpath:

@@ -92,9 +92,15 @@ class PointCloud(pd.DataFrame):
             return "soa", cols
         return "aos", self.X
 
-    def _upload(self, ctx, slot, lo=0, hi=None, index_base=0):
-        """Rows [lo, hi) into the library's slot; returns a row getter ``rows(idx) -> (len(idx),3)``."""
+    def _upload(self, ctx, slot, lo=0, hi=None, index_base=0, rows=None):
+        """Rows [lo, hi) (of the subset ``rows`` when given) into the library's slot; returns a row getter
+        ``rows(idx) -> (len(idx),3)``."""
         kind, buf = self._xyz_buffers()
+        if rows is not None:
+            part = rows[lo:hi]
+            sub = buf[part] if kind == "aos" else np.column_stack([b[part] for b in buf])
+            ctx.upload(slot, sub, index_base=index_base)
+            return lambda idx: sub[idx]
         hi = self._num_points if hi is None else hi
         if kind == "aos":
             ctx.upload(slot, buf[lo:hi], index_base=index_base)
@@ -119,6 +125,26 @@ class PointCloud(pd.DataFrame):
             else:
                 out.append(np.asarray(self[c].to_numpy(), dtype=np.float32)[idx])
         return np.column_stack(out[:3]), out[3]
+
+    def _planarity_pairs(self, rows=None):
+        """(positions int64, values float32) of the non-NaN entries of the `planarity` column; positions count
+        within ``rows`` (sorted row subset) when given.  O(stored values) on the sparse column estimate_normals
+        creates."""
+        arr = self["planarity"].array
+        if isinstance(arr, pd.arrays.SparseArray) and np.isnan(arr.fill_value) and hasattr(arr.sp_index, "indices"):
+            at = np.asarray(arr.sp_index.indices, dtype=np.int64)
+            vals = np.asarray(arr.sp_values, dtype=np.float32)
+        else:
+            dense = np.asarray(self["planarity"].to_numpy(), dtype=np.float32)
+            at = np.flatnonzero(~np.isnan(dense))
+            vals = dense[at]
+        ok = ~np.isnan(vals)
+        at, vals = at[ok], vals[ok]
+        if rows is None:
+            return at, vals
+        pos = np.searchsorted(rows, at)
+        hit = (pos < len(rows)) & (rows[np.minimum(pos, len(rows) - 1)] == at)
+        return pos[hit].astype(np.int64), vals[hit]
 
     @property
     def X_selected(self) -> np.ndarray:

@@ -13,6 +13,9 @@ if str(ROOT) not in sys.path:
 
 GOLDEN = ROOT / "tests" / "golden"
 GOLDEN_CASES = ["dragon", "bunny", "multisensor", "webots", "dragon_q5000", "bunny_obs"]
+# the movable cloud carries a `planarity` column (and, dragon_chain, a partial `selected` mask): it was the fixed
+# cloud of an earlier reference run (oracle/make_golden.py CHAIN_CASES; corrpts.py:131-135,158-163)
+GOLDEN_CHAIN = ["dragon_chain", "bunny_chain"]
 
 
 def pytest_configure(config):
@@ -47,6 +50,16 @@ def load_golden(name):
     # repr() of a plain dict written by make_golden.py; `inf` is the only non-literal in it
     kwargs = ast.literal_eval(re.sub(r"\binf\b", "1e999", str(g["kwargs"])))
     return g, files, kwargs
+
+
+def movable_columns(g, n_mov):
+    """(selected rows or None, dense float32 planarity or None) of the movable cloud of a fixture."""
+    if "mov_sel_idx" not in g.files:
+        return None, None
+    sel = g["mov_sel_idx"]
+    pl = np.full(n_mov, np.nan, np.float32)
+    pl[g["mov_planarity_rows"]] = g["mov_planarity_vals"]
+    return (None if len(sel) == n_mov else sel), pl
 
 
 def load_cloud(stem):

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import GOLDEN_CHAIN, load_golden, movable_columns
 from oracle import orc
 
 pytestmark = pytest.mark.gpu
@@ -174,7 +174,7 @@ def test_normals_vs_oracle(ctx, name, clouds):
     assert np.mean(dot > 1 - 1e-5) > (0.70 if name == "webots" else 0.995)
 
 
-@pytest.mark.parametrize("name", ["dragon", "bunny", "multisensor", "webots", "bunny_obs"])
+@pytest.mark.parametrize("name", ["dragon", "bunny", "multisensor", "webots", "bunny_obs", "dragon_q5000"])
 def test_iteration_vs_oracle(ctx, name, clouds):
     """Whole iterations (match -> reject -> LM on fused reductions) against the oracle, fed with
     the reference's normals; indices / masks bit-exact, parameters to 1e-9."""
@@ -421,3 +421,99 @@ def test_filtered_scan_variants_and_overflow_fallback(variant, cap):
         ridx, rd2 = orc.knn(P, Qp, k=1, H=Hm)
         assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
     c.close()
+
+
+@pytest.mark.parametrize("Q", [1, 6, 63, 512, 513, 1024, 1025, 1500, 2048, 2049, 5000, 10_000, 16_384, 16_385])
+@pytest.mark.parametrize("quantised", [False, True])
+def test_iteration_q_sweep_every_tail_path(ctx, Q, quantised):
+    """Every instantiation of the iteration's tail against the oracle with bit-level assertions: the fused
+    single-launch tail with 1 / 2 / 4 correspondences per lane (Q <= 512 / 1024 / 2048), the single-workgroup
+    LDS radix selection (2048 < Q <= 16384) and the multi-workgroup selection above, including both hand-over
+    points and even / odd survivor counts; a quantised cloud supplies duplicate distances.  Also
+    sicp_icp_uncertainties on each path (optimization.py:126-170)."""
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(Q)
+    n = 70_000
+    P = _surface(n, 40 + (Q % 7))
+    x_true = np.array([0.002, -0.001, 0.003, 0.05, -0.03, 0.02])
+    Xm = orc.transform(np.linalg.inv(orc.params_to_H(x_true)), P + rng.normal(0, 0.01, P.shape))
+    if quantised:
+        P, Xm = np.round(P, 2), np.round(Xm, 2)
+    sel = np.sort(rng.choice(n, Q, replace=False))
+    ctx.upload(_lib.FIX, P)
+    ctx.upload(_lib.MOV, Xm)
+    nv, pl = ctx.estimate_normals(_lib.FIX, sel, 10)
+    if Q >= 6:
+        pl[:: max(1, Q // 5)] = np.nan                      # a few rows without planarity (corrpts.py:153-155)
+    ctx.icp_setup(sel, nv, pl)
+    z = np.zeros(6)
+    x, w = z.copy(), None
+    for it in range(3):
+        o = orc.icp_iteration(Xm, P[sel], nv, pl, x, x, w, z, z, 0.3) if Q >= 6 else None
+        if o is None or o["n"] < 6:
+            with pytest.raises(_lib.BackendError) as e:
+                ctx.icp_iterate(x, z, z, 0.3, w)
+            assert e.value.code == _lib.ERR_TOO_FEW
+            return
+        R = ctx.icp_iterate(x, z, z, 0.3, w)
+        idx, dist, keep, resid = ctx.icp_state()
+        assert np.array_equal(idx, o["nn"]) and np.array_equal(dist, o["dist"]) and np.array_equal(keep, o["keep"])
+        assert R.n_kept == o["n"] and R.median == o["median"] and R.mad == o["mad"]
+        assert R.n_planar == int(np.count_nonzero(pl >= np.float32(0.3)))
+        x = np.array(R.x[:])
+        assert np.abs(x - o["x"]).max() < 1e-9
+        assert abs(R.weight_used - o["w"]) <= 1e-12 * abs(o["w"])
+        w = R.weight_used
+        assert abs(R.dist_mean - dist[keep].mean()) < 1e-15 and abs(R.dist_std - dist[keep].std()) < 1e-14
+        assert abs(R.res_mean - resid[keep].mean()) < 1e-15 and abs(R.res_std - resid[keep].std()) < 1e-14
+        assert np.allclose(resid[keep], orc.residuals(x, P[sel], nv, Xm[idx], keep), rtol=0, atol=1e-13)
+    s = ctx.icp_uncertainties()
+    so = orc.uncertainties(x, w, z, z, P[sel], nv, Xm[idx], keep)
+    assert np.allclose(s, so, rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CHAIN)
+def test_iteration_with_movable_selection_and_planarity(ctx, name, clouds):
+    """corrpts.py:131-135 (only pc2's selected points are searched) and :158-163 (pc2's planarity column filters
+    too): the searched cloud is the selected subset, sicp_cloud_set_planarity carries its column; indices (mapped
+    back through the subset), distances and masks bit-exact against the oracle, which reproduces the reference's
+    own trace of these runs on the CPU (tests/test_oracle_golden.py)."""
+    from simpleicp_amd import _lib
+    g, files, kw = load_golden(name)
+    Xf, Xm = clouds(files[0]), clouds(files[1])
+    msel, pl2 = movable_columns(g, len(Xm))
+    rows = np.arange(len(Xm)) if msel is None else msel
+    sel = g["sel_idx"]
+    z = np.zeros(6)
+    ctx.upload(_lib.FIX, Xf)
+    ctx.upload(_lib.MOV, Xm[rows])
+    sub = pl2[rows]
+    at = np.flatnonzero(~np.isnan(sub))
+    for dense in (False, True):
+        if dense:
+            ctx.set_planarity(_lib.MOV, sub)
+        else:
+            ctx.set_planarity(_lib.MOV, sub[at], rows=at)
+        ctx.icp_setup(sel, g["normals"], g["planarity"])
+        x = z.copy()
+        for it in range(4):
+            R = ctx.icp_iterate(x, z, z, 0.3, 1.0)
+            o = orc.icp_iteration(Xm, Xf[sel], g["normals"], g["planarity"], x, x, 1.0, z, z, 0.3, mov_sel=msel, planarity_mov=pl2)
+            idx, dist, keep, resid = ctx.icp_state()
+            assert np.array_equal(rows[idx], o["nn"]) and np.array_equal(dist, o["dist"]) and np.array_equal(keep, o["keep"])
+            assert R.n_kept == o["n"] and R.median == o["median"] and R.mad == o["mad"]
+            x = np.array(R.x[:])
+            assert np.abs(x - o["x"]).max() < 1e-9
+    # without the column the filter is off again (and an upload clears it)
+    ctx.set_planarity(_lib.MOV, None)
+    R0 = ctx.icp_iterate(z, z, z, 0.3, 1.0)
+    assert R0.n_planar == int(np.count_nonzero(g["planarity"] >= np.float32(0.3)))
+    ctx.set_planarity(_lib.MOV, sub)
+    ctx.upload(_lib.MOV, Xm[rows])
+    assert ctx.icp_iterate(z, z, z, 0.3, 1.0).n_planar == R0.n_planar
+    with pytest.raises(_lib.BackendError):
+        ctx.set_planarity(_lib.MOV, np.zeros(3, np.float32), rows=np.array([0, 1, len(rows)]))
+    with pytest.raises(_lib.BackendError):
+        ctx.icp_setup(np.array([0, len(Xf)]), np.zeros((2, 3), np.float32), np.zeros(2, np.float32))
+    with pytest.raises(_lib.BackendError):
+        ctx.estimate_normals(_lib.FIX, np.array([-1, 3]), 5)

@@ -7,7 +7,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from conftest import GOLDEN_CASES, load_golden
+from conftest import GOLDEN_CASES, GOLDEN_CHAIN, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -17,6 +17,12 @@ def _run(name, clouds, inject_normals, verbose=False, **extra):
     g, files, kw = load_golden(name)
     pc_fix = PointCloud(clouds(files[0]), columns=["x", "y", "z"])
     pc_mov = PointCloud(clouds(files[1]).copy(), columns=["x", "y", "z"])
+    if "mov_sel_idx" in g.files:
+        # the movable cloud was the fixed cloud of an earlier run: partial `selected` mask + sparse planarity column
+        pc_mov.idx_selected = g["mov_sel_idx"]
+        v = np.full(len(pc_mov), np.nan, np.float32)
+        v[g["mov_planarity_rows"]] = g["mov_planarity_vals"]
+        pc_mov["planarity"] = pd.arrays.SparseArray(v)
     if inject_normals:
         # the reference's own bypass (simpleicp.py:176): precomputed attribute columns
         sel = g["sel_idx"]
@@ -33,7 +39,7 @@ def _run(name, clouds, inject_normals, verbose=False, **extra):
     return g, kw, icp, pc_fix, pc_mov, out
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + GOLDEN_CHAIN)
 def test_run_with_reference_normals(name, clouds):
     """Identical inputs to the loop (the reference's normals): H must match the reference to
     1e-7 absolute per entry (its own least_squares tolerance is 1e-8 relative), iteration count
@@ -56,6 +62,12 @@ def test_run_with_reference_normals(name, clouds):
     assert np.abs(X[:64] - g["X_mov_transformed_head"]).max() < 1e-5
     assert np.abs(X.sum(axis=0) - g["X_mov_transformed_sum"]).max() < 1e-4 * len(X)
     assert np.array_equal(pc_fix.idx_selected, g["sel_idx"])
+    if name in GOLDEN_CHAIN:
+        # the movable cloud's own selection survives the run (the reference never edits pc2's mask), and the pc2
+        # planarity filter was active: some iteration lost correspondences to it (corrpts.py:158-163)
+        assert np.array_equal(pc_mov.idx_selected, g["mov_sel_idx"])
+        n_pl1 = int(np.count_nonzero(g["planarity"] >= np.float32(kw.get("min_planarity", 0.3))))
+        assert min(len(g[f"it{i:03d}_after_planarity_pc1_idx"]) for i in range(int(g["iterations"]))) < n_pl1
 
 
 # The reference's result depends on the (arbitrary, LAPACK-internal) SIGN of each normal through the

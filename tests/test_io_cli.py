@@ -54,6 +54,27 @@ def test_write_xyz_bytes_equal_reference_writers(tmp_path):
     assert np.allclose(io.read_xyz(tmp_path / "p.xyz"), X[:100], atol=5.1e-4)
 
 
+def test_xyz_extreme_values_and_non_finite_rows(tmp_path):
+    """Values whose '%.3f' image is hundreds of characters long (1e100, DBL_MAX) and nan / inf are written with the
+    bytes pandas writes, and rows that START with nan / inf are data rows for the reader as they are for
+    np.genfromtxt (the 64-byte scratch buffer was over-read for |v| >= 1e59)."""
+    from simpleicp_amd import io
+    X = np.array([[1e100, -1e59, 1.0], [np.finfo(float).max, -np.finfo(float).max, 5e-324],
+                  [np.nan, np.inf, -np.inf], [1.5, 2.5, 3.5], [-np.inf, 0.0, np.nan]])
+    io.write_xyz(tmp_path / "a.xyz", X)
+    pd.DataFrame(X, columns=list("xyz")).to_csv(tmp_path / "b.xyz", sep=" ", header=["//X", "Y", "Z"], index=False,
+                                                float_format="%.3f", na_rep="nan")
+    assert (tmp_path / "a.xyz").read_bytes() == (tmp_path / "b.xyz").read_bytes()
+    got = io.read_xyz(tmp_path / "a.xyz")
+    ref = np.genfromtxt(tmp_path / "a.xyz", comments="//")
+    assert got.shape == (5, 3) and np.array_equal(got, ref, equal_nan=True)
+    io.write_xyz(tmp_path / "c.xyz", X, decimals=-1, header=None)
+    np.savetxt(tmp_path / "d.xyz", X)
+    assert (tmp_path / "c.xyz").read_bytes() == (tmp_path / "d.xyz").read_bytes()
+    with pytest.raises(OSError):
+        io.write_xyz(tmp_path / "e.xyz", X, decimals=100)
+
+
 def test_cli_options_mirror_reference():
     """c++/src/simpleicp-cli.cpp:12-35 / rust/src/main.rs:8-46: same short and long names and defaults."""
     from simpleicp_amd.cli import build_parser

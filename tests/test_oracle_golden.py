@@ -3,7 +3,9 @@ produced by the unmodified reference (oracle/make_golden.py).  CPU-only."""
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, load_golden
+from conftest import GOLDEN_CASES, GOLDEN_CHAIN, load_golden, movable_columns
+
+ALL_CASES = GOLDEN_CASES + GOLDEN_CHAIN
 from oracle import orc, ref_port
 
 
@@ -16,7 +18,13 @@ def _case(name, clouds):
     return g, Xf, Xm, kw, obs, ow
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+def _mov(g, Xm):
+    """selected rows of the movable cloud (all when the fixture has none) and its planarity column (or None)"""
+    sel, pl = movable_columns(g, len(Xm))
+    return (np.arange(len(Xm)) if sel is None else sel), pl
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_match_and_distances_bit_exact(name, clouds):
     """Feeding the reference's own parameter estimate of iteration i-1, the oracle's
     brute-force match (K) must return the reference's cKDTree indices except on exact
@@ -24,6 +32,7 @@ def test_match_and_distances_bit_exact(name, clouds):
     g, Xf, Xm, kw, obs, ow = _case(name, clouds)
     p1 = Xf[g["sel_idx"]]
     n1 = g["normals"]
+    msel, _ = _mov(g, Xm)                       # corrpts.py:131-135: only pc2's SELECTED points are searched
     # The reference transforms the movable cloud by H and back by inv(H) IN PLACE every
     # iteration (simpleicp.py:188,202), so its coordinates drift by a few ulp; replay that.
     Xcur = Xm.copy()
@@ -33,7 +42,8 @@ def test_match_and_distances_bit_exact(name, clouds):
     for it in range(int(g["iterations"])):
         x_prev = obs if it == 0 else g[f"it{it - 1:03d}_x"]
         H = orc.params_to_H(x_prev)
-        nn, d2 = orc.knn(Xcur, p1, k=1, H=H)
+        nn, d2 = orc.knn(Xcur[msel], p1, k=1, H=H)
+        nn = msel[nn]
         ref_nn = g[f"it{it:03d}_pc2_idx"]
         diff = np.flatnonzero(nn[:, 0] != ref_nn)
         if len(diff):
@@ -47,12 +57,18 @@ def test_match_and_distances_bit_exact(name, clouds):
         Xcur = orc.transform(np.linalg.inv(H), orc.transform(H, Xcur))
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_rejection_matches_reference(name, clouds):
     g, Xf, Xm, kw, obs, ow = _case(name, clouds)
     sel = g["sel_idx"]
+    _, pl2 = _mov(g, Xm)
+    thr = kw.get("min_planarity", 0.3)
     for it in range(int(g["iterations"])):
-        keep, n, med, mad = orc.reject(g[f"it{it:03d}_dist"], g["planarity"], kw.get("min_planarity", 0.3))
+        pl = g["planarity"]
+        if pl2 is not None:                      # corrpts.py:158-163: pc2's planarity column filters too (NaN fails)
+            pl = np.where(pl2[g[f"it{it:03d}_pc2_idx"]] >= np.float32(thr), pl, np.float32(np.nan))
+            assert np.array_equal(sel[pl >= np.float32(thr)], g[f"it{it:03d}_after_planarity_pc1_idx"])
+        keep, n, med, mad = orc.reject(g[f"it{it:03d}_dist"], pl, thr)
         assert np.array_equal(sel[keep], g[f"it{it:03d}_kept_pc1_idx"])
         assert n == int(g["counts"][it])
 
@@ -86,7 +102,7 @@ def test_solver_reaches_reference_minimiser(name, clouds):
         assert np.array_equal(x[fixed], g[f"it{it:03d}_x0"][fixed])
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_oracle_end_to_end(name, clouds):
     """Whole loop with the oracle's own match: same per-iteration counts, same H."""
     g, Xf, Xm, kw, obs, ow = _case(name, clouds)
@@ -94,9 +110,10 @@ def test_oracle_end_to_end(name, clouds):
     x_prev = obs.copy()
     w = kw.get("distance_weights", 1)
     counts = []
+    msel, pl2 = movable_columns(g, len(Xm))
     for it in range(int(g["iterations"])):
         r = orc.icp_iteration(Xm, p1, g["normals"], g["planarity"], x_prev, x_prev, w, obs, ow,
-                              kw.get("min_planarity", 0.3))
+                              kw.get("min_planarity", 0.3), mov_sel=msel, planarity_mov=pl2)
         w = r["w"]
         x_prev = r["x"]
         counts.append(r["n"])
