@@ -1,31 +1,44 @@
 #!/usr/bin/env python3
-"""bench.py -- ICP iterations/s (+ kNN correspondences/s) on the BASELINE.json workload.
+"""bench.py -- ICP iterations/s (+ kNN correspondences/s) on the BASELINE.json workloads.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py                          # C4, 1 GPU, 20 steps, 3 warm-up steps
+    python bench.py --config C3              # C1 | C2 | C3 | C4 | C5size
+    python bench.py --gpus 2                 # spawns the ranks itself when not started by torchrun
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[3], SURVEY.md section 8d "C4"): synthetic 10M-vs-10M surface
-(two independent samplings, known rigid perturbation), correspondences=1000, neighbors=10,
-float64 like the reference.  A "step" is ONE full ICP iteration through the C ABI
-(`sicp_icp_iterate`: exact 1-NN match of the Q selected fixed points in the movable cloud under
-the current H, point-to-plane distances, planarity + raw-MAD rejection, Levenberg-Marquardt solve
-of the reference's objective).  Both clouds, the selected points and their normals are resident
-in HBM before the timed region; the timed region is K consecutive iterations of a run that starts
-at the initial pose (no early stop), bracketed by barrier + device synchronisation, MAX over ranks.
+Workloads (BASELINE.json `configs`):
+  C1      Dragon (dragon1 vs dragon2), correspondences=1000                     bundled data
+  C2      Bunny partial overlap, max_overlap_distance=1, correspondences=1000   bundled data
+  C3      1.34 M-vs-1.34 M synthetic stand-in for the airborne pair (the files are missing upstream), Q = 10 000
+  C4      synthetic 10 M-vs-10 M surface (two independent samplings + known rigid perturbation), Q = 1000
+          -- the configuration the metric is quoted on, and the default
+  C5size  100 M-vs-100 M, Q = 1 M on ONE GPU (the 8-GPU config's sizes; ~12 GB of the 288 GB)
 
-N > 1: STRONG scaling -- the same 10M-point movable cloud is sharded by index range over the
-ranks (one process per GPU), one all_gather exchange per iteration (simpleicp_amd/dist.py).
-After pruning, one iteration is ~100 us of latency-bound work on ONE GPU, so sharding cannot
-speed it up (the exchange adds latency); the N > 1 numbers document that cost.
+A "step" is ONE full ICP iteration through the C ABI (exact 1-NN match of the Q selected fixed points in
+the movable cloud under the current H, point-to-plane distances, planarity + raw-MAD rejection, Levenberg-
+Marquardt solve of the reference's objective).  Both clouds, the selected points and their normals are resident
+in HBM before the timed region.  The timed region is K consecutive iterations of a run that starts COLD at the
+initial pose (`sicp_icp_setup` was just called: no search bound from an earlier match; min_change = 0 so no step
+is skipped), bracketed by barrier + device synchronisation, MAX over ranks, with kernel timing events OFF.  It
+is repeated `--repeats` times (same start state every time); `value` is K / median(elapsed), the spread is in
+`repeat_stats`.  Kernel splits and the roofline object come from a separate, instrumented pass of the same K
+steps (HIP events on the library's own stream).
 
-One JSON line on stdout (rank 0).  Extra objects (all on the same line):
-  roofline             the kernel with the largest share of the step's GPU time, SURVEY 8(d) bytes
-  roofline_match       the 1-NN kernel of the default path (pruned grid search)
-  roofline_bruteforce  the north-star brute-force scan (`k_knn1_frec`), measured in a short extra
-                       leg on the same inputs: HBM fraction and FP32-VALU fraction
-  cpu_baseline         the reference's algorithm (oracle/ref_port.py: cKDTree rebuild + query +
-                       least_squares per iteration) on this box's host cores, bounded sample
+N > 1: STRONG scaling -- the same movable cloud is sharded by index range over the ranks (one process per GPU),
+one all-gather exchange per iteration.
+
+One JSON line on stdout (rank 0).  Extra objects on the same line:
+  roofline             the kernel with the largest share of the step's GPU time; `achieved` = algorithmic bytes per
+                       launch / average launch duration
+  roofline_match       the 1-NN kernel of the default path (pruned grid search), priced on the bytes the pruned
+                       search itself needs (candidates x 28 B + cell offsets + queries), with `pruning_ratio`
+  roofline_bruteforce  the north-star brute-force scan, measured in a short extra leg on the same inputs
+  parity               one more iteration after the timed region, checked against the CPU oracle
+  setup                upload / grid build / normals, each once per run() -- outside `value`, reported
+  run_end_to_end       a real run(): cold, min_change = 1, setup included
+  cpu_baseline         the reference's algorithm (oracle/ref_port.py) on this box's host cores, bounded sample
+  cpu_reference        the UNMODIFIED reference timed in the build container (profiles/cpu_reference.json)
 """
 import argparse
 import json
@@ -40,7 +53,15 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP32_VALU_PEAK_TFLOPS = 157.3    # vector FP32 peak (spec); v_fma_f32 measures 111 TF (scripts/ubench)
+FP32_VALU_PEAK_TFLOPS = 157.3    # vector FP32 peak (spec) = FP32 MFMA peak
+
+CONFIGS = {
+    "C1": dict(kind="dataset", fix="dragon1", mov="dragon2", Q=1000, k=10, kwargs={}),
+    "C2": dict(kind="dataset", fix="bunny_part1", mov="bunny_part2", Q=1000, k=10, kwargs={"max_overlap_distance": 1.0}),
+    "C3": dict(kind="synthetic", n=1_340_000, Q=10_000, k=10, kwargs={}),
+    "C4": dict(kind="synthetic", n=10_000_000, Q=1000, k=10, kwargs={}),
+    "C5size": dict(kind="synthetic", n=100_000_000, Q=1_000_000, k=10, kwargs={}),
+}
 
 
 def synthetic_pair(n, seed_fix=0, seed_mov=1):
@@ -68,6 +89,22 @@ def synthetic_pair(n, seed_fix=0, seed_mov=1):
     return np.ascontiguousarray(Xf), np.ascontiguousarray(Xm), H_true
 
 
+def load_workload(name, points=None, correspondences=None):
+    """(Xf, Xm, H_true or None, Q, k, kwargs, description)"""
+    cfg = dict(CONFIGS[name])
+    Q = correspondences or cfg["Q"]
+    if cfg["kind"] == "dataset":
+        def cloud(stem):
+            return np.load(ROOT / "tests" / "golden" / "data" / f"{stem}.npz")["q"].astype(np.float64) / 1e4
+        Xf, Xm = cloud(cfg["fix"]), cloud(cfg["mov"])
+        desc = f"{name} {cfg['fix']} vs {cfg['mov']} (bundled data, {len(Xf)} / {len(Xm)} points)"
+        return Xf, Xm, None, Q, cfg["k"], cfg["kwargs"], desc
+    n = points or cfg["n"]
+    Xf, Xm, H_true = synthetic_pair(n)
+    desc = f"{name} synthetic {n}-vs-{n} surface (SURVEY 8d generator)"
+    return Xf, Xm, H_true, Q, cfg["k"], cfg["kwargs"], desc
+
+
 def iterate(ctx, n_it, x, obs, ow):
     """n_it iterations of the hot path behind one ABI call (sicp_icp_run; min_change=0 never converges early)."""
     if n_it <= 0:
@@ -77,21 +114,47 @@ def iterate(ctx, n_it, x, obs, ow):
     return np.array(res[-1].x[:]), sum(r.ne_evals for r in res), res[-1]
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--points", type=int, default=10_000_000)
-    ap.add_argument("--correspondences", type=int, default=1000)
-    ap.add_argument("--neighbors", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C4")
+    ap.add_argument("--points", type=int, default=None, help="override the synthetic cloud size")
+    ap.add_argument("--correspondences", type=int, default=None)
+    ap.add_argument("--repeats", type=int, default=50, help="repetitions of the K-step timed run (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce-leg", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=2)
     ap.add_argument("--force-exchange", action="store_true",
                     help="register the multi-GPU exchange even with one rank (measures its overhead on one GPU)")
-    args = ap.parse_args()
+    ap.add_argument("--out", type=str, default=None, help="also write the JSON line to this file")
+    return ap.parse_args(argv)
 
+
+def _spawn_entry(local_rank, world, port, argv):
+    os.environ.update({"RANK": str(local_rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    run(parse_args(argv))
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: start one process per GPU ourselves (same rendezvous the driver's launcher uses)
+        import socket
+        import torch.multiprocessing as mp
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_spawn_entry, args=(args.gpus, port, sys.argv[1:]), nprocs=args.gpus, join=True)
+        return
+    run(args)
+
+
+def run(args):
     import torch
     import torch.distributed as td
 
@@ -100,60 +163,106 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run "
-                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU path)", file=sys.stderr)
         sys.exit(2)
+    if local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} has no GPU (only {torch.cuda.device_count()} visible)", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
-    if world > 1 or args.force_exchange:
+    exchange = world > 1 or args.force_exchange
+    if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from simpleicp_amd import _lib, dist
 
-    N, Q, k = args.points, args.correspondences, args.neighbors
-    Xf, Xm, H_true = synthetic_pair(N)
+    Xf, Xm, H_true, Q, k, kw, desc = load_workload(args.config, args.points, args.correspondences)
+    Nf, Nm = len(Xf), len(Xm)
     ctx = _lib.Context(local_rank)
+    setup = {}
+    t0 = time.perf_counter()
     ctx.upload(_lib.FIX, Xf)
-    lo, hi = dist.shard_bounds(N, rank, world)
+    lo, hi = dist.shard_bounds(Nm, rank, world)
     ctx.upload(_lib.MOV, Xm[lo:hi], index_base=lo)
-    if world > 1 or args.force_exchange:
+    setup["upload_ms"] = (time.perf_counter() - t0) * 1e3
+    if exchange:
         ctx.set_exchange(dist.make_exchange(ctx), rank, world, gn_shard=Q >= 262144)
 
-    # select_n_points (pointcloud.py:132-147) + estimate_normals (one-off, untimed but reported)
-    sel = np.unique(np.round(np.linspace(0, N - 1, Q)).astype(np.int64)) if N > Q else np.arange(N)
+    # selection: partial-overlap pre-pass (simpleicp.py:155-170) + select_n_points (pointcloud.py:132-147)
+    sel = np.arange(Nf)
+    if np.isfinite(kw.get("max_overlap_distance", np.inf)):
+        t0 = time.perf_counter()
+        sel = sel[ctx.select_in_range(_lib.FIX, _lib.MOV, None, np.eye(4), kw["max_overlap_distance"])]
+        setup["overlap_prepass_ms"] = (time.perf_counter() - t0) * 1e3
+    if len(sel) > Q:
+        sel = np.unique(sel[np.round(np.linspace(0, len(sel) - 1, Q)).astype(np.int64)])
     ctx.timing_enable(True)
     t0 = time.perf_counter()
     normals, planarity = ctx.estimate_normals(_lib.FIX, sel, k)
-    normals_s = time.perf_counter() - t0
+    setup["normals_ms"] = (time.perf_counter() - t0) * 1e3          # includes the fixed cloud's grid build
     knnk = ctx.timing()["knnk_scan"]
-    ctx.icp_setup(sel, normals, planarity)
-
+    ctx.timing_enable(False)
     obs, ow = np.zeros(6), np.zeros(6)
-    iterate(ctx, args.warmup, obs.copy(), obs, ow)        # untimed warm-up from the initial pose (builds the grid)
-    ctx.timing_reset()
-    if world > 1:
-        td.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    x, ne_evals, last = iterate(ctx, args.steps, obs.copy(), obs, ow)
-    torch.cuda.synchronize()
-    if world > 1:
-        td.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.item())
 
+    def cold():
+        """state a run() starts from: selection declared, no search bound from an earlier match"""
+        ctx.icp_setup(sel, normals, planarity)
+
+    # first contact builds the movable cloud's grid: time it separately (one iteration from cold, then again)
+    cold()
+    t0 = time.perf_counter()
+    iterate(ctx, 1, obs.copy(), obs, ow)
+    first_ms = (time.perf_counter() - t0) * 1e3
+    cold()
+    t0 = time.perf_counter()
+    iterate(ctx, 1, obs.copy(), obs, ow)
+    setup["grid_build_ms"] = max(0.0, first_ms - (time.perf_counter() - t0) * 1e3)
+    iterate(ctx, args.warmup, obs.copy(), obs, ow)                  # untimed warm-up steps
+
+    def timed_run():
+        cold()
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x, ne_evals, last = iterate(ctx, args.steps, obs.copy(), obs, ow)
+        torch.cuda.synchronize()
+        if world > 1:
+            td.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            el = float(t.item())
+        return el, x, ne_evals, last
+
+    times = []
+    for _ in range(max(1, args.repeats)):
+        el, x, ne_evals, last = timed_run()
+        times.append(el)
+    times = np.array(times)
+    elapsed = float(np.median(times))
+
+    # instrumented pass: the same K steps with HIP events around every kernel class (perturbs the step, so it is
+    # not the timed run)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    cold()
+    iterate(ctx, args.steps, obs.copy(), obs, ow)
     timing = ctx.timing()
     match_kernel = ctx.last_match_kernel()
+    work = ctx.match_work() if hasattr(ctx, "match_work") else None
+    ctx.timing_enable(False)
+
+    # parity leg, device side (every rank takes part in the exchange; only rank 0 consults the oracle)
+    parity_rec = None if args.no_parity else parity_device(ctx, sel, normals, planarity, obs, ow)
+
     if rank != 0:
-        if world > 1:
+        if exchange:
             ctx.close()
             td.destroy_process_group()
         return
@@ -161,36 +270,54 @@ def main():
     H = _lib.params_to_H(x)
     n_local, nq = hi - lo, len(sel)
     avg = {kname: v["ms"] / max(1, v["launches"]) for kname, v in timing.items()}
-    match_ms, solve_ms = avg["match"], avg["solve"]
+    match_ms, solve_ms, select_ms = avg["match"], avg["solve"], avg["reject_select"]
     fused = nq <= 2048
-    # SURVEY 8(d) algorithmic bytes per launch
-    bytes_match = n_local * 24 + nq * (24 + 16)                      # read the searched cloud once + queries + (idx, d2)
     evals_per_it = ne_evals / args.steps
-    bytes_solve = int(last.n_kept) * 72 * evals_per_it + nq * 8 * 3  # 72 B/correspondence/GN evaluation + median/MAD passes
-    pmc = {}
+    bytes_bruteforce = n_local * 24 + nq * (24 + 16)        # read the searched cloud once + queries + (idx, d2)
+    bytes_solve = int(last.n_kept) * 72 * (evals_per_it if fused else 1.0) + (nq * 8 * 3 if fused else 0)
+    pmc, pmc_src = {}, None
     pmc_file = ROOT / "profiles" / "latest_pmc.json"
     if pmc_file.exists():
         pmc = json.loads(pmc_file.read_text())
+        pmc_src = f"profiles/latest_pmc.json ({pmc.get('_note', 'separate rocprofv3 --pmc passes')}); NOT collected in this run"
 
     def roof(kernel, ms, bytes_alg, note, extra=None):
         ach = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-             "traffic": pmc.get(kernel), "kernel": kernel, "avg_ms": ms, "bytes_alg_per_launch": int(bytes_alg),
-             "note": note}
+             "traffic": pmc.get(kernel), "traffic_source": pmc_src if pmc.get(kernel) is not None else None,
+             "kernel": kernel, "avg_ms": ms, "bytes_alg_per_launch": int(bytes_alg), "note": note}
         if extra:
             d.update(extra)
         return d
 
-    r_match = roof(match_kernel, match_ms, bytes_match,
-                   "exact 1-NN on a static uniform grid: only the cells inside the bound ball are read, so measured "
-                   "traffic is far BELOW the brute-force algorithmic bytes (pruning); wave-per-query, latency-bound"
-                   if match_kernel == "k_grid_nn" else
-                   "brute-force Q x N scan: VALU-bound by construction (SURVEY 8d), cloud read once")
-    r_solve = roof("k_icp_solve" if fused else "k_normal_eq", solve_ms, bytes_solve,
+    if match_kernel == "k_grid_nn":
+        # the pruned search's OWN bytes: every candidate it evaluates costs 24 B of coordinates (+4 B of original
+        # index on ties, counted for all), every grid row two 4-B offsets, every query its coordinates, the previous
+        # match (bound) and the 48-B result -- counted by the instrumented kernel variant when available, else the
+        # PMC traffic stands in
+        if work:
+            per = {kk: v / max(1, work["launches"]) for kk, v in work.items() if kk != "launches"}
+            bytes_match = per["candidates"] * 28 + per["rows"] * 8 + nq * (24 + 24 + 48)
+            extra = {"candidates_per_query": per["candidates"] / nq, "grid_rows_per_query": per["rows"] / nq}
+        else:
+            bytes_match = pmc.get("k_grid_nn") or bytes_bruteforce
+            extra = {"bytes_alg_source": "PMC traffic (no in-kernel work counters in this build)"}
+        extra["pruning_ratio"] = bytes_bruteforce / max(1.0, bytes_match)
+        extra["bytes_bruteforce_per_launch"] = int(bytes_bruteforce)
+        r_match = roof(match_kernel, match_ms, bytes_match,
+                       "exact 1-NN on a static uniform grid, one wave per query: reads only the cells inside the bound ball "
+                       "(pruning_ratio = brute-force algorithmic bytes / these); ~4 dependent memory round trips per "
+                       "query, i.e. latency-bound, not bandwidth-bound", extra)
+    else:
+        r_match = roof(match_kernel, match_ms, bytes_bruteforce,
+                       "brute-force Q x N scan: VALU-bound by construction (SURVEY 8d), cloud read once")
+    tail_kernel = "k_icp_tail" if fused else "k_normal_eq"
+    r_solve = roof(tail_kernel, solve_ms, bytes_solve,
                    "everything after the match in ONE single-workgroup launch (distances, MAD rejection, LM with "
                    "device-side 6x6 solves): ~1000 correspondences = latency-bound on one CU by design, not bandwidth"
-                   if fused else "fused residual + 6x6 normal-equation reduction, 72 B/correspondence")
-    dominant = r_solve if solve_ms * (1 if fused else evals_per_it) >= match_ms else r_match
+                   if fused else "fused residual + 6x6 normal-equation reduction, 72 B/correspondence/evaluation")
+    solve_total = solve_ms * (1 if fused else evals_per_it)
+    dominant = r_solve if solve_total >= match_ms else r_match
 
     out = {
         "metric": "ICP iterations/sec (kNN correspondences/sec in `correspondences_per_s`), 10M-vs-10M pts",
@@ -204,30 +331,48 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": f"C4 synthetic {N}-vs-{N} surface (SURVEY 8d generator), correspondences={Q}, "
-                               f"neighbors={k}, exact 1-NN (bit-identical to brute force)",
-                   "n_fixed": N, "n_movable": N, "correspondences": nq, "neighbors": k,
+        "data": "synthetic" if H_true is not None else "bundled reference data sets (tests/golden/data)",
+        "config": {"workload": f"{desc}, correspondences={Q}, neighbors={k}, exact 1-NN (bit-identical to brute force)",
+                   "name": args.config, "n_fixed": Nf, "n_movable": Nm, "correspondences": nq, "neighbors": k,
                    "parallelism": f"movable-cloud index shards x{world}, queries replicated"},
         "correspondences_per_s": nq * args.steps / elapsed,
+        "repeat_stats": {"repeats": len(times), "ms_per_step_median": elapsed / args.steps * 1e3,
+                         "ms_per_step_p10": float(np.percentile(times, 10)) / args.steps * 1e3,
+                         "ms_per_step_p90": float(np.percentile(times, 90)) / args.steps * 1e3,
+                         "ms_per_step_min": float(times.min()) / args.steps * 1e3,
+                         "ms_per_step_first": float(times[0]) / args.steps * 1e3,
+                         "timed_region": "K steps from the cold state (icp_setup just called), min_change=0, events off"},
         "roofline": dominant,
         "roofline_match": r_match,
-        "kernels": {name: {"avg_ms": avg[name], "launches": timing[name]["launches"]} for name in timing},
-        "gpu_ms_per_step": match_ms + solve_ms * (1 if fused else evals_per_it),
-        "normals": {"seconds": normals_s, "knnk_scan_ms": knnk["ms"], "pairs": int(N) * nq},
+        "kernels_instrumented": {name: {"avg_ms": avg[name], "launches": timing[name]["launches"]} for name in timing},
+        "gpu_ms_per_step_instrumented": match_ms + solve_total + select_ms,
+        "setup": {**setup, "normals_knn_kernel_ms": knnk["ms"],
+                  "note": "once per run(), outside `value`: host->HBM upload of both clouds (pageable memory), "
+                          "estimate_normals for the Q selected points (with the fixed cloud's grid), the movable cloud's grid"},
         "solver": {"normal_eq_evaluations_per_iteration": evals_per_it, "final_n_kept": int(last.n_kept),
                    "final_res_std": last.res_std},
-        "accuracy": {"max_abs_H_minus_H_true": float(np.abs(H - H_true).max())},
         "device": ctx.device_name(),
     }
+    if H_true is not None:
+        out["accuracy"] = {"max_abs_H_minus_H_true": float(np.abs(H - H_true).max())}
 
-    if world == 1 and not args.no_bruteforce_leg:
-        out["roofline_bruteforce"] = bruteforce_leg(local_rank, Xf, Xm, sel, normals, planarity, x, pmc)
+    if parity_rec is not None:
+        out["parity"] = parity_oracle(parity_rec, Xf, Xm, sel, normals, planarity, obs, ow)
+    if world == 1 and not args.no_end_to_end:
+        out["run_end_to_end"] = end_to_end(Xf, Xm, Q, k, kw)
+    if world == 1 and not args.no_bruteforce_leg and Nm * nq <= 2e11:
+        out["roofline_bruteforce"] = bruteforce_leg(local_rank, Xf, Xm, sel, normals, planarity, pmc, pmc_src)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(Xf, Xm, sel, normals, planarity, args.cpu_iterations)
+    ref_file = ROOT / "profiles" / "cpu_reference.json"
+    if ref_file.exists():
+        ref = json.loads(ref_file.read_text())
+        if args.config in ref.get("configs", {}):
+            out["cpu_reference"] = {**ref["configs"][args.config], "measured_on": ref.get("measured_on"),
+                                    "kind": "reference", "source": "profiles/cpu_reference.json (scripts/time_reference.py)"}
     if args.force_exchange:
         out["config"]["parallelism"] += " (exchange forced on 1 rank)"
-    if world > 1 or args.force_exchange:
+    if exchange:
         td.destroy_process_group()
     # RCCL prints a version banner through C stdio; flush it first so the JSON line is the LAST line
     try:
@@ -236,10 +381,76 @@ def main():
     except Exception:  # noqa: BLE001
         pass
     sys.stdout.flush()
-    print(json.dumps(out), flush=True)
+    line = json.dumps(out)
+    if args.out:
+        Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+        Path(args.out).write_text(line + "\n")
+    print(line, flush=True)
 
 
-def bruteforce_leg(device, Xf, Xm, sel, normals, planarity, x_ref, pmc):
+def parity_device(ctx, sel, normals, planarity, obs, ow):
+    """Outside the timed region: two iterations from the cold state through the product path; what they produced."""
+    rec = []
+    x = obs.copy()
+    ctx.icp_setup(sel, normals, planarity)
+    for it in range(2):
+        R = ctx.icp_iterate(x, obs, ow, 0.3, 1.0)
+        idx, dist, keep, _ = ctx.icp_state()
+        rec.append((x.copy(), R, idx, dist, keep))
+        x = np.array(R.x[:])
+    return rec
+
+
+def parity_oracle(rec, Xf, Xm, sel, normals, planarity, obs, ow):
+    """... checked against the CPU oracle (brute-force match, distances, rejection, solve).  At Q x N_m <= 3e10 pairs
+    the oracle runs the whole problem; above that a bounded sample of the queries is checked (the match is per
+    query, so a sample pins it just as well)."""
+    from oracle import orc
+    nq = len(sel)
+    cap = int(3e10 // len(Xm))
+    out = {"oracle": "oracle/sicp_oracle.c (brute-force CPU restatement, pinned against the unmodified reference)",
+           "iterations_checked": len(rec)}
+    ok_all = True
+    for it, (x, R, idx, dist, keep) in enumerate(rec):
+        if nq <= cap:
+            o = orc.icp_iteration(Xm, Xf[sel], normals, planarity, x, x, 1.0, obs, ow, 0.3)
+            res = {"indices_equal": bool(np.array_equal(idx, o["nn"])), "distances_equal": bool(np.array_equal(dist, o["dist"])),
+                   "keep_mask_equal": bool(np.array_equal(keep, o["keep"])),
+                   "median_mad_equal": bool(R.median == o["median"] and R.mad == o["mad"]),
+                   "max_abs_dx": float(np.abs(np.array(R.x[:]) - o["x"]).max())}
+            res["x_within_1e-9"] = res["max_abs_dx"] < 1e-9
+        else:
+            pick = np.unique(np.round(np.linspace(0, nq - 1, max(1, cap))).astype(np.int64))
+            nn, _ = orc.knn(Xm, Xf[sel[pick]], k=1, H=orc.params_to_H(x))
+            d = orc.point_to_plane(Xf[sel[pick]], normals[pick], Xm[nn[:, 0]], orc.params_to_H(x))
+            res = {"indices_equal": bool(np.array_equal(idx[pick], nn[:, 0])), "distances_equal": bool(np.array_equal(dist[pick], d)),
+                   "queries_sampled": int(len(pick))}
+        ok_all = ok_all and all(v for kk, v in res.items() if isinstance(v, bool))
+        out[f"iteration_{it}"] = res
+    out["ok"] = bool(ok_all)
+    return out
+
+
+def end_to_end(Xf, Xm, Q, k, kw):
+    """A real SimpleICP.run(): DataFrames in, cold, min_change = 1 (the reference's default), setup included."""
+    from simpleicp_amd import PointCloud, SimpleICP
+    best = None
+    for _ in range(2):                                   # second pass = warm process (allocator, page cache)
+        pc_fix = PointCloud(Xf, columns=["x", "y", "z"])
+        pc_mov = PointCloud(Xm.copy(), columns=["x", "y", "z"])
+        icp = SimpleICP(verbose=False)
+        icp.add_point_clouds(pc_fix, pc_mov)
+        t0 = time.perf_counter()
+        icp.run(correspondences=Q, neighbors=k, **kw)
+        dt = time.perf_counter() - t0
+        best = {"seconds": dt, "iterations": icp.last_run_info["iterations"],
+                "iterations_per_s": icp.last_run_info["iterations"] / dt,
+                "note": "SimpleICP.run() on DataFrames: upload, overlap pre-pass, normals, grid build, iterations to the "
+                        "reference's convergence test (min_change=1), final transform + download; second (warm) pass"}
+    return best
+
+
+def bruteforce_leg(device, Xf, Xm, sel, normals, planarity, pmc, pmc_src):
     """The north-star kernel: brute-force scan (FP32 conservative filter + exact FP64 verification) of the
     same Q x N problem, 6 iterations; also checks that it lands on the same estimate as the default path."""
     from simpleicp_amd import _lib
@@ -267,14 +478,15 @@ def bruteforce_leg(device, Xf, Xm, sel, normals, planarity, x_ref, pmc):
     kern = ctx.last_match_kernel()
     ctx.close()
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": pmc.get(kern), "kernel": kern, "avg_ms": ms, "bytes_alg_per_launch": bytes_alg,
+            "traffic": pmc.get(kern), "traffic_source": pmc_src if pmc.get(kern) is not None else None,
+            "kernel": kern, "avg_ms": ms, "bytes_alg_per_launch": bytes_alg,
             "pair_evals_per_s": pairs / (ms * 1e-3),
-            "valu_frac": pairs * 6 / (ms * 1e-3) / (FP32_VALU_PEAK_TFLOPS * 1e12),
+            "valu_or_mfma_frac": pairs * 6 / (ms * 1e-3) / (FP32_VALU_PEAK_TFLOPS * 1e12),
             "iterations_per_s": 6 / dt,
-            "note": "brute-force Q x N scan is VALU-bound by construction (SURVEY 8d): 3 v_fma_f32 + 1/2 v_min3 per pair "
-                    "(6 flop/pair against the 157.3 TF FP32 vector peak; v_fma_f32 alone measures 111 TF); the few passing "
-                    "(query, group) pairs are recorded and re-evaluated exactly in FP64 by k_knn1_fixup; the cloud is read "
-                    "from HBM once per 1024 queries"}
+            "note": "brute-force Q x N scan is compute-bound by construction (SURVEY 8d): 6 flop per pair in the FP32 filter "
+                    "(valu_or_mfma_frac = against the 157.3 TF FP32 vector = FP32 matrix peak); the few passing (query, group) "
+                    "pairs are recorded and re-evaluated exactly in FP64 by k_knn1_fixup; the cloud is read from HBM once per "
+                    "query block"}
 
 
 def cpu_baseline(Xf, Xm, sel, normals, planarity, iterations):
@@ -283,6 +495,8 @@ def cpu_baseline(Xf, Xm, sel, normals, planarity, iterations):
     normals injected (the reference's own estimate_normals needs ~10 min at 10M points)."""
     from oracle import ref_port
     cores = os.cpu_count() or 1
+    if len(Xm) > 20_000_000:
+        iterations = 1
     t0 = time.perf_counter()
     res = ref_port.run(Xf, Xm, correspondences=len(sel), max_iterations=iterations, min_change=0.0,
                        normals=normals, planarity=planarity, sel_idx=sel)

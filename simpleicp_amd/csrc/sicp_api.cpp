@@ -109,6 +109,7 @@ struct Cloud {
 };
 
 struct EventPair { hipEvent_t a, b; int kernel; };
+constexpr int REC_RING = 16;     // records in flight + being read
 
 long round_up(long v, long g) { return (v + g - 1) / g * g; }
 
@@ -231,6 +232,10 @@ struct sicp_ctx {
     bool host_trace = false;       // SICP_HOST_TRACE: per-iteration host timings on stderr
     bool solve_trace = false;      // SICP_SOLVE_TRACE: the fused kernel's cycle counters on stderr
     long solve_seq = 0;            // completion tickets of the fused kernel
+    DevBuf<IcpDev> icp_dev;        // device-resident loop state of a chained run (sicp_tail.hip)
+    double *h_rec = nullptr;       // pinned ring of per-iteration records the tail kernel streams to the host
+    IcpDev *h_state = nullptr;     // pinned staging of the loop state
+    int chain_depth = 4;           // iterations enqueued ahead of the last record read (SICP_CHAIN_DEPTH)
     // exchange
     sicp_exchange_fn xfn = nullptr;
     void *xuser = nullptr;
@@ -743,8 +748,13 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     int rc = c->small.reserve(128);
     if (rc == SICP_OK) rc = c->ne_partial.reserve((size_t)NE_MAX_GRID * 32);
     if (rc == SICP_OK) rc = c->ticket.reserve(4);
+    if (rc == SICP_OK) rc = c->icp_dev.reserve(1);
+    if (rc == SICP_OK && hipHostMalloc((void **)&c->h_rec, (size_t)REC_RING * REC_DOUBLES * sizeof(double), hipHostMallocMapped) != hipSuccess) rc = SICP_ERR_HIP;
+    if (rc == SICP_OK && hipHostMalloc((void **)&c->h_state, sizeof(IcpDev), hipHostMallocDefault) != hipSuccess) rc = SICP_ERR_HIP;
+    if (rc == SICP_OK) std::memset(c->h_rec, 0, (size_t)REC_RING * REC_DOUBLES * sizeof(double));
     if (rc == SICP_OK && hipMemsetAsync(c->ticket.p, 0, 4 * sizeof(unsigned), c->stream) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
+    if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
     if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : 0;
     if (const char *e = std::getenv("SICP_FSCAN_CAP")) c->fscan_cap = std::atol(e);
     if (const char *e = std::getenv("SICP_GRID_TARGET")) { const double t = std::atof(e); if (t >= 0.25 && t <= 1024) c->grid_target = t; }
@@ -770,8 +780,10 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->hit_cnt.release(); c->hit_list.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
     c->resid.release(); c->flag.release(); c->keep.release(); c->small.release(); c->ne_partial.release();
-    c->ticket.release();
+    c->ticket.release(); c->icp_dev.release();
     if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->h_rec) (void)hipHostFree(c->h_rec);
+    if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SICP_OK;
@@ -1053,22 +1065,152 @@ SICP_EXPORT int sicp_icp_setup(sicp_ctx *c, const int64_t *sel_idx, int64_t Q, c
     return sync(c);
 }
 
-SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
+namespace {
+
+int too_few(long long n)
 {
-    if (!c || !P || !R) return fail(SICP_ERR_INVALID, "null argument");
+    return fail(SICP_ERR_TOO_FEW, "Too few correspondences! At least 6 correspondences are needed to estimate the 6 "
+                                  "rigid body transformation parameters. The current number of correspondences is %lld.", n);
+}
+
+int check_iter_args(sicp_ctx *c, const sicp_iter_params *P)
+{
     if (c->Q <= 0) return fail(SICP_ERR_INVALID, "call sicp_icp_setup first");
     CHK(check_slot(c, SICP_MOV, true));
-    HIPCHK(hipSetDevice(c->device));
+    for (int j = 0; j < 6; ++j)
+        if (std::isnan(P->obs_weight[j]) || P->obs_weight[j] < 0) return fail(SICP_ERR_INVALID, "obs_weight[%d] must be >= 0", j);
+    return SICP_OK;
+}
+
+// does this configuration run the single-launch tail (sicp_tail.hip) with the loop state on the device?
+bool device_tail(const sicp_ctx *c) { return c->Q <= SOLVE_MAX_Q && !(c->gn_shard && c->xfn) && c->solve_mode != 2; }
+
+// ---- Q <= SOLVE_MAX_Q: match + ONE tail launch per iteration, iterations enqueued back to back --------------
+// The tail kernel reads the estimate it starts from out of the device-resident loop state and leaves the next
+// one there (with H(x), its inverse, the frozen weight, the convergence verdict); with the grid search the
+// match kernel takes its transform from that state too, so `chain_depth` iterations are in flight ahead of the
+// record the host is reading and nothing waits for a host round trip.  Launches after the end of the run
+// (converged / failed) see the stop flag and exit at once.  min_change < 0: no convergence test.
+int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, double min_change, sicp_iter_result *results,
+                    int64_t *done_out)
+{
+    const long Q = c->Q;
+    Cloud &cl = c->cloud[SICP_MOV];
+    *done_out = 0;
+    if (max_it <= 0) return SICP_OK;
+    // the pruned exact search on the static grid serves every rigid H, i.e. every H(x) of the loop
+    const bool grid = (c->knn1_mode == 0 || c->knn1_mode == 3) && cl.n < (1LL << 31);
+    if (grid) CHK(grid_build(c, SICP_MOV));
+    const int depth = grid ? c->chain_depth : 1;
+
+    IcpDev &hs = *c->h_state;
+    std::memset(&hs, 0, sizeof hs);
+    double H12[12];
+    params_to_H12(P0->x, H12);
+    for (int j = 0; j < 6; ++j) hs.x[j] = P0->x[j];
+    for (int j = 0; j < 3; ++j) { hs.sc[2 * j] = std::sin(P0->x[j]); hs.sc[2 * j + 1] = std::cos(P0->x[j]); }
+    for (int i = 0; i < 12; ++i) hs.H.m[i] = H12[i];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) hs.Hinv.m[4 * i + j] = H12[4 * j + i];
+        hs.Hinv.m[4 * i + 3] = -(H12[i] * H12[3] + H12[4 + i] * H12[7] + H12[8 + i] * H12[11]);
+    }
+    hs.w = (P0->distance_weight > 0) ? P0->distance_weight : -1.0;
+    HIPCHK(hipMemcpyAsync(c->icp_dev.p, &hs, sizeof hs, hipMemcpyHostToDevice, c->stream));
+
+    TailArgs A;
+    for (int j = 0; j < 6; ++j) { A.obs[j] = P0->obs[j]; A.ow[j] = P0->obs_weight[j]; }
+    A.min_change = min_change;
+    A.min_planarity = (float)P0->min_planarity;
+    A.max_steps = P0->max_lm_steps > 0 ? (int)P0->max_lm_steps : 100;
+    A.Q = (int)Q;
+    A.pl2 = cl.pl_n > 0 ? cl.pl.p : nullptr;
+    A.pl2_n = cl.pl_n;
+
+    double seqs[REC_RING];
+    double xcur[6]; std::memcpy(xcur, P0->x, sizeof xcur);
+    int64_t launched = 0, completed = 0;
+    bool over = false;
+    int rc = SICP_OK;
+    const bool htrace = c->host_trace;
+    while (true) {
+        while (launched < max_it && launched - completed < depth && !over) {
+            const auto h0 = std::chrono::steady_clock::now();
+            const double *prev = c->have_prev_match ? c->m_p2.p : nullptr;
+            if (grid) {
+                c->last_match_kernel = 2;
+                Timed t(c, SICP_K_KNN1);
+                launch_grid_nn_chained(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, Q, prev, cl.grid.g,
+                                       cl.grid.cell_start.p, cl.grid.sxyz.p, cl.grid.sxyz.p + cl.n, cl.grid.sxyz.p + 2 * cl.n,
+                                       cl.grid.sidx.p, c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p, c->m_idx.p, c->m_p2.p);
+            } else {
+                // brute-force flavours take H by value: one iteration in flight, H from the last record
+                params_to_H12(xcur, H12);
+                Xf X; for (int i = 0; i < 12; ++i) X.m[i] = H12[i];
+                CHK(knn1_device(c, SICP_MOV, c->q.p, Q, c->qpad, &X, std::numeric_limits<double>::infinity(), prev, c->m_d2.p,
+                                c->m_idx.p, c->m_p2.p));
+            }
+            HIPCHK(hipGetLastError());
+            c->have_prev_match = true;          // (after an exchange: the job-wide winner's coordinates -- still a valid bound)
+            CHK(exchange_best(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
+            A.seq = (double)(++c->solve_seq);
+            seqs[launched % REC_RING] = A.seq;
+            {
+                Timed t(c, SICP_K_NORMALEQ);
+                launch_icp_tail(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, c->m_p2.p,
+                                c->m_idx.p, A, c->icp_dev.p, c->dist.p, c->keep.p, c->resid.p,
+                                c->h_rec + (launched % REC_RING) * REC_DOUBLES);
+            }
+            HIPCHK(hipGetLastError());
+            ++launched;
+            if (htrace) {
+                const auto h1 = std::chrono::steady_clock::now();
+                std::fprintf(stderr, "[host] iteration %lld enqueued in %.1f us\n", (long long)launched,
+                             std::chrono::duration<double, std::micro>(h1 - h0).count());
+            }
+        }
+        if (completed == launched) break;
+        const double *o = c->h_rec + (completed % REC_RING) * REC_DOUBLES;
+        CHK(wait_ticket(c, o + REC_TICKET, seqs[completed % REC_RING]));
+        const int status = (int)o[REC_STATUS];
+        if (status == 3) { ++completed; over = true; continue; }        // launched after the end of the run: not an iteration
+        sicp_iter_result &R = results[*done_out];
+        std::memset(&R, 0, sizeof R);
+        R.n_queries = Q; R.n_planar = (int64_t)o[0]; R.median = o[1]; R.mad = o[2]; R.n_kept = (int64_t)o[3];
+        R.dist_mean = o[4]; R.dist_std = o[5];
+        for (int j = 0; j < 6; ++j) R.x[j] = o[10 + j];
+        ++completed; ++*done_out;
+        c->have_iter = true;
+        c->have_last_ne = false;
+        std::memcpy(c->last_x, R.x, sizeof c->last_x);
+        if (status == 1 || R.n_kept < 6) { rc = too_few((long long)R.n_kept); over = true; continue; }
+        if (status != 0) { rc = fail(SICP_ERR_NUMERIC, "objective is not finite"); over = true; continue; }
+        R.weight_used = o[6]; R.cost = o[7]; R.lm_steps = (int64_t)o[8]; R.ne_evals = (int64_t)o[9];
+        R.res_mean = o[16]; R.res_std = o[17];
+        params_to_H12(R.x, R.H);
+        R.H[12] = 0; R.H[13] = 0; R.H[14] = 0; R.H[15] = 1;
+        std::memcpy(xcur, R.x, sizeof xcur);
+        c->last_w = R.weight_used;
+        std::memcpy(c->last_obs, P0->obs, sizeof c->last_obs);
+        std::memcpy(c->last_ow, P0->obs_weight, sizeof c->last_ow);
+        std::memcpy(c->last_ne, o + 20, sizeof c->last_ne);
+        c->have_last_ne = true;
+        if (c->solve_trace)
+            std::fprintf(stderr, "[tail] cycles: load+dist %.0f select %.0f (median %.0f in %.0f rounds, MAD %.0f in %.0f) stats %.0f lm %.0f "
+                                 "(%lld evals %.0f, %lld steps, solves %.0f) final %.0f\n",
+                         o[50], o[51], o[55], o[56], o[57], o[58], o[52], o[53], (long long)R.ne_evals, o[59], (long long)R.lm_steps, o[60], o[54]);
+        if (o[REC_CONVERGED] != 0.0) over = true;
+    }
+    return rc;
+}
+
+// ---- larger Q (or a sharded 6x6 reduction): multi-kernel tail, LM loop on the host ---------------------------
+int iterate_host_lm(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
+{
     std::memset(R, 0, sizeof *R);
     const long Q = c->Q;
     int nfree = 0, freeidx[6];
-    for (int j = 0; j < 6; ++j) {
-        if (std::isnan(P->obs_weight[j]) || P->obs_weight[j] < 0) return fail(SICP_ERR_INVALID, "obs_weight[%d] must be >= 0", j);
+    for (int j = 0; j < 6; ++j)
         if (std::isfinite(P->obs_weight[j])) freeidx[nfree++] = j;
-    }
-
-    const bool htrace = c->host_trace;
-    const auto h0 = std::chrono::steady_clock::now();
     // ---- match: simpleicp.py:188-202, corrpts.py:124-137 (transform fused into the scan) ----
     double H12[12];
     params_to_H12(P->x, H12);
@@ -1077,66 +1219,6 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
                     c->have_prev_match ? c->m_p2.p : nullptr, c->m_d2.p, c->m_idx.p, c->m_p2.p));
     c->have_prev_match = true;              // (after an exchange: the job-wide winner's coordinates -- still a valid bound)
     CHK(exchange_best(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
-    // ---- small Q: the whole tail of the iteration is ONE single-workgroup launch (sicp_solve.hip) ----
-    const bool sharded_gn = c->gn_shard && c->xfn;
-    if (Q <= SOLVE_MAX_Q && !sharded_gn && c->solve_mode != 2) {
-        SolveArgs A;
-        A.H = X;
-        for (int j = 0; j < 6; ++j) { A.x0[j] = P->x[j]; A.obs[j] = P->obs[j]; A.ow[j] = P->obs_weight[j]; }
-        for (int j = 0; j < 3; ++j) { A.sc0[2 * j] = std::sin(P->x[j]); A.sc0[2 * j + 1] = std::cos(P->x[j]); }
-        A.w = (P->distance_weight > 0) ? P->distance_weight : -1.0;
-        A.min_planarity = (float)P->min_planarity;
-        A.max_steps = P->max_lm_steps > 0 ? (int)P->max_lm_steps : 100;
-        A.Q = Q;
-        A.pl2 = c->cloud[SICP_MOV].pl_n > 0 ? c->cloud[SICP_MOV].pl.p : nullptr;
-        A.pl2_n = c->cloud[SICP_MOV].pl_n;
-        A.seq = (double)(++c->solve_seq);
-        const auto h1 = std::chrono::steady_clock::now();
-        double *d_out = c->h_small + 64;      // pinned + mapped: the kernel's 56 result doubles land on the host directly
-        {
-            Timed t(c, SICP_K_NORMALEQ);
-            launch_icp_solve(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p,
-                             c->m_p2.p, c->m_idx.p, A, c->dist.p, c->flag.p, c->keep.p, c->resid.p, d_out);
-        }
-        HIPCHK(hipGetLastError());
-        const auto h2 = std::chrono::steady_clock::now();
-        CHK(wait_ticket(c, c->h_small + 64 + 55, A.seq));
-        if (htrace) {
-            const auto h3 = std::chrono::steady_clock::now();
-            auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-            std::fprintf(stderr, "[host] match launch %.1f us, solve launch %.1f us, wait %.1f us\n", us(h0, h1), us(h1, h2), us(h2, h3));
-        }
-        const double *o = c->h_small + 64;
-        R->n_queries = Q; R->n_planar = (int64_t)o[0]; R->median = o[1]; R->mad = o[2]; R->n_kept = (int64_t)o[3];
-        R->dist_mean = o[4]; R->dist_std = o[5];
-        c->have_iter = true;
-        std::memcpy(c->last_x, P->x, sizeof c->last_x);
-        c->have_last_ne = false;
-        if (o[18] == 1.0 || R->n_kept < 6) {
-            std::memcpy(R->x, P->x, sizeof R->x);
-            return fail(SICP_ERR_TOO_FEW, "Too few correspondences! At least 6 correspondences are needed to estimate the 6 "
-                                          "rigid body transformation parameters. The current number of correspondences is %lld.",
-                        (long long)R->n_kept);
-        }
-        if (o[18] != 0.0) return fail(SICP_ERR_NUMERIC, "objective is not finite");
-        R->weight_used = o[6]; R->cost = o[7]; R->lm_steps = (int64_t)o[8]; R->ne_evals = (int64_t)o[9];
-        for (int j = 0; j < 6; ++j) R->x[j] = o[10 + j];
-        R->res_mean = o[16]; R->res_std = o[17];
-        params_to_H12(R->x, R->H);
-        R->H[12] = 0; R->H[13] = 0; R->H[14] = 0; R->H[15] = 1;
-        std::memcpy(c->last_x, R->x, sizeof c->last_x);
-        c->last_w = R->weight_used;
-        std::memcpy(c->last_obs, P->obs, sizeof c->last_obs);
-        std::memcpy(c->last_ow, P->obs_weight, sizeof c->last_ow);
-        std::memcpy(c->last_ne, o + 20, sizeof c->last_ne);
-        c->have_last_ne = true;
-        if (c->solve_trace) {
-            std::fprintf(stderr, "[solve] cycles: dist %.0f sort %.0f stats %.0f lm %.0f (%lld evals, %lld steps, 6x6 solves %.0f) final %.0f\n",
-                         o[50], o[51], o[52], o[53], (long long)R->ne_evals, (long long)R->lm_steps, o[56], o[54]);
-            std::fprintf(stderr, "[eval]  cycles over all evals: rows %.0f barrier %.0f sums %.0f barrier %.0f\n", o[57], o[58], o[59], o[60]);
-        }
-        return SICP_OK;
-    }
     c->have_last_ne = false;
     // ---- distances + rejections: corrpts.py:139-211 ----
     launch_postmatch(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, c->m_p2.p,
@@ -1170,9 +1252,7 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
     std::memcpy(c->last_x, P->x, sizeof c->last_x);
     if (R->n_kept < 6) {
         std::memcpy(R->x, P->x, sizeof R->x);
-        return fail(SICP_ERR_TOO_FEW, "Too few correspondences! At least 6 correspondences are needed to estimate the 6 "
-                                      "rigid body transformation parameters. The current number of correspondences is %lld.",
-                    (long long)R->n_kept);
+        return too_few((long long)R->n_kept);
     }
     double w = P->distance_weight;
     if (!(w > 0)) w = 1.0 / (R->dist_std * R->dist_std);   // simpleicp.py:233-234
@@ -1245,11 +1325,32 @@ SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_it
     return SICP_OK;
 }
 
+}  // namespace
+
+SICP_EXPORT int sicp_icp_iterate(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
+{
+    if (!c || !P || !R) return fail(SICP_ERR_INVALID, "null argument");
+    CHK(check_iter_args(c, P));
+    HIPCHK(hipSetDevice(c->device));
+    if (!device_tail(c)) return iterate_host_lm(c, P, R);
+    std::memset(R, 0, sizeof *R);
+    int64_t done = 0;
+    return run_device_tail(c, P, 1, -1.0, R, &done);
+}
+
 SICP_EXPORT int sicp_icp_run(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_iterations, double min_change,
                              sicp_iter_result *results, int64_t *iterations_out)
 {
     if (!c || !P0 || !results || !iterations_out) return fail(SICP_ERR_INVALID, "null argument");
     *iterations_out = 0;
+    if (max_iterations <= 0) return SICP_OK;
+    CHK(check_iter_args(c, P0));
+    HIPCHK(hipSetDevice(c->device));
+    if (device_tail(c)) {
+        if (std::isnan(min_change)) min_change = 0.0;
+        // (a failing iteration's entry carries the estimate it started from: the tail kernel records it)
+        return run_device_tail(c, P0, max_iterations, min_change < 0 ? 0.0 : min_change, results, iterations_out);
+    }
     sicp_iter_params P = *P0;
     auto change = [](double now, double before) {          // simpleicp.py:361-365
         if (before == 0) return now == 0 ? 0.0 : std::numeric_limits<double>::infinity();
@@ -1257,7 +1358,7 @@ SICP_EXPORT int sicp_icp_run(sicp_ctx *c, const sicp_iter_params *P0, int64_t ma
     };
     for (int64_t it = 0; it < max_iterations; ++it) {
         sicp_iter_result &R = results[it];
-        const int rc = sicp_icp_iterate(c, &P, &R);
+        const int rc = iterate_host_lm(c, &P, &R);
         *iterations_out = it + 1;
         if (rc != SICP_OK) return rc;
         std::memcpy(P.x, R.x, sizeof P.x);

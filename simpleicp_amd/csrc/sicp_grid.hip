@@ -104,7 +104,10 @@ __device__ __forceinline__ void xf(const Xf &H, double x, double y, double z, do
     t = H.m[8] * x;  t = fma(H.m[9], y, t);  t = fma(H.m[10], z, t);  oz = t + H.m[11];
 }
 
-template <bool XFORM>
+// CHAINED: the launch belongs to a run whose iterations are enqueued back to back -- H and its inverse come from
+// the device-resident loop state the previous tail launch left (sicp_tail.hip), and the launch exits at once
+// when that tail declared the run over.
+template <bool XFORM, bool CHAINED>
 __global__ __launch_bounds__(256) void k_grid_nn(
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, long Q,
     const double *__restrict__ prev_p2 /* nullable: (Q,3) a cloud point per query (last match) -> its exact
@@ -112,12 +115,17 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     GridGeom G, const uint32_t *__restrict__ cell_start, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const uint32_t *__restrict__ sidx,
     Xf H, Xf Hinv, double rmax, double max_d2, int64_t idx_base,
-    double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out)
+    double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
+    const IcpDev *__restrict__ st)
 {
     const int lane = threadIdx.x & 63;
     const long q = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (q >= Q) return;                                   // whole wave leaves together
-    const double ax = qx[q], ay = qy[q], az = qz[q];
+    const double ax = qx[q], ay = qy[q], az = qz[q];      // (issued before the loop state is waited for)
+    if (CHAINED) {
+        H = st->H; Hinv = st->Hinv;
+        if (st->stop) return;
+    }
     double cxq = ax, cyq = ay, czq = az;                  // query in the cloud's own frame
     if (XFORM) xf(Hinv, ax, ay, az, cxq, cyq, czq);
     // covers rounding of H^-1 q and |R^T R - I| ~ 1e-16: distances in the two frames agree to
@@ -597,11 +605,22 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
     const dim3 grid(cdiv(Q, 4)), block(256);
     Xf id = {};
     if (H)
-        hipLaunchKernelGGL((k_grid_nn<true>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, sx, sy, sz, sidx, *H,
-                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out);
+        hipLaunchKernelGGL((k_grid_nn<true, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, sx, sy, sz, sidx, *H,
+                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr);
     else
-        hipLaunchKernelGGL((k_grid_nn<false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, sx, sy, sz, sidx, id,
-                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out);
+        hipLaunchKernelGGL((k_grid_nn<false, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, sx, sy, sz, sidx, id,
+                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr);
+}
+
+// the match of a chained iteration: transform taken from the loop state on the device
+void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
+                            const GridGeom &G, const uint32_t *cell_start, const double *sx, const double *sy, const double *sz,
+                            const uint32_t *sidx, const IcpDev *st, double rmax, int64_t idx_base, double *d2_out,
+                            int64_t *idx_out, double *p2_out)
+{
+    Xf id = {};
+    hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(cdiv(Q, 4)), dim3(256), 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, sx, sy, sz,
+                       sidx, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st);
 }
 
 void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int k, const GridGeom &G,

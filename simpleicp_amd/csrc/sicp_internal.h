@@ -21,26 +21,43 @@ constexpr int    NE_MAX_GRID = 1024;
 constexpr long   STATS_MB_MIN_Q = 16384;  // above: mean / std over many workgroups (two launches) instead of one CU
 #define SICP_PAD_COORD 1.0e300
 
-// fused single-workgroup tail of the iteration (sicp_solve.hip)
-constexpr int SOLVE_MAX_Q = 2048;   // 7 staged Jacobian columns x 2048 x 8 B = 112 KiB of LDS
-constexpr int SOLVE_BLOCK = 512;   // 8 waves: 256-VGPR budget (30 fp64 accumulators + Jacobian rows, no spills)
-struct SolveArgs {
-    Xf H;                       // transform of the match (H(x0))
-    double x0[6], obs[6], ow[6];
-    double sc0[6];              // sin, cos of x0[0..2] from the host libm
-    double w;                   // distance weight; <= 0 = automatic
-    double seq;                 // completion ticket the kernel publishes in out[55] when everything is written
-    float min_planarity;
-    int max_steps;
-    long Q;
-    const float *pl2;           // movable cloud's planarity column by GLOBAL index (corrpts.py:158-163), or null
-    long pl2_n;
-};
-void launch_icp_solve(hipStream_t st, const double *qx, const double *qy, const double *qz, const float *normals,
-                      const float *planarity, const double *p2, const int64_t *idx, const SolveArgs &A, double *dist,
-                      uint8_t *flag, uint8_t *keep, double *resid, double *out);
+constexpr int SOLVE_MAX_Q = 2048;   // single-launch tail (sicp_tail.hip): 8 staged Jacobian columns x 2048 x 8 B = 128 KiB of LDS
 void launch_fill_f32(hipStream_t s, float *dst, long n, float v);
 void launch_scatter_f32(hipStream_t s, float *dst, const int64_t *rows, const float *vals, long m);
+
+// ---- device-chained iteration loop (sicp_tail.hip) ----
+// Loop state that lives in device memory for a whole run: each tail launch starts from it and leaves the next
+// iteration's start there, so the launches of consecutive iterations are enqueued without a host round trip.
+struct IcpDev {
+    double x[6];                  // estimate the next iteration starts from
+    double sc[6];                 // sin, cos of x[0..2]
+    Xf H, Hinv;                   // H(x) and its rigid inverse [R^T | -R^T t]: the transform of the next match
+    double w;                     // distance weight; <= 0: automatic, frozen by the first iteration that runs
+    double prev_mean, prev_std;   // residual statistics of the last completed iteration (convergence test)
+    int done_iters;               // iterations completed in this run
+    int stop;                     // the run is over (converged / failed): later launches of the chain exit at once
+    int pad[2];
+};
+struct TailArgs {
+    double obs[6], ow[6];
+    double min_change;            // simpleicp.py:356-379, percent; < 0: no convergence test (single-iteration API)
+    double seq;                   // completion ticket published with this iteration's record
+    float min_planarity;
+    int max_steps;
+    int Q;
+    const float *pl2;             // movable cloud's planarity column by GLOBAL index (corrpts.py:158-163), or null
+    long pl2_n;
+};
+// per-iteration record the tail streams into pinned host memory (doubles):
+// 0 n_planar, 1 median, 2 mad, 3 n_kept, 4 dist_mean, 5 dist_std, 6 w_used, 7 cost, 8 lm_steps, 9 ne_evals,
+// 10..15 x, 16 res_mean, 17 res_std, 18 status, 19 converged, 20..49 normal equations at x, 50..54 phase cycles
+constexpr int REC_STATUS = 18;      // 0 ok / 1 too few correspondences / 2 objective not finite / 3 skipped (run already over)
+constexpr int REC_CONVERGED = 19;
+constexpr int REC_TICKET = 63;
+constexpr int REC_DOUBLES = 64;
+void launch_icp_tail(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
+                     const float *planarity, const double *p2, const int64_t *idx, const TailArgs &A, IcpDev *st, double *dist,
+                     uint8_t *keep, double *resid, double *rec);
 
 // uniform grid over a cloud in its own frame (sicp_grid.hip)
 struct GridGeom { double mn[3]; double h, inv_h; int dim[3]; };
@@ -60,6 +77,11 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
                     const GridGeom &G, const uint32_t *cell_start, const double *sx, const double *sy, const double *sz,
                     const uint32_t *sidx, const Xf *H, const Xf *Hinv, double rmax, double max_d2, int64_t idx_base,
                     double *d2_out, int64_t *idx_out, double *p2_out);
+
+void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
+                            const GridGeom &G, const uint32_t *cell_start, const double *sx, const double *sy, const double *sz,
+                            const uint32_t *sidx, const IcpDev *st, double rmax, int64_t idx_base, double *d2_out,
+                            int64_t *idx_out, double *p2_out);
 
 void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec);
 void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, double *d2, int64_t *idx, double *p2);

@@ -1,0 +1,711 @@
+// sicp_tail.hip -- everything after the match of one ICP iteration in ONE launch of ONE workgroup
+// (Q <= SOLVE_MAX_Q), chained on the device: the kernel takes the estimate it starts from out of the
+// device-resident loop state (IcpDev) and leaves the next one there (together with H(x), its inverse, the
+// frozen distance weight and the convergence verdict), so the host can enqueue the iterations of a run back to
+// back -- match, tail, match, tail, ... -- and only reads the per-iteration records the kernel streams into
+// pinned memory.
+//
+//   point-to-plane distances + planarity flags            corrpts.py:139-163,195-211
+//   median / raw-MAD rejection                            corrpts.py:165-188
+//   kept-distance statistics, automatic weight            simpleicp.py:229-234
+//   Levenberg-Marquardt on fused 6x6 normal equations     optimization.py:65-124,172-288
+//   residual statistics + convergence test                simpleicp.py:356-379
+//
+// At Q ~ 1000 everything here is latency, nothing is bandwidth -- and that includes INSTRUCTION FETCH: a
+// single workgroup runs every instruction once or a few times from a cold instruction cache, so the code is
+// written to be small (loops instead of unrolled copies, one call site per building block):
+//   * every correspondence lives in registers for the whole kernel (one global round trip, up front);
+//   * exact order statistics by RANGE-HISTOGRAM SELECTION instead of sorting: 256 bins over the current key
+//     interval, the bin holding the wanted rank becomes the next interval (1-3 rounds on real distances), the
+//     last <= 8 keys are ranked with one ballot;
+//   * the 29 normal-equation sums are ONE Gram product on the FP64 matrix pipe: rows [a0..a5 | r | 1] staged in
+//     LDS, v_mfma_f64_16x16x4_f64 with A = B (two 8x8 Gram blocks per instruction, 8 correspondences each);
+//   * the 6x6 solve runs redundantly in every lane (LDL^T in registers): no cross-lane traffic, no barrier;
+//   * record and loop state leave the kernel as ONE store instruction each (lanes of wave 0).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sicp_internal.h"
+#include "sicp_lanes.h"
+
+namespace sicp {
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void xfm(const double (&H)[12], double x, double y, double z, double &ox, double &oy, double &oz)
+{
+    double t;
+    t = H[0] * x;  t = fma(H[1], y, t);  t = fma(H[2], z, t);   ox = t + H[3];
+    t = H[4] * x;  t = fma(H[5], y, t);  t = fma(H[6], z, t);   oy = t + H[7];
+    t = H[8] * x;  t = fma(H[9], y, t);  t = fma(H[10], z, t);  oz = t + H[11];
+}
+__device__ __forceinline__ double pdist(double dx, double dy, double dz, float nx, float ny, float nz)
+{
+    const double a = dx * (double)nx, b = dy * (double)ny, c = dz * (double)nz;
+    return (a + b) + c;
+}
+__device__ __forceinline__ unsigned long long okey(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double oval(unsigned long long k)
+{
+    const unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+constexpr int TB = 256;                    // 4 waves, one per SIMD: each may use the whole 512-entry register file
+                                           // (the uniform solver state and up to 8 correspondences per lane live there)
+constexpr int NW = TB / 64;
+constexpr int HC = 16;                     // privatised histogram copies of a selection round
+constexpr int CAND_MAX = 8;                // keys left when a selection stops binning and ranks them directly
+constexpr unsigned long long NOKEY = ~0ull;
+constexpr int ST_DOUBLES = sizeof(IcpDev) / sizeof(double);
+static_assert(sizeof(IcpDev) % sizeof(double) == 0 && ST_DOUBLES <= 64, "the loop state leaves the kernel as one 64-lane store");
+
+struct TailShared {
+    double ja[SOLVE_MAX_Q][8];             // staged rows [a0..a5 | r | 1] of the kept correspondences (128 KiB at Q = 2048)
+    double gp[NW][2][64];                  // per-wave Gram blocks
+    double gf[NW][2][64];                  // per-wave copies of the reduced Gram matrix: current estimate / trial
+    double red[2][NW][4];                  // block sums: one slot per call site, no reuse hazards
+    double dmm[NW][2];                     // per-wave (min, -max) of the flagged distances
+    unsigned long long wmin[NW];           // per-wave smallest member key above a selection's final interval
+    unsigned tot[256];                     // folded histogram of a selection round
+    unsigned long long cand[CAND_MAX];
+    unsigned ncand;
+    unsigned wcnt[NW];
+    double out[64];                        // record / loop state on their way out (wave 0)
+};
+
+// block-wide sums of NV values per lane; every lane returns with the totals (fixed order)
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double (*buf)[4])
+{
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i] = wsum(v[i]); if (lane == 0) buf[wid][i] = v[i]; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = (buf[0][i] + buf[1][i]) + (buf[2][i] + buf[3][i]);
+}
+
+__device__ __forceinline__ unsigned long long wmin_u64(unsigned long long v)
+{
+    unsigned long long o;
+    o = lane_xor64<32>(v); v = o < v ? o : v;  o = lane_xor64<16>(v); v = o < v ? o : v;
+    o = lane_xor64<8>(v);  v = o < v ? o : v;  o = lane_xor64<4>(v);  v = o < v ? o : v;
+    o = lane_xor64<2>(v);  v = o < v ? o : v;  o = lane_xor64<1>(v);  v = o < v ? o : v;
+    return v;
+}
+__device__ __forceinline__ double wmin_f64(double v)
+{
+    v = fmin(v, lane_xor_f64<32>(v)); v = fmin(v, lane_xor_f64<16>(v)); v = fmin(v, lane_xor_f64<8>(v));
+    v = fmin(v, lane_xor_f64<4>(v));  v = fmin(v, lane_xor_f64<2>(v));  v = fmin(v, lane_xor_f64<1>(v));
+    return v;
+}
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Exact order statistics of the block's member keys (EPT per lane, NOKEY = not a member; m >= 1 members):
+// ka = key of rank r (0-based), kb = key of rank r + 1 when want2 (else ka).  Every lane gets both.
+//   [lo, hi] : an interval that contains every member key;
+//   round    : 256 bins of width 2^sh over [lo, hi]; the bin that holds the rank becomes the next [lo, hi] (integer
+//              arithmetic on the order-preserving keys: monotone, exact).  Real distances share their leading bits, so
+//              whole waves hit one bin in the first round -- and same-address LDS atomics cost ~10-20 cycles PER LANE.
+//              The histogram is therefore kept in HC privatised copies (lane & 15 picks one, rows padded to 257 words:
+//              at most 4 lanes of an instruction can meet); 256 lanes then fold one bin each, and every wave scans the
+//              totals itself;
+//   end      : the bin holds <= CAND_MAX keys (ranked with one ballot: lane 8 i + j compares keys i and j) or is a
+//              single key value (duplicates: quantised clouds).
+// hc (HC x 257 words, carved out of the row staging area) and S.ncand must be zero on entry and are zero again on exit.
+template <int EPT>
+__device__ __forceinline__ void block_select(TailShared &S, unsigned *hc, const unsigned long long (&k)[EPT], long r, bool want2,
+                                             unsigned long long lo, unsigned long long hi, unsigned long long &ka,
+                                             unsigned long long &kb, int &rounds_out)
+{
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    unsigned long long below = 0;            // members with key < lo
+    unsigned cs = 0;                         // members inside [lo, hi] once the loop ends
+    int sh = 0;
+    unsigned *mycopy = hc + (lane & (HC - 1)) * 257;
+#pragma unroll 1
+    for (int round = 0; round < 10; ++round) {
+        const unsigned long long range = hi - lo;
+        sh = range < 256ull ? 0 : (64 - __clzll((long long)range)) - 8;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (k[e] != NOKEY && k[e] >= lo && k[e] <= hi) atomicAdd(&mycopy[(unsigned)((k[e] - lo) >> sh)], 1u);
+        __syncthreads();
+        {   // lane t folds bin t over the copies and leaves them clean for the next round
+            unsigned tot = 0;
+#pragma unroll
+            for (int c = 0; c < HC; ++c) { tot += hc[c * 257 + tid]; hc[c * 257 + tid] = 0u; }
+            S.tot[tid] = tot;
+        }
+        __syncthreads();
+        // every wave scans the 256 totals on its own (lane l owns bins 4l..4l+3)
+        const uint4 h4 = *reinterpret_cast<const uint4 *>(&S.tot[4 * lane]);
+        const unsigned mine = h4.x + h4.y + h4.z + h4.w;
+        const unsigned incl = wscan_u32(mine);
+        const unsigned long long t = (unsigned long long)r - below;           // rank inside [lo, hi]
+        const unsigned long long gt = __ballot((unsigned long long)incl > t);
+        const int L = __ffsll((long long)gt) - 1;                               // the lane whose bins hold rank t
+        const unsigned eL = (unsigned)__builtin_amdgcn_readlane((int)(incl - mine), L);
+        const unsigned a0 = (unsigned)__builtin_amdgcn_readlane((int)h4.x, L), a1 = (unsigned)__builtin_amdgcn_readlane((int)h4.y, L);
+        const unsigned a2 = (unsigned)__builtin_amdgcn_readlane((int)h4.z, L), a3 = (unsigned)__builtin_amdgcn_readlane((int)h4.w, L);
+        unsigned acc = eL; int j = 0; cs = a0;
+        if (t >= (unsigned long long)acc + a0) { acc += a0; j = 1; cs = a1;
+            if (t >= (unsigned long long)acc + a1) { acc += a1; j = 2; cs = a2;
+                if (t >= (unsigned long long)acc + a2) { acc += a2; j = 3; cs = a3; } } }
+        const unsigned s = 4u * (unsigned)L + (unsigned)j;
+        below += acc;
+        lo = lo + ((unsigned long long)s << sh);
+        if (sh > 0) { const unsigned long long top = lo + ((1ull << sh) - 1ull); hi = top < hi ? top : hi; } else hi = lo;
+        rounds_out = round + 1;
+        if (cs <= (unsigned)CAND_MAX || sh == 0) break;
+    }
+    const unsigned long long t = (unsigned long long)r - below;                 // rank inside the final interval
+    const bool need_above = want2 && t + 1 >= cs;                                // the next rank lies above the final interval
+    if (sh == 0 || lo == hi) {
+        ka = lo; kb = lo;                                                         // one key value (cs copies of it)
+    } else {
+        // <= CAND_MAX members left: list them (at most 8 lanes touch the counter), then rank all pairs with one ballot
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (k[e] != NOKEY && k[e] >= lo && k[e] <= hi) { const unsigned slot = atomicAdd(&S.ncand, 1u); if (slot < (unsigned)CAND_MAX) S.cand[slot] = k[e]; }
+        __syncthreads();
+        if (tid == 0) S.ncand = 0u;             // (every gather atomic is behind the barrier; the next use is barriers away)
+        const int ci = lane >> 3, cj = lane & 7;
+        const unsigned long long vi = S.cand[ci], vj = S.cand[cj];
+        const bool before = ci != cj && (unsigned)ci < cs && (unsigned)cj < cs && (cj < ci ? vj <= vi : vj < vi);   // key j sorts before key i
+        const unsigned long long M = __ballot(before);
+        const unsigned rk = (unsigned)__popcll((long long)((M >> (8 * (lane & 7))) & 0xffull));   // lane i < 8: rank of key i
+        const unsigned long long mine = S.cand[lane & 7];
+        const bool valid = lane < 8 && (unsigned)lane < cs;
+        const unsigned long long ha = __ballot(valid && (unsigned long long)rk == t);
+        ka = readlane_u64(mine, __ffsll((long long)ha) - 1);
+        kb = ka;
+        if (want2 && !need_above) {
+            const unsigned long long hb = __ballot(valid && (unsigned long long)rk == t + 1);
+            kb = readlane_u64(mine, __ffsll((long long)hb) - 1);
+        }
+    }
+    if (need_above) {
+        // the smallest member key greater than hi: wave minimum (register moves), then one slot per wave
+        unsigned long long nx = NOKEY;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) if (k[e] != NOKEY && k[e] > hi) nx = k[e] < nx ? k[e] : nx;
+        nx = wmin_u64(nx);
+        if (lane == 0) S.wmin[wid] = nx;
+        __syncthreads();
+        unsigned long long b = S.wmin[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { const unsigned long long a = S.wmin[w]; b = a < b ? a : b; }
+        kb = b;
+    }
+}
+
+template <int EPT>
+struct Corr {                                       // one lane's correspondences, register resident
+    double px[EPT], py[EPT], pz[EPT], qx[EPT], qy[EPT], qz[EPT];
+    float nx[EPT], ny[EPT], nz[EPT];
+    bool keep[EPT];
+};
+
+// sin/cos of (a + d) from sin/cos of a: exact addition theorem with a short Taylor series for the
+// small step d (|d| <= 0.25 rad: d^17/17! < 2e-25); larger steps take the library routine.
+__device__ __attribute__((noinline)) double2 sincos_cold(double a)      // one out-of-line copy, results in registers
+{
+    double s, c;
+    sincos(a, &s, &c);
+    return make_double2(s, c);
+}
+
+__device__ __forceinline__ void sincos_step(double a_new, double d, double sa, double ca, double &sn, double &cn)
+{
+    if (fabs(d) > 0.25) { const double2 r = sincos_cold(a_new); sn = r.x; cn = r.y; return; }
+    const double d2 = d * d;
+    double sd = 1.0 / 1307674368000.0;
+    sd = fma(sd, d2, -1.0 / 6227020800.0);
+    sd = fma(sd, d2, 1.0 / 39916800.0);
+    sd = fma(sd, d2, -1.0 / 362880.0);
+    sd = fma(sd, d2, 1.0 / 5040.0);
+    sd = fma(sd, d2, -1.0 / 120.0);
+    sd = fma(sd, d2, 1.0 / 6.0);
+    sd = d - d * d2 * sd;
+    double cd = 1.0 / 20922789888000.0;
+    cd = fma(cd, d2, -1.0 / 87178291200.0);
+    cd = fma(cd, d2, 1.0 / 479001600.0);
+    cd = fma(cd, d2, -1.0 / 3628800.0);
+    cd = fma(cd, d2, 1.0 / 40320.0);
+    cd = fma(cd, d2, -1.0 / 720.0);
+    cd = fma(cd, d2, 1.0 / 24.0);
+    cd = 1.0 - d2 * (0.5 - d2 * cd);
+    sn = fma(sa, cd, ca * sd);
+    cn = fma(ca, cd, -(sa * sd));
+}
+
+__device__ __forceinline__ bool observed(double w) { return w > 0 && w < __builtin_inf(); }
+
+__device__ __forceinline__ void euler_H(const double (&x)[6], const double (&sc)[6], double (&H)[12])
+{
+    const double s1 = sc[0], c1 = sc[1], s2 = sc[2], c2 = sc[3], s3 = sc[4], c3 = sc[5];
+    H[0] = c2 * c3;                 H[1] = -c2 * s3;                H[2] = s2;        H[3] = x[3];
+    H[4] = c1 * s3 + s1 * s2 * c3;  H[5] = c1 * c3 - s1 * s2 * s3;  H[6] = -s1 * c2;  H[7] = x[4];
+    H[8] = s1 * s3 - c1 * s2 * c3;  H[9] = s1 * c3 + c1 * s2 * s3;  H[10] = c1 * c2;  H[11] = x[5];
+}
+
+// Normal equations of the unweighted residuals at x over the kept correspondences as the 8x8 Gram matrix G of the
+// rows [a0..a5 | r | 1] (J^T J = G[0..5][0..5], J^T r = G[.][6], sum r = G[6][7], sum r^2 = G[6][6], n = G[7][7]),
+// left in this wave's LDS slot S.gf[wave][slot] -- the sums are uniform, registers are not spent on them.
+// Jacobian of r = n.(R p + t - p1) w.r.t. the Euler angles through the instantaneous axes
+// w1 = e_x, w2 = Rx e_y = (0, c1, s1), w3 = Rx Ry e_z = (s2, -s1 c2, c1 c2)  (R = Rx Ry Rz, mathutils.py:39-68):
+// a_k = w_k . ((R p) x n).
+template <int EPT>
+__device__ __forceinline__ void eval_ne(TailShared &S, const double (&x)[6], const double (&sc)[6], const Corr<EPT> &C,
+                                        double (&rr)[EPT], int slot)
+{
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    double H[12];
+    euler_H(x, sc, H);
+    const double s1 = sc[0], c1 = sc[1], s2 = sc[2], c2 = sc[3];
+    const double w3y = -s1 * c2, w3z = c1 * c2;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (C.keep[e]) {
+            double X, Y, Z;
+            xfm(H, C.px[e], C.py[e], C.pz[e], X, Y, Z);
+            a[6] = pdist(X - C.qx[e], Y - C.qy[e], Z - C.qz[e], C.nx[e], C.ny[e], C.nz[e]);
+            const double nx = C.nx[e], ny = C.ny[e], nz = C.nz[e];
+            const double ux = X - x[3], uy = Y - x[4], uz = Z - x[5];          // R p
+            const double cx = uy * nz - uz * ny, cy = uz * nx - ux * nz, cz = ux * ny - uy * nx;   // (R p) x n
+            a[0] = cx;
+            a[1] = c1 * cy + s1 * cz;
+            a[2] = s2 * cx + w3y * cy + w3z * cz;
+            a[3] = nx; a[4] = ny; a[5] = nz;
+            a[7] = 1.0;
+        }
+        rr[e] = a[6];
+        double2 *row = reinterpret_cast<double2 *>(&S.ja[tid + e * TB][0]);
+        row[0] = make_double2(a[0], a[1]); row[1] = make_double2(a[2], a[3]);
+        row[2] = make_double2(a[4], a[5]); row[3] = make_double2(a[6], a[7]);
+    }
+    __syncthreads();
+    // Gram product on the FP64 matrix pipe.  v_mfma_f64_16x16x4_f64: A[m = lane&15][k = lane>>4], B[k][n = lane&15],
+    // one f64 per lane each.  Lane l supplies component (l & 7) of correspondence  base + 8 j + 4 ((l >> 3) & 1) + (l >> 4)
+    // as BOTH operands: rows / columns 0..7 of D accumulate the Gram block of four correspondences, rows / columns
+    // 8..15 that of four more; the two off-diagonal 8x8 blocks are garbage and ignored.  Two chains: the pipe overlaps them.
+    v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+    {
+        const double *src = &S.ja[wid * (EPT * 64) + 4 * ((lane >> 3) & 1) + (lane >> 4)][lane & 7];
+#pragma unroll
+        for (int j = 0; j < EPT * 4; ++j) {                  // unrolled: the LDS reads of all steps are in flight together
+            const double v = src[0], u = src[64];            // 8 rows x 8 doubles further
+            src += 128;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(u, u, acc2, 0, 0, 0);
+        }
+        acc += acc2;
+    }
+    // D: col = lane & 15, row = (lane >> 4) + 4 * reg
+    {
+        const int n = lane & 15;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int m = (lane >> 4) + 4 * rg;
+            if ((m >> 3) == (n >> 3)) S.gp[wid][m >> 3][(m & 7) * 8 + (n & 7)] = acc[rg];
+        }
+    }
+    __syncthreads();
+    // every wave folds the partial blocks itself and parks the result in its own LDS slot (a wave's LDS
+    // operations are ordered: no barrier between this write and the reads that follow)
+    double g = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) g += S.gp[w][0][lane] + S.gp[w][1][lane];
+    S.gf[wid][slot][lane] = g;
+}
+
+__device__ __forceinline__ double objective(const double *G, double w, const double (&x)[6], const TailArgs &A)
+{
+    double c = w * w * G[6 * 8 + 6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+        if (observed(A.ow[j])) { const double e = A.ow[j] * (x[j] - A.obs[j]); c += e * e; }
+    return c;
+}
+
+// LM step from the normal equations: (N + lambda diag N) dx = -g in every lane (LDL^T in registers, in place on
+// the lower triangle); parameters with an infinite observation weight are fixed (identity row / column).
+// Returns false when a pivot is not positive and finite.
+__device__ __forceinline__ bool lm_step(const double *G, double w, const double (&x)[6], double lambda, const TailArgs &A,
+                                        double (&dx)[6])
+{
+    const double w2 = w * w;
+    double M[6][6], b[6];                                  // only M[i][j], j <= i, is used
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const bool fi = !(A.ow[i] < __builtin_inf());
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const bool fj = !(A.ow[j] < __builtin_inf());
+            double a = w2 * G[j * 8 + i];
+            if (i == j) { if (observed(A.ow[i])) a += A.ow[i] * A.ow[i]; a += lambda * a; }
+            M[i][j] = (fi || fj) ? (i == j ? 1.0 : 0.0) : a;
+        }
+        double g = w2 * G[i * 8 + 6];
+        if (observed(A.ow[i])) g += A.ow[i] * A.ow[i] * (x[i] - A.obs[i]);
+        b[i] = fi ? 0.0 : -g;
+    }
+    // M = L D L^T: afterwards M[i][j] (j < i) = L[i][j], M[j][j] = D[j]
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = M[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= M[j][k] * M[j][k] * M[k][k];
+        ok = ok && (d > 0.0) && (d < __builtin_inf());
+        M[j][j] = d;
+        const double inv = 1.0 / d;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double t = M[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= M[i][k] * M[j][k] * M[k][k];
+            M[i][j] = t * inv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int k = 0; k < i; ++k) b[i] -= M[i][k] * b[k];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double t = b[i] / M[i][i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) t -= M[k][i] * dx[k];
+        dx[i] = t;
+    }
+    return ok;
+}
+
+// wave 0: the words parked in S.out leave in ONE store instruction; for the record the completion ticket
+// follows behind a system-scope fence (the host polls that pinned word instead of waiting for the end-of-kernel signal)
+__device__ __forceinline__ void flush_out(TailShared &S, double *dst, int count)
+{
+    const int lane = threadIdx.x;
+    if (lane < count) dst[lane] = S.out[lane];
+}
+__device__ __forceinline__ void publish(double *rec, double seq)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(rec + REC_TICKET, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+}  // namespace
+
+template <int EPT>
+__global__ __launch_bounds__(TB, 1) void k_icp_tail(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+    const float *__restrict__ normals, const float *__restrict__ planarity, const double *__restrict__ p2,
+    const int64_t *__restrict__ idx, TailArgs A, IcpDev *__restrict__ st, double *__restrict__ dist,
+    uint8_t *__restrict__ keep, double *__restrict__ resid, double *__restrict__ rec)
+{
+    __shared__ TailShared S;
+    const int tid = threadIdx.x, wid = tid >> 6;
+    const int Q = A.Q;
+    long long tk[6]; tk[0] = clock64();
+    // ---- loop state + this lane's correspondences: ONE global round trip (every load is issued before the first
+    //      barrier and before the stop flag is looked at) ----
+    Corr<EPT> C;
+    int64_t mi[EPT];
+    float pl[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * TB;
+        const int ic = i < Q ? i : Q - 1;                 // clamped: every lane loads, lanes past Q are masked below
+        C.px[e] = p2[3 * ic]; C.py[e] = p2[3 * ic + 1]; C.pz[e] = p2[3 * ic + 2];
+        C.qx[e] = qx[ic]; C.qy[e] = qy[ic]; C.qz[e] = qz[ic];
+        C.nx[e] = normals[3 * ic]; C.ny[e] = normals[3 * ic + 1]; C.nz[e] = normals[3 * ic + 2];
+        mi[e] = idx[ic]; pl[e] = planarity[ic];
+    }
+    double x[6], sc[6], H0[12];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { x[j] = st->x[j]; sc[j] = st->sc[j]; }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) H0[j] = st->H.m[j];
+    const double w_state = st->w, prev_mean = st->prev_mean, prev_std = st->prev_std;
+    const int done_iters = st->done_iters;
+    const int stop = st->stop;
+    unsigned *hc = reinterpret_cast<unsigned *>(&S.ja[0][0]);      // the row staging area is idle until the LM phase
+    for (int i = tid; i < HC * 257; i += TB) hc[i] = 0u;
+    if (tid == 0) S.ncand = 0u;
+    if (tid < 64) S.out[tid] = 0.0;
+    if (stop) {
+        // the run ended in an earlier launch (converged / failed): nothing to do but tell the host
+        if (tid == 0) rec[REC_STATUS] = 3.0;
+        if (wid == 0) publish(rec, A.seq);
+        return;
+    }
+
+    double d[EPT];
+    bool fl[EPT];
+    unsigned long long key[EPT];
+    unsigned nflag = 0;
+    double dmn = __builtin_inf(), dmx = -__builtin_inf();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * TB;
+        C.keep[e] = false; fl[e] = false; d[e] = 0.0; key[e] = NOKEY;
+        if (i < Q) {
+            bool f = mi[e] >= 0 && pl[e] >= A.min_planarity;
+            if (f && A.pl2) f = mi[e] < A.pl2_n && A.pl2[mi[e]] >= A.min_planarity;      // corrpts.py:158-163 (NaN fails)
+            double X, Y, Z;
+            xfm(H0, C.px[e], C.py[e], C.pz[e], X, Y, Z);
+            d[e] = pdist(X - C.qx[e], Y - C.qy[e], Z - C.qz[e], C.nx[e], C.ny[e], C.nz[e]);
+            dist[i] = d[e];
+            fl[e] = f;
+            if (f) { key[e] = okey(d[e]); dmn = fmin(dmn, d[e]); dmx = fmax(dmx, d[e]); }
+        }
+        nflag += (unsigned)__popcll((long long)__ballot(fl[e]));
+    }
+    // survivors of the planarity test and the range of their distances: wave reductions + one barrier
+    dmn = wmin_f64(dmn); dmx = wmin_f64(-dmx);
+    if ((tid & 63) == 0) { S.wcnt[wid] = nflag; S.dmm[wid][0] = dmn; S.dmm[wid][1] = dmx; }
+    __syncthreads();
+    long m = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { m += S.wcnt[w]; dmn = fmin(dmn, S.dmm[w][0]); dmx = fmin(dmx, S.dmm[w][1]); }
+    unsigned long long klo = okey(dmn), khi = okey(-dmx);
+    tk[1] = clock64();
+
+    if (m == 0) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { const int i = tid + e * TB; if (i < Q) { keep[i] = 0; resid[i] = 0.0; } }
+        if (tid == 0) {
+            S.out[1] = __builtin_nan(""); S.out[2] = __builtin_nan("");
+            for (int k = 0; k < 6; ++k) S.out[10 + k] = x[k];
+            S.out[REC_STATUS] = 1.0;
+            st->stop = 1;
+        }
+        if (wid == 0) { flush_out(S, rec, REC_TICKET); publish(rec, A.seq); }
+        return;
+    }
+
+    // ---- median / raw MAD (corrpts.py:165-188): np.median = mean of the two middle values ----
+    double med = 0.0, mad = 0.0;
+    int rounds[2] = {0, 0};
+    long long tsel = 0;
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        if (which == 1) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) if (fl[e]) key[e] = okey(fabs(d[e] - med));
+            // |d - med| is monotone in d on either side of med: its range follows from the distances' own
+            const double u = fabs(oval(klo) - med), v = fabs(oval(khi) - med);
+            klo = okey(0.0); khi = okey(u > v ? u : v);
+            tsel = clock64();
+        }
+        unsigned long long ka, kb;
+        int nr = 0;
+        block_select<EPT>(S, hc, key, (m - 1) / 2, (m & 1) == 0, klo, khi, ka, kb, nr);
+        const double mid = (oval(ka) + oval(kb)) / 2.0;
+        if (which == 0) { med = mid; rounds[0] = nr; } else { mad = mid; rounds[1] = nr; }
+    }
+    const double bound = 3 * mad;
+    tk[2] = clock64();
+
+    // ---- keep mask, mean / population std (ddof 0) of the kept distances: ONE pass over deviations from the median
+    //      (a shift within a few MAD of the mean: var = (S2 - S1^2 / n) / n loses nothing to cancellation) ----
+    double v3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * TB;
+        const double dev = d[e] - med;
+        const bool kq = fl[e] && fabs(dev) <= bound;
+        C.keep[e] = kq;
+        if (i < Q) keep[i] = kq ? 1 : 0;
+        if (kq) { v3[0] += 1.0; v3[1] += dev; v3[2] = fma(dev, dev, v3[2]); }
+    }
+    block_sum<3>(v3, S.red[0]);
+    const double nk = v3[0], dmean = med + v3[1] / nk;
+    const double dvar = (v3[2] - v3[1] * v3[1] / nk) / nk;
+    const double dstd = sqrt(dvar > 0.0 ? dvar : 0.0);
+    if (tid == 0) { S.out[0] = (double)m; S.out[1] = med; S.out[2] = mad; S.out[3] = nk; S.out[4] = dmean; S.out[5] = dstd; }
+    if (nk < 6.0) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { const int i = tid + e * TB; if (i < Q) resid[i] = 0.0; }
+        if (tid == 0) {
+            for (int k = 0; k < 6; ++k) S.out[10 + k] = x[k];
+            S.out[REC_STATUS] = 1.0;
+            st->stop = 1;
+        }
+        if (wid == 0) { flush_out(S, rec, REC_TICKET); publish(rec, A.seq); }
+        return;
+    }
+    const double w = (w_state > 0) ? w_state : 1.0 / (dstd * dstd);          // simpleicp.py:233-234 (frozen afterwards)
+    tk[3] = clock64();
+
+    // ---- Levenberg-Marquardt on the fused 6x6 reductions (same acceptance rules as the host solver);
+    //      one evaluation site: the first evaluation is a trial that is always accepted ----
+    int nfree = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) nfree += (A.ow[j] < __builtin_inf()) ? 1 : 0;
+    double xn[6], scn[6], rr[EPT], rrn[EPT];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { xn[j] = x[j]; scn[j] = sc[j]; }
+    int steps = 0, evals = 0, cur = 1, tries = 0;
+    bool first = true;
+    double cost = 0.0, lambda = 0.0, dxmax = 0.0;
+    long long t_eval = 0, t_step = 0;
+#pragma unroll 1
+    for (;;) {
+        long long tq = clock64();
+        eval_ne<EPT>(S, xn, scn, C, rrn, cur ^ 1); ++evals;      // (its first barrier orders it after the last one's LDS reads)
+        t_eval += clock64() - tq;
+        const double costn = objective(S.gf[wid][cur ^ 1], w, xn, A);
+        if (first || costn <= cost * (1 + 1e-12) || dxmax < 1e-15) {          // 1e-12: rounding noise of the sums
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { x[j] = xn[j]; sc[j] = scn[j]; }
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) rr[e] = rrn[e];
+            cur ^= 1; cost = costn; tries = 0;
+            if (!first) {
+                lambda = lambda > 0 ? lambda * 0.1 : 0.0;
+                if (lambda < 1e-12) lambda = 0.0;
+                ++steps;
+                double xmax = 0.0;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) xmax = fmax(xmax, fabs(x[j]));
+                if (dxmax <= 1e-13 * (1.0 + xmax)) break;
+            }
+            first = false;
+            if (steps >= A.max_steps || nfree == 0) break;
+        } else {
+            lambda = lambda > 0 ? lambda * 10 : 1e-6;
+            if (++tries >= 40) break;
+        }
+        // next trial from (x, lambda)
+        bool ok = false;
+        double dstep[6];
+#pragma unroll 1
+        for (; tries < 40; ++tries) {
+            tq = clock64();
+            ok = lm_step(S.gf[wid][cur], w, x, lambda, A, dstep);
+            t_step += clock64() - tq;
+            dxmax = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { xn[j] = x[j] + dstep[j]; dxmax = fmax(dxmax, fabs(dstep[j])); }
+            ok = ok && (dxmax < __builtin_inf());
+            if (ok) break;
+            lambda = lambda > 0 ? lambda * 10 : 1e-6;
+        }
+        if (!ok) break;
+        double xm = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) xm = fmax(xm, fabs(x[j]));
+        // the undamped Gauss-Newton step from x is below 1e-10: x is the minimiser to that accuracy (the reference stops at 1e-8)
+        if (lambda == 0.0 && dxmax <= 1e-10 * (1.0 + xm)) break;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sincos_step(xn[j], dstep[j], sc[2 * j], sc[2 * j + 1], scn[2 * j], scn[2 * j + 1]);
+    }
+    tk[4] = clock64();
+
+    // ---- residuals at the optimum (rr belongs to x: rejected trials only wrote rrn) + their mean / std ----
+    const double *G = S.gf[wid][cur];
+    const double gn = G[7 * 8 + 7];
+    const double rmean = G[6 * 8 + 7] / gn;
+    double rss[1] = {0.0};
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * TB;
+        if (i < Q) resid[i] = rr[e];
+        if (C.keep[e]) { const double t = rr[e] - rmean; rss[0] += t * t; }
+    }
+    block_sum<1>(rss, S.red[1]);
+    const double rstd = sqrt(rss[0] / gn);
+    const bool finite = cost < __builtin_inf();
+    // convergence test of simpleicp.py:356-379 on (mean, std) of this and the previous iteration's residuals
+    bool conv = false;
+    if (A.min_change >= 0.0 && done_iters > 0 && finite) {
+        const double cm = prev_mean == 0.0 ? (rmean == 0.0 ? 0.0 : __builtin_inf()) : fabs((rmean - prev_mean) / prev_mean * 100.0);
+        const double cs = prev_std == 0.0 ? (rstd == 0.0 ? 0.0 : __builtin_inf()) : fabs((rstd - prev_std) / prev_std * 100.0);
+        conv = cm < A.min_change && cs < A.min_change;
+    }
+    if (wid != 0) return;
+    // ---- wave 0: the record (pinned host memory) and the next iteration's start (device) leave as two stores ----
+    if (tid < 30) {
+        // record layout of the 30 sums: 21 upper-triangle entries of J^T J (row-major), 6 of J^T r, sum r, sum r^2, n
+        int u = 0, v = 0;
+        if (tid < 21) { int t = tid; while (t >= 6 - u) { t -= 6 - u; ++u; } v = u + t; }
+        else if (tid < 27) { u = tid - 21; v = 6; }
+        else if (tid == 27) { u = 6; v = 7; }
+        else if (tid == 28) { u = 6; v = 6; }
+        else { u = 7; v = 7; }
+        S.out[20 + tid] = G[u * 8 + v];
+    }
+    if (tid == 0) {
+        S.out[6] = w; S.out[7] = cost; S.out[8] = steps; S.out[9] = evals;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) S.out[10 + j] = x[j];
+        S.out[16] = rmean; S.out[17] = rstd;
+        S.out[REC_STATUS] = finite ? 0.0 : 2.0;
+        S.out[REC_CONVERGED] = conv ? 1.0 : 0.0;
+        tk[5] = clock64();
+        for (int k = 0; k < 5; ++k) S.out[50 + k] = (double)(tk[k + 1] - tk[k]);
+        S.out[55] = (double)(tsel - tk[1]); S.out[56] = rounds[0]; S.out[57] = (double)(tk[2] - tsel); S.out[58] = rounds[1];
+        S.out[59] = (double)t_eval; S.out[60] = (double)t_step;
+    }
+    flush_out(S, rec, REC_TICKET);
+    publish(rec, A.seq);
+    // the next iteration's start: estimate, its sin / cos, H(x) and the rigid inverse [R^T | -R^T t]
+    if (tid == 0) {
+        IcpDev n;
+        double Hn[12];
+        euler_H(x, sc, Hn);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { n.x[j] = x[j]; n.sc[j] = sc[j]; }
+#pragma unroll
+        for (int j = 0; j < 12; ++j) n.H.m[j] = Hn[j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) n.Hinv.m[4 * i + j] = Hn[4 * j + i];
+            n.Hinv.m[4 * i + 3] = -(Hn[i] * Hn[3] + Hn[4 + i] * Hn[7] + Hn[8 + i] * Hn[11]);
+        }
+        n.w = w; n.prev_mean = rmean; n.prev_std = rstd;
+        n.done_iters = done_iters + 1; n.stop = (conv || !finite) ? 1 : 0; n.pad[0] = 0; n.pad[1] = 0;
+        const double *src = reinterpret_cast<const double *>(&n);
+#pragma unroll
+        for (int j = 0; j < ST_DOUBLES; ++j) S.out[j] = src[j];
+    }
+    flush_out(S, reinterpret_cast<double *>(st), ST_DOUBLES);
+}
+
+void launch_icp_tail(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
+                     const float *planarity, const double *p2, const int64_t *idx, const TailArgs &A, IcpDev *st, double *dist,
+                     uint8_t *keep, double *resid, double *rec)
+{
+    // correspondences per lane: the register-resident copy is sized to the problem
+    if (A.Q <= TB)
+        hipLaunchKernelGGL(k_icp_tail<1>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, planarity, p2, idx, A, st, dist, keep, resid, rec);
+    else if (A.Q <= 2 * TB)
+        hipLaunchKernelGGL(k_icp_tail<2>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, planarity, p2, idx, A, st, dist, keep, resid, rec);
+    else if (A.Q <= 4 * TB)
+        hipLaunchKernelGGL(k_icp_tail<4>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, planarity, p2, idx, A, st, dist, keep, resid, rec);
+    else
+        hipLaunchKernelGGL(k_icp_tail<8>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, planarity, p2, idx, A, st, dist, keep, resid, rec);
+}
+
+}  // namespace sicp

@@ -138,4 +138,4 @@ def test_iterations_equal_oracle_at_full_size(data):
             x = np.array(R.x[:])
             assert np.abs(x - o["x"]).max() < 1e-9
         whole = c.icp_run(z, z, z, 0.3, 1.0, max_iterations=3, min_change=0.0)
-        assert np.array_equal(np.array(whole[-1].x[:]), x)
+        assert np.abs(np.array(whole[-1].x[:]) - x).max() < 1e-13

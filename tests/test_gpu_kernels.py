@@ -216,8 +216,10 @@ def test_iteration_vs_oracle(ctx, name, clouds):
 
 @pytest.mark.parametrize("name,w", [("dragon", 1.0), ("bunny", None)])
 def test_icp_run_equals_iterate_loop(ctx, name, w, clouds):
-    """sicp_icp_run (whole loop behind one call) == the same loop driven from the host through
-    sicp_icp_iterate: identical iteration count (same convergence test) and bit-identical results."""
+    """sicp_icp_run (whole loop behind one call, iterations chained on the device) == the same loop driven from the
+    host through sicp_icp_iterate: identical iteration count (same convergence test), identical correspondence
+    counts, estimates equal to rounding (the chained loop carries sin / cos of the angles forward on the device
+    with the addition theorem, the host-driven loop takes them from libm for every x it is handed)."""
     from simpleicp_amd import _lib
     g, files, kw = load_golden(name)
     Xf, Xm = clouds(files[0]), clouds(files[1])
@@ -238,8 +240,8 @@ def test_icp_run_equals_iterate_loop(ctx, name, w, clouds):
     whole = ctx.icp_run(z, z, z, 0.3, w, max_iterations=100, min_change=1.0)
     assert len(whole) == len(loop) and (w is None or len(loop) == int(g["iterations"]))
     for a, b in zip(whole, loop):
-        assert a.x[:] == b.x[:] and a.H[:] == b.H[:] and a.n_kept == b.n_kept and a.res_std == b.res_std
-        assert a.weight_used == b.weight_used
+        assert np.abs(np.array(a.x[:]) - np.array(b.x[:])).max() < 1e-13 and np.abs(np.array(a.H[:]) - np.array(b.H[:])).max() < 1e-13
+        assert a.n_kept == b.n_kept and abs(a.res_std - b.res_std) < 1e-13 and abs(a.weight_used - b.weight_used) <= 1e-12 * abs(b.weight_used)
     assert len(ctx.icp_run(z, z, z, max_iterations=3, min_change=0.0)) == 3
     assert ctx.icp_run(z, z, z, max_iterations=0) == []
 
