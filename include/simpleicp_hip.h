@@ -231,6 +231,10 @@ int sicp_timing_enable(sicp_ctx *ctx, int on);
  * (all return identical results) */
 int sicp_last_match_kernel(sicp_ctx *ctx, int *kind_out);
 int sicp_timing_reset(sicp_ctx *ctx);
+/* Work the pruned grid search did in its launches since sicp_timing_reset, counted by the kernel itself while
+ * timing is enabled: out3[0] candidates evaluated (one 32-byte record read each), out3[1] non-empty grid rows
+ * visited (two 4-byte offsets each), out3[2] launches -- the bytes the bench prices the search's roofline on. */
+int sicp_match_work(sicp_ctx *ctx, uint64_t out3[3]);
 int sicp_timing_get(sicp_ctx *ctx, int kernel, double *total_ms_out, int64_t *launches_out);
 
 #ifdef __cplusplus

@@ -26,7 +26,7 @@ EXPORTS = [
     "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_upload_columns", "sicp_cloud_size", "sicp_cloud_transform",
     "sicp_cloud_download", "sicp_cloud_set_planarity", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
-    "sicp_set_exchange", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_last_match_kernel",
+    "sicp_set_exchange", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_last_match_kernel",
     "sicp_xyz_count", "sicp_xyz_read", "sicp_xyz_write",
 ]
 
@@ -101,6 +101,7 @@ def load():
     L.sicp_lexmin_gathered.argtypes = [vp, vp, cint, i64, vp, vp, vp]
     L.sicp_timing_enable.argtypes = [vp, cint]
     L.sicp_timing_reset.argtypes = [vp]
+    L.sicp_match_work.argtypes = [vp, vp]
     L.sicp_last_match_kernel.argtypes = [vp, C.POINTER(cint)]
     L.sicp_xyz_count.argtypes = [C.c_char_p, C.POINTER(i64)]
     L.sicp_xyz_read.argtypes = [C.c_char_p, vp, i64, C.POINTER(i64), cint]
@@ -358,6 +359,12 @@ class Context:
         k = C.c_int()
         self._chk(self._L.sicp_last_match_kernel(self._h, C.byref(k)))
         return MATCH_KERNELS[k.value]
+
+    def match_work(self):
+        """Work counters of the grid search since timing_reset (kept while timing is enabled)."""
+        out = np.zeros(3, np.uint64)
+        self._chk(self._L.sicp_match_work(self._h, _ptr(out)))
+        return {"candidates": int(out[0]), "rows": int(out[1]), "launches": int(out[2])}
 
     def timing(self):
         out = {}

@@ -89,13 +89,13 @@ struct Grid {
     long ncells = 0;
     double avg_per_cell = 0;
     DevBuf<uint32_t> cell_start;     // ncells + 1
-    DevBuf<uint32_t> sidx;           // sorted position -> local row
-    DevBuf<double> sxyz;             // sx[n] | sy[n] | sz[n] in cell order
+    DevBuf<double> rec;              // the cloud in cell order: packed 32-byte records (x, y, z, local row as int64 bits)
 };
 
 struct Cloud {
     int64_t n = 0, npad = 0, idx_base = 0;
     double rmax = 0.0;    // largest point norm (error bounds of the filtered / grid searches)
+    double bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};   // bounding box (measured with rmax in the upload's one statistics pass)
     Grid grid;
     DevBuf<float> pl;     // `planarity` column by GLOBAL index (pl_n entries; 0 = the cloud has no such column)
     int64_t pl_n = 0;
@@ -206,8 +206,8 @@ struct sicp_ctx {
     long fscan_cap = 0;            // SICP_FSCAN_CAP: recorded groups per query (tests force overflow with tiny values)
     DevBuf<uint32_t> hit_cnt, hit_list;
     int knn1_mode = 0;             // SICP_KNN1 = exact | filter | grid: force one 1-NN flavour (A/B + tests); 0 = auto
-    DevBuf<uint32_t> g_keys, g_vals, g_keys2, g_counts;   // grid build scratch
-    DevBuf<unsigned char> g_tmp;
+    DevBuf<uint32_t> g_ids, g_counts, g_cursor, g_blk;    // grid build scratch: cell ids, histogram, scatter cursors, scan partials
+    DevBuf<unsigned long long> match_work;                // [0] candidates evaluated, [1] grid rows visited, [2] launches (instrumented runs)
     DevBuf<unsigned long long> rj_keys;   // large-Q rejection scratch: Q keys + the selection state
     bool have_prev_match = false;  // m_p2 holds last iteration's winners (bound source)
     int last_match_kernel = 0;     // 0 exact scan, 1 filtered scan (inline), 2 grid, 3 filtered scan (record + fix-up)
@@ -391,18 +391,10 @@ int grid_build(sicp_ctx *c, int slot)
     Grid &gr = cl.grid;
     if (gr.valid) return SICP_OK;
     const long n = cl.n;
-    unsigned long long *d_keys = (unsigned long long *)(c->small.p + 48);     // 6 u64
-    unsigned long long h_init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
-    HIPCHK(hipMemcpyAsync(d_keys, h_init, sizeof h_init, hipMemcpyHostToDevice, c->stream));
-    launch_bbox(c->stream, cl.x(), cl.y(), cl.z(), n, d_keys);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_small + 48, d_keys, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    CHK(sync(c));
-    unsigned long long hk[6]; std::memcpy(hk, c->h_small + 48, sizeof hk);
     double mn[3], ex[3], vol = 1.0; int deff = 0;
     for (int a = 0; a < 3; ++a) {
-        mn[a] = key_to_double(hk[a]);
-        ex[a] = key_to_double(hk[3 + a]) - mn[a];
+        mn[a] = cl.bb_lo[a];
+        ex[a] = cl.bb_hi[a] - cl.bb_lo[a];
         if (!(ex[a] >= 0) || !std::isfinite(ex[a])) return fail(SICP_ERR_INVALID, "cloud has non-finite coordinates");
         if (ex[a] > 0) { vol *= ex[a]; ++deff; }
     }
@@ -410,7 +402,55 @@ int grid_build(sicp_ctx *c, int slot)
     const long cap = 1L << 27;                       // dense cell array cap (512 MiB of offsets)
     double h = deff ? std::pow(vol * target / (double)n, 1.0 / deff) : 1.0;
     if (!(h > 0) || !std::isfinite(h)) h = 1.0;
-    CHK(c->g_keys.reserve(n)); CHK(c->g_vals.reserve(n)); CHK(c->g_keys2.reserve(n)); CHK(gr.sidx.reserve(n));
+    unsigned long long *d_cnt = (unsigned long long *)(c->small.p + 54);      // 2 u64
+    // Data on a surface / curve fills far fewer cells than the volume estimate assumes.  Large clouds: measure
+    // the occupancy in a small central window of the box (1/8 of every extent) at the candidate cell size and
+    // correct it -- a coalesced read of the cloud per probe instead of a full trial binning with random atomics.
+    bool probed = false;                             // the window probes settled on this h: no full-cloud occupancy check
+    if (n >= 262144 && deff > 0) {
+        const long every = 4;                        // a quarter of the cloud: cells of ~16 points still hold ~4 sampled ones
+        double wlo[3], whi[3];
+        for (int a = 0; a < 3; ++a) {
+            const double mid = mn[a] + 0.5 * ex[a], half = ex[a] > 0 ? ex[a] / 16.0 : 1.0;
+            wlo[a] = mid - half; whi[a] = mid + half;
+        }
+        double h_prev = 0, avg_prev = 0;
+        for (int probe = 0; probe < 4; ++probe) {
+            GridGeom W;
+            long wc = 1;
+            for (int a = 0; a < 3; ++a) {
+                W.mn[a] = wlo[a];
+                double d = std::floor((whi[a] - wlo[a]) / h) + 1.0;
+                if (d > 4096.0) d = 4096.0;
+                W.dim[a] = (int)d; wc *= (long)W.dim[a];
+            }
+            if (wc > (1L << 24)) break;                                   // window grid too fine to probe: keep h
+            W.h = h; W.inv_h = 1.0 / h;
+            CHK(c->g_counts.reserve((size_t)wc + 1));
+            HIPCHK(hipMemsetAsync(c->g_counts.p, 0, ((size_t)wc + 1) * sizeof(uint32_t), c->stream));
+            HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), c->stream));
+            launch_window_probe(c->stream, cl.x(), cl.y(), cl.z(), n, every, W, whi, c->g_counts.p, d_cnt);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(c->h_small + 54, d_cnt, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            CHK(sync(c));
+            unsigned long long res[2]; std::memcpy(res, c->h_small + 54, sizeof res);
+            if (res[0] < 4096 || res[1] == 0) break;                      // (nearly) empty window: no evidence, keep h
+            // points per occupied cell of the FULL cloud: the sample misses a cell of k points with probability
+            // ~exp(-k / every) -- negligible around the target
+            const double avg = (double)res[0] * (double)every / (double)res[1];
+            if (avg <= 1.5 * target && avg >= target / 1.5) { probed = true; break; }
+            // occupancy ~ h^D: D from the last two probes once there are two, the embedding dimension before
+            double D = deff;
+            if (h_prev > 0 && avg_prev > 0 && avg != avg_prev) {
+                D = std::log(avg / avg_prev) / std::log(h / h_prev);
+                if (!(D > 0.5)) D = 0.5;
+                if (D > 3.0) D = 3.0;
+            }
+            h_prev = h; avg_prev = avg;
+            h *= std::pow(target / avg, 1.0 / D);
+        }
+    }
+    CHK(c->g_ids.reserve(n));
     GridGeom G;
     long ncells = 1;
     for (int attempt = 0;; ++attempt) {
@@ -429,32 +469,27 @@ int grid_build(sicp_ctx *c, int slot)
         G.h = h; G.inv_h = 1.0 / h;
         CHK(c->g_counts.reserve((size_t)ncells + 1));
         HIPCHK(hipMemsetAsync(c->g_counts.p, 0, ((size_t)ncells + 1) * sizeof(uint32_t), c->stream));
-        launch_cell_ids(c->stream, cl.x(), cl.y(), cl.z(), n, G, c->g_keys.p, c->g_vals.p, c->g_counts.p);
-        unsigned long long *d_cnt = (unsigned long long *)(c->small.p + 54);
         HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), c->stream));
-        launch_count_nonempty(c->stream, c->g_counts.p, ncells, d_cnt);
+        launch_cell_ids(c->stream, cl.x(), cl.y(), cl.z(), n, G, c->g_ids.p, c->g_counts.p, probed ? nullptr : d_cnt);
         HIPCHK(hipGetLastError());
+        if (probed) { gr.avg_per_cell = target; break; }
         HIPCHK(hipMemcpyAsync(c->h_small + 54, d_cnt, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         CHK(sync(c));
         unsigned long long occ; std::memcpy(&occ, c->h_small + 54, sizeof occ);
         gr.avg_per_cell = (double)n / (double)std::max<unsigned long long>(occ, 1);
-        // data on a surface / curve fills far fewer cells than the volume estimate assumes: shrink
+        // still far too coarse (small clouds are not probed; windows can mislead): shrink and bin again
         if (gr.avg_per_cell > 3 * target && attempt < 4 && ncells < cap / 2) { h *= std::sqrt(target / gr.avg_per_cell); continue; }
         break;
     }
     gr.g = G; gr.ncells = ncells;
-    // offsets = exclusive scan of the histogram (entry ncells = n)
+    // offsets = exclusive scan of the histogram (entry ncells = n), then the counting-sort scatter writes every
+    // point once, as a packed record, into its cell's range
     CHK(gr.cell_start.reserve((size_t)ncells + 1));
-    int bits = 1; while ((1L << bits) < ncells && bits < 32) ++bits;
-    const size_t tmp_bytes = std::max(grid_scan_temp_bytes(ncells + 1), grid_sort_temp_bytes(n, bits));
-    CHK(c->g_tmp.reserve(tmp_bytes + 256));
-    if (grid_scan(c->stream, c->g_tmp.p, tmp_bytes, c->g_counts.p, gr.cell_start.p, ncells + 1) != hipSuccess)
-        return fail(SICP_ERR_HIP, "grid: exclusive scan failed");
-    // stable sort by cell id: rows of a cell stay in ascending original order
-    if (grid_sort(c->stream, c->g_tmp.p, tmp_bytes, c->g_keys.p, c->g_keys2.p, c->g_vals.p, gr.sidx.p, n, bits) != hipSuccess)
-        return fail(SICP_ERR_HIP, "grid: radix sort failed");
-    CHK(gr.sxyz.reserve((size_t)3 * n));
-    launch_gather_sorted(c->stream, cl.x(), cl.y(), cl.z(), gr.sidx.p, n, gr.sxyz.p, gr.sxyz.p + n, gr.sxyz.p + 2 * n);
+    CHK(c->g_cursor.reserve((size_t)ncells + 1));
+    CHK(c->g_blk.reserve((size_t)grid_scan_blocks(ncells) + 1));
+    CHK(gr.rec.reserve((size_t)4 * n));
+    launch_grid_scan(c->stream, c->g_counts.p, ncells, c->g_blk.p, gr.cell_start.p, c->g_cursor.p);
+    launch_scatter(c->stream, cl.x(), cl.y(), cl.z(), c->g_ids.p, n, c->g_cursor.p, gr.rec.p);
     HIPCHK(hipGetLastError());
     CHK(sync(c));
     gr.valid = true;
@@ -528,9 +563,9 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
         c->last_match_kernel = 2;
         {
             Timed t(c, SICP_K_KNN1);
-            launch_grid_nn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, prev_p2, gr.g, gr.cell_start.p, gr.sxyz.p,
-                           gr.sxyz.p + cl.n, gr.sxyz.p + 2 * cl.n, gr.sidx.p, H, H ? &Hinv : nullptr, cl.rmax, max_d2,
-                           cl.idx_base, d2_out, idx_out, p2_out);
+            launch_grid_nn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, prev_p2, gr.g, gr.cell_start.p, gr.rec.p, H,
+                           H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out, p2_out,
+                           c->timing ? c->match_work.p : nullptr);
         }
         HIPCHK(hipGetLastError());
         return SICP_OK;
@@ -632,8 +667,8 @@ int knnk_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, in
         Grid &gr = cl.grid;
         {
             Timed t(c, SICP_K_KNNK);
-            launch_grid_knn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, k, gr.g, gr.cell_start.p, gr.sxyz.p,
-                            gr.sxyz.p + cl.n, gr.sxyz.p + 2 * cl.n, gr.sidx.p, cl.rmax, cl.idx_base, d2_out, idx_out);
+            launch_grid_knn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, k, gr.g, gr.cell_start.p, gr.rec.p, cl.rmax,
+                            cl.idx_base, d2_out, idx_out);
         }
         HIPCHK(hipGetLastError());
         return SICP_OK;
@@ -749,6 +784,8 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (rc == SICP_OK) rc = c->ne_partial.reserve((size_t)NE_MAX_GRID * 32);
     if (rc == SICP_OK) rc = c->ticket.reserve(4);
     if (rc == SICP_OK) rc = c->icp_dev.reserve(1);
+    if (rc == SICP_OK) rc = c->match_work.reserve(4);
+    if (rc == SICP_OK && hipMemsetAsync(c->match_work.p, 0, 4 * sizeof(unsigned long long), c->stream) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc == SICP_OK && hipHostMalloc((void **)&c->h_rec, (size_t)REC_RING * REC_DOUBLES * sizeof(double), hipHostMallocMapped) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc == SICP_OK && hipHostMalloc((void **)&c->h_state, sizeof(IcpDev), hipHostMallocDefault) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc == SICP_OK) std::memset(c->h_rec, 0, (size_t)REC_RING * REC_DOUBLES * sizeof(double));
@@ -774,8 +811,8 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    for (auto &cl : c->cloud) { cl.xyz.release(); cl.pl.release(); cl.grid.cell_start.release(); cl.grid.sidx.release(); cl.grid.sxyz.release(); }
-    c->g_keys.release(); c->g_vals.release(); c->g_keys2.release(); c->g_counts.release(); c->g_tmp.release(); c->rj_keys.release();
+    for (auto &cl : c->cloud) { cl.xyz.release(); cl.pl.release(); cl.grid.cell_start.release(); cl.grid.rec.release(); }
+    c->g_ids.release(); c->g_counts.release(); c->g_cursor.release(); c->g_blk.release(); c->match_work.release(); c->rj_keys.release();
     c->stage.release(); c->part_d2.release(); c->part_idx.release(); c->kq.release(); c->k_d2.release();
     c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->hit_cnt.release(); c->hit_list.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
@@ -813,24 +850,30 @@ int upload_begin(sicp_ctx *c, int slot, int64_t n, int64_t index_base)
     return SICP_OK;
 }
 
-// ... and finishes: largest norm, for the filtered scan's rounding-error bound
-int upload_end(sicp_ctx *c, int slot)
+// ... and finishes: ONE statistics pass gives the largest norm (rounding-error bounds of the filtered / grid searches;
+// a non-finite cloud is refused like cKDTree would) and the bounding box the grid build starts from
+int cloud_stats(sicp_ctx *c, int slot)
 {
     Cloud &cl = c->cloud[slot];
-    unsigned long long *d_bits = (unsigned long long *)(c->small.p + 40);
-    HIPCHK(hipMemsetAsync(d_bits, 0, sizeof(unsigned long long), c->stream));
-    launch_max_norm2(c->stream, cl.x(), cl.y(), cl.z(), cl.n, d_bits);
+    unsigned long long *d_st = (unsigned long long *)(c->small.p + 40);       // 7 u64
+    unsigned long long h_init[7] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull, 0ull};
+    HIPCHK(hipMemcpyAsync(d_st, h_init, sizeof h_init, hipMemcpyHostToDevice, c->stream));
+    launch_cloud_stats(c->stream, cl.x(), cl.y(), cl.z(), cl.n, d_st);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_small + 40, d_bits, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_small + 40, d_st, 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     CHK(sync(c));
-    if (!std::isfinite(c->h_small[40])) {
+    unsigned long long hk[7]; std::memcpy(hk, c->h_small + 40, sizeof hk);
+    double nn; std::memcpy(&nn, &hk[6], sizeof nn);
+    if (!std::isfinite(nn)) {
         cl.n = 0;                                    // like cKDTree (pointcloud.py:161,185): no search structure over NaN / inf
         return fail(SICP_ERR_INVALID, "cloud has non-finite coordinates (NaN / inf, or |p|^2 overflows a double)");
     }
-    cl.rmax = std::sqrt(c->h_small[40]) * (1.0 + 1e-12);
+    cl.rmax = std::sqrt(nn) * (1.0 + 1e-12);
+    for (int a = 0; a < 3; ++a) { cl.bb_lo[a] = key_to_double(hk[a]); cl.bb_hi[a] = key_to_double(hk[3 + a]); }
     if (slot == SICP_MOV) c->have_prev_match = false;
     return SICP_OK;
 }
+int upload_end(sicp_ctx *c, int slot) { return cloud_stats(c, slot); }
 }  // namespace
 
 SICP_EXPORT int sicp_cloud_upload(sicp_ctx *c, int slot, const double *xyz, int64_t n, int64_t index_base)
@@ -878,9 +921,7 @@ SICP_EXPORT int sicp_cloud_transform(sicp_ctx *c, int slot, const double H[16])
     launch_transform(c->stream, cl.x(), cl.y(), cl.z(), cl.n, X);
     HIPCHK(hipGetLastError());
     cl.grid.valid = false;
-    cl.rmax = (smax3(X) * cl.rmax + std::sqrt(X.m[3] * X.m[3] + X.m[7] * X.m[7] + X.m[11] * X.m[11])) * (1.0 + 1e-9);
-    if (slot == SICP_MOV) c->have_prev_match = false;
-    return sync(c);
+    return cloud_stats(c, slot);                          // new bounding box / largest norm (also the synchronisation point)
 }
 
 SICP_EXPORT int sicp_cloud_set_planarity(sicp_ctx *c, int slot, const int64_t *rows, const float *planarity, int64_t m,
@@ -1140,8 +1181,8 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 c->last_match_kernel = 2;
                 Timed t(c, SICP_K_KNN1);
                 launch_grid_nn_chained(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, Q, prev, cl.grid.g,
-                                       cl.grid.cell_start.p, cl.grid.sxyz.p, cl.grid.sxyz.p + cl.n, cl.grid.sxyz.p + 2 * cl.n,
-                                       cl.grid.sidx.p, c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p, c->m_idx.p, c->m_p2.p);
+                                       cl.grid.cell_start.p, cl.grid.rec.p, c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p,
+                                       c->m_idx.p, c->m_p2.p, c->timing ? c->match_work.p : nullptr);
             } else {
                 // brute-force flavours take H by value: one iteration in flight, H from the last record
                 params_to_H12(xcur, H12);
@@ -1479,10 +1520,18 @@ SICP_EXPORT int sicp_last_match_kernel(sicp_ctx *c, int *kind_out)
     *kind_out = c->last_match_kernel;
     return SICP_OK;
 }
+SICP_EXPORT int sicp_match_work(sicp_ctx *c, uint64_t out3[3])
+{
+    if (!c || !out3) return fail(SICP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(out3, c->match_work.p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    return sync(c);
+}
 SICP_EXPORT int sicp_timing_reset(sicp_ctx *c)
 {
     if (!c) return fail(SICP_ERR_INVALID, "null ctx");
     if (!c->pending.empty()) CHK(sync(c));
+    HIPCHK(hipMemsetAsync(c->match_work.p, 0, 4 * sizeof(unsigned long long), c->stream));
     for (int i = 0; i < SICP_K_COUNT; ++i) { c->t_ms[i] = 0; c->t_n[i] = 0; }
     return SICP_OK;
 }

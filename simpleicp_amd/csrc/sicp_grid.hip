@@ -1,20 +1,24 @@
-// sicp_grid.hip -- pruned EXACT 1-NN on a static uniform grid.
+// sicp_grid.hip -- pruned EXACT 1-NN / k-NN on a static uniform grid.
 //
 // The searched (movable) cloud never moves in its own frame, so it is binned ONCE per upload:
-// cell id per point -> stable radix sort (hipCUB; a library primitive used only in this one-off
-// build) -> cell offsets by histogram + exclusive scan -> coordinates gathered into cell order.
-// Per iteration each query is pulled back into the cloud's frame with the rigid inverse of H and
-// ONE WAVE enumerates the cells that intersect a ball around it; every candidate is evaluated with
-// the exact arithmetic contract (T)+(D) from its original coordinates and compared
-// lexicographically on (d2, original index).  The ball radius comes from an exact upper bound of
-// the answer (previous iteration's match re-evaluated under the new H) or from an expanding search;
-// termination needs best <= radius minus a slack that covers the rounding of H^-1 q and the
-// non-orthogonality of the floating-point R, so the result equals the brute-force scan's, bit for
-// bit (tests compare the two on full-size inputs).  The reference instead rebuilds a cKDTree on
-// the transformed cloud every iteration (corrpts.py:131, simpleicp.py:188-202).
+//   k_cloud_stats   bounding box + largest norm in one pass (one atomic per block and quantity)
+//   cell size       from the bounding volume and, for surfaces / curves, from two histograms of a strided SAMPLE
+//                   (occupancy at h and h/2 gives the data's box-counting dimension: no full-cloud trial pass)
+//   k_cell_ids      cell id per point + histogram              (the only pass with random atomics)
+//   scan            exclusive prefix sum of the histogram = cell offsets (three small kernels, no library)
+//   k_scatter       counting-sort scatter: every point is written ONCE, as a packed 32-byte record
+//                   (x, y, z, original index), into its cell's range
+// Per iteration each query is pulled back into the cloud's frame with the rigid inverse of H and ONE WAVE
+// enumerates the cell rows that intersect a ball around it; every candidate is evaluated with the exact
+// arithmetic contract (T)+(D) from its original coordinates and compared lexicographically on (d2, original
+// index) -- so the order of the points inside a cell does not matter.  The ball radius comes from an exact upper
+// bound of the answer (previous iteration's match re-evaluated under the new H) or from an expanding search;
+// termination needs best <= radius minus a slack that covers the rounding of H^-1 q and the non-orthogonality of
+// the floating-point R, so the result equals the brute-force scan's, bit for bit (tests compare the two on
+// full-size inputs).  The reference instead rebuilds a cKDTree on the transformed cloud every iteration
+// (corrpts.py:131, simpleicp.py:188-202).
 #include <hip/hip_runtime.h>
 #include <algorithm>
-#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
 #include "sicp_internal.h"
@@ -30,25 +34,65 @@ __device__ __forceinline__ unsigned long long okey(double v)
     return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
 }
 
-// out[0..2] = min keys, out[3..5] = max keys (ordered-uint64 image of the doubles)
-__global__ void k_bbox(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z, long n,
-                       unsigned long long *__restrict__ out)
+__device__ __forceinline__ double wmin_d(double v)
 {
+    v = fmin(v, lane_xor_f64<32>(v)); v = fmin(v, lane_xor_f64<16>(v)); v = fmin(v, lane_xor_f64<8>(v));
+    v = fmin(v, lane_xor_f64<4>(v));  v = fmin(v, lane_xor_f64<2>(v));  v = fmin(v, lane_xor_f64<1>(v));
+    return v;
+}
+
+// One pass over a cloud: out[0..2] = min keys, out[3..5] = max keys (ordered-uint64 image of the doubles),
+// out[6] = bits of the largest squared norm (a NaN sticks: the upload rejects non-finite clouds).
+// Wave reductions are register moves, the block folds in LDS: 7 atomics per BLOCK.
+__global__ __launch_bounds__(256) void k_cloud_stats(const double *__restrict__ x, const double *__restrict__ y,
+                                                     const double *__restrict__ z, long n, unsigned long long *__restrict__ out)
+{
+    __shared__ double red[4][8];
     double lo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
-    double hi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const double v[3] = {x[i], y[i], z[i]};
+    double nh[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};      // minus the maxima
+    double m = 0.0;
+    bool bad = false;
+    // four points per lane and step: twelve independent loads in flight (a plain grid-stride loop is latency-bound)
+    const long stride = (long)gridDim.x * 1024;
+    for (long base = (long)blockIdx.x * 1024 + threadIdx.x; base < n; base += stride) {
+        double v[4][3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { lo[a] = v[a] < lo[a] ? v[a] : lo[a]; hi[a] = v[a] > hi[a] ? v[a] : hi[a]; }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double l = __shfl_down(lo[a], off, 64), h = __shfl_down(hi[a], off, 64);
-            lo[a] = l < lo[a] ? l : lo[a]; hi[a] = h > hi[a] ? h : hi[a];
+        for (int u = 0; u < 4; ++u) {
+            const long i = base + 256 * u;
+            const long ic = i < n ? i : n - 1;                // clamped: a repeated point changes no statistic
+            v[u][0] = x[ic]; v[u][1] = y[ic]; v[u][2] = z[ic];
         }
-        if ((threadIdx.x & 63) == 0) { atomicMin(out + a, okey(lo[a])); atomicMax(out + 3 + a, okey(hi[a])); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], v[u][a]); nh[a] = fmin(nh[a], -v[u][a]); }
+            const double nn = fma(v[u][2], v[u][2], fma(v[u][1], v[u][1], v[u][0] * v[u][0]));
+            bad = bad || !(nn < __builtin_inf());             // NaN or inf
+            m = fmax(m, nn);
+        }
+    }
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = wmin_d(lo[a]); nh[a] = wmin_d(nh[a]); }
+    m = -wmin_d(-m);
+    const bool anybad = __ballot(bad) != 0ull;
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { red[wid][a] = lo[a]; red[wid][3 + a] = nh[a]; }
+        red[wid][6] = m; red[wid][7] = anybad ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int a = threadIdx.x;
+        if (a < 6) {
+            const double v = fmin(fmin(red[0][a], red[1][a]), fmin(red[2][a], red[3][a]));
+            if (a < 3) atomicMin(out + a, okey(v)); else atomicMax(out + a, okey(-v));
+        } else {
+            double v = fmax(fmax(red[0][6], red[1][6]), fmax(red[2][6], red[3][6]));
+            if (red[0][7] + red[1][7] + red[2][7] + red[3][7] > 0.0) v = __builtin_nan("");
+            // non-negative doubles order like their bit patterns; a NaN's pattern is above every finite one
+            atomicMax(out + 6, (unsigned long long)__double_as_longlong(v));
+        }
     }
 }
 
@@ -57,40 +101,139 @@ __device__ __forceinline__ int cell_coord(double v, double mn, double inv_h, int
     int c = (int)floor((v - mn) * inv_h);
     return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
 }
-
-__global__ void k_cell_ids(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
-                           long n, GridGeom G, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                           uint32_t *__restrict__ counts)
+__device__ __forceinline__ uint32_t cell_of(const GridGeom &G, double x, double y, double z)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int cx = cell_coord(x[i], G.mn[0], G.inv_h, G.dim[0]);
-    const int cy = cell_coord(y[i], G.mn[1], G.inv_h, G.dim[1]);
-    const int cz = cell_coord(z[i], G.mn[2], G.inv_h, G.dim[2]);
-    const uint32_t id = ((uint32_t)cz * G.dim[1] + cy) * G.dim[0] + cx;
-    keys[i] = id; vals[i] = (uint32_t)i;
-    atomicAdd(counts + id, 1u);
+    const int cx = cell_coord(x, G.mn[0], G.inv_h, G.dim[0]);
+    const int cy = cell_coord(y, G.mn[1], G.inv_h, G.dim[1]);
+    const int cz = cell_coord(z, G.mn[2], G.inv_h, G.dim[2]);
+    return ((uint32_t)cz * G.dim[1] + cy) * G.dim[0] + cx;
 }
 
-__global__ void k_gather_sorted(const double *__restrict__ x, const double *__restrict__ y,
-                                const double *__restrict__ z, const uint32_t *__restrict__ sidx, long n,
-                                double *__restrict__ sx, double *__restrict__ sy, double *__restrict__ sz)
+// cell id of every point + histogram; OCC: also count the cells that receive their first point (needs the
+// returning flavour of the atomic: only small clouds, whose cell size no probe has checked, ask for it)
+template <bool OCC>
+__global__ __launch_bounds__(256) void k_cell_ids(const double *__restrict__ x, const double *__restrict__ y,
+                                                  const double *__restrict__ z, long n, GridGeom G,
+                                                  uint32_t *__restrict__ ids, uint32_t *__restrict__ counts,
+                                                  unsigned long long *__restrict__ occupied)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t s = sidx[i];
-    sx[i] = x[s]; sy[i] = y[s]; sz[i] = z[s];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    bool first = false;
+    if (i < n) {
+        const uint32_t id = cell_of(G, x[i], y[i], z[i]);
+        ids[i] = id;
+        if (OCC) first = atomicAdd(counts + id, 1u) == 0u;
+        else atomicAdd(counts + id, 1u);
+    }
+    if (OCC) {
+        const unsigned long long b = __ballot(first);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(occupied, (unsigned long long)__popcll((long long)b));
+    }
 }
 
-// number of non-empty cells (to judge the cell size)
-__global__ void k_count_nonempty(const uint32_t *__restrict__ counts, long ncells, unsigned long long *out)
+// Occupancy probe for the cell-size choice: histogram of the points of a SAMPLE (every `every`-th 1024-point chunk of
+// the cloud: coalesced, a fraction of the traffic) that fall inside a small window of the bounding box (G describes
+// the window's own grid); out[0] += sampled points inside, out[1] += cells that got a first point
+__global__ __launch_bounds__(256) void k_window_probe(const double *__restrict__ x, const double *__restrict__ y,
+                                                      const double *__restrict__ z, long n, long every, GridGeom G, double wx,
+                                                      double wy, double wz, uint32_t *__restrict__ counts,
+                                                      unsigned long long *__restrict__ out)
 {
-    unsigned long long c = 0;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ncells; i += (long)gridDim.x * blockDim.x)
-        c += counts[i] ? 1 : 0;
+    __shared__ unsigned long long part[4][2];
+    unsigned long long inside = 0, firsts = 0;
+    const long chunks = (n + 1023) / 1024;
+    for (long ch = (long)blockIdx.x * every; ch < chunks; ch += (long)gridDim.x * every) {
+        const long base = ch * 1024 + threadIdx.x;
+        double v[4][3];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+        for (int u = 0; u < 4; ++u) {
+            const long i = base + 256 * u;
+            const long ic = i < n ? i : n - 1;
+            v[u][0] = x[ic]; v[u][1] = y[ic]; v[u][2] = z[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double px = v[u][0], py = v[u][1], pz = v[u][2];
+            const bool in = base + 256 * u < n && px >= G.mn[0] && px < wx && py >= G.mn[1] && py < wy && pz >= G.mn[2] && pz < wz;
+            if (in) { inside += 1; firsts += atomicAdd(counts + cell_of(G, px, py, pz), 1u) == 0u ? 1 : 0; }
+        }
+    }
+    inside = wsum_u64(inside); firsts = wsum_u64(firsts);
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = inside; part[threadIdx.x >> 6][1] = firsts; }
+    __syncthreads();
+    if (threadIdx.x < 2) {                     // one atomic per block and counter
+        const unsigned long long t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (t) atomicAdd(out + threadIdx.x, t);
+    }
+}
+
+// ---- exclusive prefix sum of the histogram (cell offsets), three launches, no library --------------------------
+constexpr int SCAN_ITEMS = 2048;            // per block: 256 lanes x 8
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *total)      // 256 lanes; returns the lane's exclusive prefix
+{
+    __shared__ unsigned wsum4[4];
+    const unsigned incl = wscan_u32(v);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 63) wsum4[wid] = incl;
+    __syncthreads();
+    unsigned before = 0;
+    for (int w = 0; w < wid; ++w) before += wsum4[w];
+    *total = wsum4[0] + wsum4[1] + wsum4[2] + wsum4[3];
+    return before + incl - v;
+}
+__global__ __launch_bounds__(256) void k_scan_sums(const uint32_t *__restrict__ in, long n, uint32_t *__restrict__ block_sum)
+{
+    const long base = (long)blockIdx.x * SCAN_ITEMS + (long)threadIdx.x * 8;
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (base + k < n) s += in[base + k];
+    unsigned total;
+    (void)block_excl_scan(s, &total);
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void k_scan_blocks(uint32_t *__restrict__ block_sum, long nblocks)      // ONE workgroup, in place -> exclusive
+{
+    __shared__ unsigned carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (long base = 0; base < nblocks; base += 256) {
+        const long i = base + threadIdx.x;
+        const unsigned v = i < nblocks ? block_sum[i] : 0u;
+        unsigned total;
+        const unsigned ex = block_excl_scan(v, &total);
+        const unsigned carry = carry_s;
+        if (i < nblocks) block_sum[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+}
+// out[i] = sum of in[0..i) for i in [0, n]  (entry n = the grand total); cursor (nullable) receives a copy
+__global__ __launch_bounds__(256) void k_scan_final(const uint32_t *__restrict__ in, long n, const uint32_t *__restrict__ block_off,
+                                                    uint32_t *__restrict__ out, uint32_t *__restrict__ cursor)
+{
+    const long base = (long)blockIdx.x * SCAN_ITEMS + (long)threadIdx.x * 8;
+    unsigned v[8], s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = base + k < n ? in[base + k] : 0u; s += v[k]; }
+    unsigned total;
+    unsigned run = block_off[blockIdx.x] + block_excl_scan(s, &total);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (base + k <= n) { out[base + k] = run; if (cursor && base + k < n) cursor[base + k] = run; }
+        run += v[k];
+    }
+}
+
+// counting-sort scatter: point i goes to the next free slot of its cell as a packed record (x, y, z, index bits)
+__global__ __launch_bounds__(256) void k_scatter(const double *__restrict__ x, const double *__restrict__ y,
+                                                 const double *__restrict__ z, const uint32_t *__restrict__ ids, long n,
+                                                 uint32_t *__restrict__ cursor, double4 *__restrict__ rec)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pos = atomicAdd(cursor + ids[i], 1u);
+    rec[pos] = make_double4(x[i], y[i], z[i], __longlong_as_double((long long)i));
 }
 
 // ------------------------------------------------------------------------------------
@@ -107,21 +250,27 @@ __device__ __forceinline__ void xf(const Xf &H, double x, double y, double z, do
 // CHAINED: the launch belongs to a run whose iterations are enqueued back to back -- H and its inverse come from
 // the device-resident loop state the previous tail launch left (sicp_tail.hip), and the launch exits at once
 // when that tail declared the run over.
+//
+// Search of one pass: lane r of the wave fetches row r's contiguous point range (the cells of one (cy, cz) row are
+// contiguous in the cell order); the non-empty rows are then visited FOUR AT A TIME -- their ranges are broadcast
+// with v_readlane (uniform row index: no LDS crossbar), lane l takes point l of each row, and the four 32-byte
+// record loads are in flight together.  A pass costs two dependent memory round trips (offsets, records).
 template <bool XFORM, bool CHAINED>
 __global__ __launch_bounds__(256) void k_grid_nn(
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, long Q,
     const double *__restrict__ prev_p2 /* nullable: (Q,3) a cloud point per query (last match) -> its exact
-                                          distance under H bounds the answer; saves the expanding search */,
-    GridGeom G, const uint32_t *__restrict__ cell_start, const double *__restrict__ sx,
-    const double *__restrict__ sy, const double *__restrict__ sz, const uint32_t *__restrict__ sidx,
+                                          distance under H bounds the answer */,
+    GridGeom G, const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
     Xf H, Xf Hinv, double rmax, double max_d2, int64_t idx_base,
     double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
-    const IcpDev *__restrict__ st)
+    const IcpDev *__restrict__ st, unsigned long long *__restrict__ work /* nullable: [0] candidates, [1] rows, [2] launches */)
 {
     const int lane = threadIdx.x & 63;
     const long q = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (q >= Q) return;                                   // whole wave leaves together
     const double ax = qx[q], ay = qy[q], az = qz[q];      // (issued before the loop state is waited for)
+    double px0 = 0, py0 = 0, pz0 = 0;
+    if (prev_p2) { px0 = prev_p2[3 * q]; py0 = prev_p2[3 * q + 1]; pz0 = prev_p2[3 * q + 2]; }
     if (CHAINED) {
         H = st->H; Hinv = st->Hinv;
         if (st->stop) return;
@@ -132,20 +281,26 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     // ~1e-15 * scale; 1e-12 * scale leaves three orders of magnitude
     const double scale = rmax + sqrt(fma(czq, czq, fma(cyq, cyq, cxq * cxq))) + 1.0;
     const double slack = 1e-12 * scale;
-    const double r_cap = (max_d2 < __builtin_inf()) ? sqrt(max_d2) * (1.0 + 1e-12) + slack : __builtin_inf();
-    double bnd = __builtin_inf();
+    double r_lim = (max_d2 < __builtin_inf()) ? sqrt(max_d2) * (1.0 + 1e-12) + slack : __builtin_inf();
+    bool lim_is_bound = false;                            // r_lim is the distance to a cloud point: that ball is never empty
     if (prev_p2) {
-        double X = prev_p2[3 * q], Y = prev_p2[3 * q + 1], Z = prev_p2[3 * q + 2];
+        double X = px0, Y = py0, Z = pz0;
         if (XFORM) { double u, v, w; xf(H, X, Y, Z, u, v, w); X = u; Y = v; Z = w; }
         const double dx = X - ax, dy = Y - ay, dz = Z - az;
-        bnd = fma(dz, dz, fma(dy, dy, dx * dx));
+        const double bnd = fma(dz, dz, fma(dy, dy, dx * dx));
+        if (bnd < __builtin_inf()) {
+            const double rb = sqrt(bnd) * (1.0 + 1e-12) + slack;
+            if (rb < r_lim) { r_lim = rb; lim_is_bound = true; }
+        }
     }
-    const bool has_bound = bnd < __builtin_inf();
-    double r = has_bound ? sqrt(bnd) * (1.0 + 1e-12) + slack : 0.5 * G.h;
-    if (r > r_cap) r = r_cap;
+    // a bound that spans many cells (first iterations: the estimate still moves by metres) is not searched in one
+    // go: start small and let the first hit shrink the ball
+    double r = 0.75 * G.h;
+    if (r > r_lim) r = r_lim;
 
-    double best = __builtin_inf();
-    uint32_t bidx = 0xffffffffu, bpos = 0;
+    double best = __builtin_inf(), bx = 0, by = 0, bz = 0;
+    uint32_t bidx = 0xffffffffu;
+    unsigned long long n_cand = 0, n_rows = 0;
     for (int pass = 0; pass < 64; ++pass) {
         int lo[3], hi[3];
         const double c3[3] = {cxq, cyq, czq};
@@ -159,12 +314,9 @@ __global__ __launch_bounds__(256) void k_grid_nn(
             // whole axis covered <=> the ball reaches past both faces of the box
             all = all && (fl <= 0.0) && (fh >= (double)(G.dim[a] - 1));
         }
-        best = __builtin_inf(); bidx = 0xffffffffu; bpos = 0;
+        best = __builtin_inf(); bidx = 0xffffffffu;
         const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
         const long nrows = (long)ny * nz;
-        // cells of one (cy, cz) row are contiguous in the sorted order: lane r fetches row r's point
-        // range, a wave scan turns up to 64 ranges into one flat candidate list, and the lanes stride
-        // over it -- two dependent memory round trips per batch instead of two per row
         for (long rb = 0; rb < nrows; rb += 64) {
             uint32_t b = 0, len = 0;
             if (rb + lane < nrows) {
@@ -174,69 +326,81 @@ __global__ __launch_bounds__(256) void k_grid_nn(
                 b = cell_start[row + lo[0]];
                 len = cell_start[row + hi[0] + 1] - b;
             }
-            const uint32_t incl = wscan_u32(len);
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            // four flat candidates per lane per round: their (row, offset) searches and coordinate loads
-            // are independent, so four memory round trips overlap (wave-uniform trip count: the
-            // shuffles need all lanes)
-            for (uint32_t base = 0; base < total; base += 256) {
-                uint32_t pos[4]; bool ok[4];
+            unsigned long long todo = __ballot(len > 0);          // rows of this batch that hold points
+            if (work) { n_rows += (unsigned long long)__popcll((long long)todo); }
+            while (todo) {
+                // up to four rows per step: ranges by register broadcast, one record per lane and row
+                uint32_t rbv[4], rlv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const uint32_t k = base + 64 * u + lane;
-                    int r0 = 0;                                 // first row whose inclusive offset exceeds k
-#pragma unroll
-                    for (int step = 32; step > 0; step >>= 1) {
-                        const uint32_t v = __shfl(incl, r0 + step - 1, 64);
-                        if (v <= k) r0 += step;
+                    rbv[u] = 0; rlv[u] = 0;
+                    if (todo) {
+                        const int j = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1ull;
+                        rbv[u] = (uint32_t)__builtin_amdgcn_readlane((int)b, j);
+                        rlv[u] = (uint32_t)__builtin_amdgcn_readlane((int)len, j);
                     }
-                    r0 = r0 > 63 ? 63 : r0;
-                    const uint32_t rbeg = __shfl(b, r0, 64), ri = __shfl(incl, r0, 64), rl = __shfl(len, r0, 64);
-                    ok[u] = k < total;
-                    pos[u] = ok[u] ? rbeg + (k - (ri - rl)) : 0u;
                 }
-                double X[4], Y[4], Z[4];
+                uint32_t longest = rlv[0] > rlv[1] ? rlv[0] : rlv[1];
+                { const uint32_t t2 = rlv[2] > rlv[3] ? rlv[2] : rlv[3]; longest = longest > t2 ? longest : t2; }
+                for (uint32_t o = 0; o < longest; o += 64) {              // (rows longer than a wave: dense cells, duplicates)
+                    double4 P[4];
+                    bool ok[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { X[u] = sx[pos[u]]; Y[u] = sy[pos[u]]; Z[u] = sz[pos[u]]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (!ok[u]) continue;
-                    double px = X[u], py = Y[u], pz = Z[u];
-                    if (XFORM) { double a, bq, cq; xf(H, px, py, pz, a, bq, cq); px = a; py = bq; pz = cq; }
-                    const double dx = px - ax, dy = py - ay, dz = pz - az;
-                    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
-                    if (d2 <= best) {
-                        const uint32_t oi = sidx[pos[u]];
-                        if (d2 < best || oi < bidx) { best = d2; bidx = oi; bpos = pos[u]; }
+                    for (int u = 0; u < 4; ++u) {
+                        ok[u] = o + (uint32_t)lane < rlv[u];
+                        P[u] = rec[ok[u] ? rbv[u] + o + (uint32_t)lane : 0u];
                     }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (!ok[u]) continue;
+                        double X = P[u].x, Y = P[u].y, Z = P[u].z;
+                        if (XFORM) { double a2, b2, c2; xf(H, X, Y, Z, a2, b2, c2); X = a2; Y = b2; Z = c2; }
+                        const double dx = X - ax, dy = Y - ay, dz = Z - az;
+                        const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                        const uint32_t oi = (uint32_t)__double_as_longlong(P[u].w);
+                        if (d2 < best || (d2 == best && oi < bidx)) { best = d2; bidx = oi; bx = P[u].x; by = P[u].y; bz = P[u].z; }
+                    }
+                    if (work) { for (int u = 0; u < 4; ++u) n_cand += (unsigned long long)__popcll((long long)__ballot(ok[u])); }
                 }
             }
         }
-        // wave-wide lexicographic (d2, original index) minimum: DPP butterfly, every lane ends up with it
+        // wave-wide lexicographic (d2, original index) minimum: DPP butterfly, every lane ends up with it;
+        // the lane that found it keeps the coordinates
+        const double lbest = best; const uint32_t lidx = bidx;
 #define SICP_LEXMIN_STEP(J)                                                                       \
         {                                                                                         \
             const double od = lane_xor_f64<J>(best);                                              \
-            const uint32_t oi = lane_xor32<J>(bidx), op = lane_xor32<J>(bpos);                    \
-            if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; bpos = op; }      \
+            const uint32_t oi = lane_xor32<J>(bidx);                                              \
+            if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; }                 \
         }
         SICP_LEXMIN_STEP(32) SICP_LEXMIN_STEP(16) SICP_LEXMIN_STEP(8) SICP_LEXMIN_STEP(4) SICP_LEXMIN_STEP(2) SICP_LEXMIN_STEP(1)
 #undef SICP_LEXMIN_STEP
         const bool found = bidx != 0xffffffffu;
+        const bool winner = found && lbest == best && lidx == bidx;         // exactly one lane (indices are unique)
         const double r_eff = (r - slack) / (1.0 + 1e-12);
-        if (found && sqrt(best) <= r_eff) break;          // nothing outside the ball can beat or tie it
-        if (all || r >= r_cap || has_bound) break;        // searched everything that may qualify
-        r = found ? sqrt(best) * (1.0 + 1e-12) + slack : 2.0 * r;
-        if (r > r_cap) r = r_cap;
-    }
-    if (lane == 0) {
-        const bool ok = (bidx != 0xffffffffu) && (best < max_d2);
-        d2_out[q] = ok ? best : __builtin_inf();
-        idx_out[q] = ok ? idx_base + (int64_t)bidx : (int64_t)-1;
-        if (p2_out) {
-            p2_out[3 * q]     = ok ? sx[bpos] : 0.0;
-            p2_out[3 * q + 1] = ok ? sy[bpos] : 0.0;
-            p2_out[3 * q + 2] = ok ? sz[bpos] : 0.0;
+        const bool done = (found && sqrt(best) <= r_eff)      // nothing outside the ball can beat or tie it
+                          || all || r >= r_lim;               // searched everything that may qualify
+        if (done) {
+            const bool ok = found && (best < max_d2);
+            if (winner || (!found && lane == 0)) {
+                d2_out[q] = ok ? best : __builtin_inf();
+                idx_out[q] = ok ? idx_base + (int64_t)bidx : (int64_t)-1;
+                if (p2_out) {
+                    p2_out[3 * q]     = ok ? bx : 0.0;
+                    p2_out[3 * q + 1] = ok ? by : 0.0;
+                    p2_out[3 * q + 2] = ok ? bz : 0.0;
+                }
+            }
+            break;
         }
+        r = found ? sqrt(best) * (1.0 + 1e-12) + slack : 2.0 * r;
+        if (r > r_lim) r = r_lim;
+    }
+    (void)lim_is_bound;
+    if (work) {
+        if (lane == 0) { atomicAdd(work, n_cand); atomicAdd(work + 1, n_rows); }
+        if (q == 0 && lane == 0) atomicAdd(work + 2, 1ull);
     }
 }
 
@@ -249,8 +413,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_grid_knn(
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, long Q, int k,
-    GridGeom G, const uint32_t *__restrict__ cell_start, const double *__restrict__ sx,
-    const double *__restrict__ sy, const double *__restrict__ sz, const uint32_t *__restrict__ sidx,
+    GridGeom G, const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
     double rmax, int64_t idx_base, double *__restrict__ d2_out, int64_t *__restrict__ idx_out)
 {
     const int lane = threadIdx.x & 63;
@@ -282,8 +445,7 @@ __global__ __launch_bounds__(256) void k_grid_knn(
             const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
             cnt += cell_start[row + hi[0] + 1] - cell_start[row + lo[0]];
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        cnt = wsum_u64(cnt);
         if (cnt < (unsigned long long)k && !all) { r *= 2.0; continue; }
 
         // k extraction rounds over the candidate cells
@@ -297,21 +459,22 @@ __global__ __launch_bounds__(256) void k_grid_knn(
                 const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
                 const uint32_t b = cell_start[row + lo[0]], e = cell_start[row + hi[0] + 1];
                 for (uint32_t i = b + lane; i < e; i += 64) {
-                    const double dx = sx[i] - ax, dy = sy[i] - ay, dz = sz[i] - az;
+                    const double4 P = rec[i];
+                    const double dx = P.x - ax, dy = P.y - ay, dz = P.z - az;
                     const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
-                    if (d2 <= best && (first || d2 >= fd)) {
-                        const uint32_t oi = sidx[i];
-                        const bool above = first || d2 > fd || oi > fi;
-                        if (above && (d2 < best || oi < bidx)) { best = d2; bidx = oi; }
-                    }
+                    const uint32_t oi = (uint32_t)__double_as_longlong(P.w);
+                    const bool above = first || d2 > fd || (d2 == fd && oi > fi);
+                    if (above && (d2 < best || (d2 == best && oi < bidx))) { best = d2; bidx = oi; }
                 }
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double od = __shfl_xor(best, off, 64);
-                const uint32_t oi = __shfl_xor(bidx, off, 64);
-                if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; }
+#define SICP_LEXMIN_STEP(J)                                                                       \
+            {                                                                                     \
+                const double od = lane_xor_f64<J>(best);                                          \
+                const uint32_t oi = lane_xor32<J>(bidx);                                          \
+                if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; }             \
             }
+            SICP_LEXMIN_STEP(32) SICP_LEXMIN_STEP(16) SICP_LEXMIN_STEP(8) SICP_LEXMIN_STEP(4) SICP_LEXMIN_STEP(2) SICP_LEXMIN_STEP(1)
+#undef SICP_LEXMIN_STEP
             const bool ok = bidx != 0xffffffffu;
             if (final_pass || all) {
                 if (lane == 0) {
@@ -547,87 +710,75 @@ hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *fl
 // host launchers
 // ------------------------------------------------------------------------------------
 
-void launch_bbox(hipStream_t s, const double *x, const double *y, const double *z, long n, unsigned long long *out6)
+void launch_cloud_stats(hipStream_t s, const double *x, const double *y, const double *z, long n, unsigned long long *out7)
 {
-    long g = (n + 255) / 256;
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(k_bbox, dim3((unsigned)g), dim3(256), 0, s, x, y, z, n, out6);
+    long g = (n + 1023) / 1024;
+    if (g > 1024) g = 1024;             // 7 same-address atomics per block: few blocks, long grid-stride loops
+    hipLaunchKernelGGL(k_cloud_stats, dim3((unsigned)g), dim3(256), 0, s, x, y, z, n, out7);
 }
 
 void launch_cell_ids(hipStream_t s, const double *x, const double *y, const double *z, long n, const GridGeom &G,
-                     uint32_t *keys, uint32_t *vals, uint32_t *counts)
+                     uint32_t *ids, uint32_t *counts, unsigned long long *occupied)
 {
-    hipLaunchKernelGGL(k_cell_ids, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, n, G, keys, vals, counts);
+    if (occupied) hipLaunchKernelGGL(k_cell_ids<true>, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, n, G, ids, counts, occupied);
+    else hipLaunchKernelGGL(k_cell_ids<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, n, G, ids, counts, occupied);
 }
 
-void launch_count_nonempty(hipStream_t s, const uint32_t *counts, long ncells, unsigned long long *out)
+void launch_window_probe(hipStream_t s, const double *x, const double *y, const double *z, long n, long every, const GridGeom &Gw,
+                         const double wmax[3], uint32_t *counts, unsigned long long *out2)
 {
-    long g = (ncells + 255) / 256;
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(k_count_nonempty, dim3((unsigned)g), dim3(256), 0, s, counts, ncells, out);
+    const long chunks = (n + 1023) / 1024;
+    long g = (chunks + every - 1) / every;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_window_probe, dim3((unsigned)g), dim3(256), 0, s, x, y, z, n, every, Gw, wmax[0], wmax[1], wmax[2],
+                       counts, out2);
 }
 
-size_t grid_sort_temp_bytes(long n, int bits)
+long grid_scan_blocks(long n) { return (n + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS; }
+
+// out[0..n] = exclusive prefix sums of in[0..n) (entry n = total); block_off: grid_scan_blocks(n) words of scratch
+void launch_grid_scan(hipStream_t s, const uint32_t *in, long n, uint32_t *block_off, uint32_t *out, uint32_t *cursor)
 {
-    size_t t = 0;
-    uint32_t *p = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t, p, p, p, p, (int)n, 0, bits, (hipStream_t)0);
-    return t;
-}
-size_t grid_scan_temp_bytes(long ncells)
-{
-    size_t t = 0;
-    uint32_t *p = nullptr;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t, p, p, (int)ncells, (hipStream_t)0);
-    return t;
-}
-hipError_t grid_sort(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *k_in, uint32_t *k_out,
-                     const uint32_t *v_in, uint32_t *v_out, long n, int bits)
-{
-    return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (int)n, 0, bits, s);
-}
-hipError_t grid_scan(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, long ncells)
-{
-    return hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, in, out, (int)ncells, s);
+    const long nb = grid_scan_blocks(n);
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(256), 0, s, in, n, block_off);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, block_off, nb);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(256), 0, s, in, n, (const uint32_t *)block_off, out, cursor);
 }
 
-void launch_gather_sorted(hipStream_t s, const double *x, const double *y, const double *z, const uint32_t *sidx, long n,
-                          double *sx, double *sy, double *sz)
+void launch_scatter(hipStream_t s, const double *x, const double *y, const double *z, const uint32_t *ids, long n,
+                    uint32_t *cursor, void *rec)
 {
-    hipLaunchKernelGGL(k_gather_sorted, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, sidx, n, sx, sy, sz);
+    hipLaunchKernelGGL(k_scatter, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, ids, n, cursor, (double4 *)rec);
 }
 
 void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
-                    const GridGeom &G, const uint32_t *cell_start, const double *sx, const double *sy, const double *sz,
-                    const uint32_t *sidx, const Xf *H, const Xf *Hinv, double rmax, double max_d2, int64_t idx_base,
-                    double *d2_out, int64_t *idx_out, double *p2_out)
+                    const GridGeom &G, const uint32_t *cell_start, const void *rec, const Xf *H, const Xf *Hinv, double rmax,
+                    double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work)
 {
     const dim3 grid(cdiv(Q, 4)), block(256);
     Xf id = {};
     if (H)
-        hipLaunchKernelGGL((k_grid_nn<true, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, sx, sy, sz, sidx, *H,
-                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr);
+        hipLaunchKernelGGL((k_grid_nn<true, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec, *H,
+                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work);
     else
-        hipLaunchKernelGGL((k_grid_nn<false, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, sx, sy, sz, sidx, id,
-                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr);
+        hipLaunchKernelGGL((k_grid_nn<false, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec, id,
+                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work);
 }
 
 // the match of a chained iteration: transform taken from the loop state on the device
 void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
-                            const GridGeom &G, const uint32_t *cell_start, const double *sx, const double *sy, const double *sz,
-                            const uint32_t *sidx, const IcpDev *st, double rmax, int64_t idx_base, double *d2_out,
-                            int64_t *idx_out, double *p2_out)
+                            const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
+                            int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work)
 {
     Xf id = {};
-    hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(cdiv(Q, 4)), dim3(256), 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, sx, sy, sz,
-                       sidx, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st);
+    hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(cdiv(Q, 4)), dim3(256), 0, s, qx, qy, qz, Q, prev_p2, G, cell_start,
+                       (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work);
 }
 
 void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int k, const GridGeom &G,
-                     const uint32_t *cell_start, const double *sx, const double *sy, const double *sz, const uint32_t *sidx,
-                     double rmax, int64_t idx_base, double *d2_out, int64_t *idx_out)
+                     const uint32_t *cell_start, const void *rec, double rmax, int64_t idx_base, double *d2_out, int64_t *idx_out)
 {
-    hipLaunchKernelGGL(k_grid_knn, dim3(cdiv(Q, 4)), dim3(256), 0, s, qx, qy, qz, Q, k, G, cell_start, sx, sy, sz, sidx,
+    hipLaunchKernelGGL(k_grid_knn, dim3(cdiv(Q, 4)), dim3(256), 0, s, qx, qy, qz, Q, k, G, cell_start, (const double4 *)rec,
                        rmax, idx_base, d2_out, idx_out);
 }
 

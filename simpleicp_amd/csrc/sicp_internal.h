@@ -62,32 +62,27 @@ void launch_icp_tail(hipStream_t s, const double *qx, const double *qy, const do
 // uniform grid over a cloud in its own frame (sicp_grid.hip)
 struct GridGeom { double mn[3]; double h, inv_h; int dim[3]; };
 
-void launch_bbox(hipStream_t s, const double *x, const double *y, const double *z, long n, unsigned long long *out6);
+void launch_cloud_stats(hipStream_t s, const double *x, const double *y, const double *z, long n, unsigned long long *out7);
 void launch_cell_ids(hipStream_t s, const double *x, const double *y, const double *z, long n, const GridGeom &G,
-                     uint32_t *keys, uint32_t *vals, uint32_t *counts);
-void launch_count_nonempty(hipStream_t s, const uint32_t *counts, long ncells, unsigned long long *out);
-size_t grid_sort_temp_bytes(long n, int bits);
-size_t grid_scan_temp_bytes(long ncells);
-hipError_t grid_sort(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *k_in, uint32_t *k_out,
-                     const uint32_t *v_in, uint32_t *v_out, long n, int bits);
-hipError_t grid_scan(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, long ncells);
-void launch_gather_sorted(hipStream_t s, const double *x, const double *y, const double *z, const uint32_t *sidx, long n,
-                          double *sx, double *sy, double *sz);
+                     uint32_t *ids, uint32_t *counts, unsigned long long *occupied);
+void launch_window_probe(hipStream_t s, const double *x, const double *y, const double *z, long n, long every, const GridGeom &Gw,
+                         const double wmax[3], uint32_t *counts, unsigned long long *out2);
+long grid_scan_blocks(long n);
+void launch_grid_scan(hipStream_t s, const uint32_t *in, long n, uint32_t *block_off, uint32_t *out, uint32_t *cursor);
+void launch_scatter(hipStream_t s, const double *x, const double *y, const double *z, const uint32_t *ids, long n,
+                    uint32_t *cursor, void *rec);
+// rec: the cloud in cell order as packed 32-byte records (x, y, z, original row as int64 bits)
 void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
-                    const GridGeom &G, const uint32_t *cell_start, const double *sx, const double *sy, const double *sz,
-                    const uint32_t *sidx, const Xf *H, const Xf *Hinv, double rmax, double max_d2, int64_t idx_base,
-                    double *d2_out, int64_t *idx_out, double *p2_out);
-
+                    const GridGeom &G, const uint32_t *cell_start, const void *rec, const Xf *H, const Xf *Hinv, double rmax,
+                    double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work);
 void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
-                            const GridGeom &G, const uint32_t *cell_start, const double *sx, const double *sy, const double *sz,
-                            const uint32_t *sidx, const IcpDev *st, double rmax, int64_t idx_base, double *d2_out,
-                            int64_t *idx_out, double *p2_out);
+                            const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
+                            int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work);
+void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int k, const GridGeom &G,
+                     const uint32_t *cell_start, const void *rec, double rmax, int64_t idx_base, double *d2_out, int64_t *idx_out);
 
 void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec);
 void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, double *d2, int64_t *idx, double *p2);
-void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int k, const GridGeom &G,
-                     const uint32_t *cell_start, const double *sx, const double *sy, const double *sz, const uint32_t *sidx,
-                     double rmax, int64_t idx_base, double *d2_out, int64_t *idx_out);
 size_t reject_select_scratch_bytes();
 hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
                             unsigned long long *keys, void *state, unsigned long long *small);
@@ -116,7 +111,6 @@ void launch_knn1_fixup(hipStream_t s, const double *qx, const double *qy, const 
 int  frec_blocks_per_cu(int block);
 void launch_bound_prev(hipStream_t s, const double *qx, const double *qy, const double *qz, const double *p2, long Q,
                        long qpad, const Xf &H, double *bound);
-void launch_max_norm2(hipStream_t s, const double *x, const double *y, const double *z, long n, unsigned long long *out);
 void launch_knn1_reduce(hipStream_t s, const double *part_d2, const uint32_t *part_idx, int nparts, int qpad, long Q,
                         double max_d2, int64_t idx_base, const double *px, const double *py, const double *pz,
                         double *d2_out, int64_t *idx_out, double *p2_out);

@@ -459,20 +459,6 @@ __global__ void k_bound_prev(const double *__restrict__ qx, const double *__rest
     bound[q] = fma(dz, dz, fma(dy, dy, dx * dx));
 }
 
-// largest squared norm of a cloud (for the filter's error bound); out = bits of a non-negative double
-__global__ void k_max_norm2(const double *__restrict__ x, const double *__restrict__ y,
-                            const double *__restrict__ z, long n, unsigned long long *__restrict__ out)
-{
-    double m = 0.0;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const double v = fma(z[i], z[i], fma(y[i], y[i], x[i] * x[i]));
-        m = (v > m || v != v) ? v : m;                      // a NaN sticks: the upload rejects non-finite clouds
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(m, off, 64); m = (o > m || o != o) ? o : m; }
-    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
-}
-
 // chunk partials -> per-query winner (ascending chunk order + strict `<` keeps the lowest
 // index on ties), strict upper bound (pointcloud.py:163-167), gather of the winner's
 // ORIGINAL coordinates (what the optimiser consumes, optimization.py:172-211).
@@ -1283,13 +1269,6 @@ void launch_bound_prev(hipStream_t s, const double *qx, const double *qy, const 
                        long qpad, const Xf &H, double *bound)
 {
     hipLaunchKernelGGL(k_bound_prev, dim3(cdiv(qpad, 256)), dim3(256), 0, s, qx, qy, qz, p2, Q, qpad, H, bound);
-}
-
-void launch_max_norm2(hipStream_t s, const double *x, const double *y, const double *z, long n, unsigned long long *out)
-{
-    long g = (n + 255) / 256;
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)g), dim3(256), 0, s, x, y, z, n, out);
 }
 
 void launch_knn1_reduce(hipStream_t s, const double *part_d2, const uint32_t *part_idx, int nparts, int qpad, long Q,
