@@ -32,7 +32,7 @@ One JSON line on stdout (rank 0).  Extra objects on the same line:
   roofline             the kernel with the largest share of the step's GPU time; `achieved` = algorithmic bytes per
                        launch / average launch duration
   roofline_match       the 1-NN kernel of the default path (pruned grid search), priced on the bytes the pruned
-                       search itself needs (candidates x 28 B + cell offsets + queries), with `pruning_ratio`
+                       search itself needs (candidates x 32-byte records + cell offsets + queries), with `pruning_ratio`
   roofline_bruteforce  the north-star brute-force scan, measured in a short extra leg on the same inputs
   parity               one more iteration after the timed region, checked against the CPU oracle
   setup                upload / grid build / normals, each once per run() -- outside `value`, reported
@@ -255,7 +255,14 @@ def run(args):
     iterate(ctx, args.steps, obs.copy(), obs, ow)
     timing = ctx.timing()
     match_kernel = ctx.last_match_kernel()
-    work = ctx.match_work() if hasattr(ctx, "match_work") else None
+    # ... and one more with the grid search tallying the candidates / rows it touches (the bytes its roofline is priced on)
+    work = None
+    if match_kernel == "k_grid_nn":
+        ctx.timing_enable(True, count_work=True)
+        ctx.timing_reset()
+        cold()
+        iterate(ctx, args.steps, obs.copy(), obs, ow)
+        work = ctx.match_work()
     ctx.timing_enable(False)
 
     # parity leg, device side (every rank takes part in the exchange; only rank 0 consults the oracle)
@@ -291,13 +298,12 @@ def run(args):
         return d
 
     if match_kernel == "k_grid_nn":
-        # the pruned search's OWN bytes: every candidate it evaluates costs 24 B of coordinates (+4 B of original
-        # index on ties, counted for all), every grid row two 4-B offsets, every query its coordinates, the previous
-        # match (bound) and the 48-B result -- counted by the instrumented kernel variant when available, else the
-        # PMC traffic stands in
-        if work:
+        # the pruned search's OWN bytes: every candidate it evaluates is one packed 32-B record (x, y, z, index),
+        # every non-empty grid row two 4-B offsets, every query its coordinates, the previous match (bound) and the
+        # 48-B result -- tallied by the kernel itself in a separate pass
+        if work and work["launches"]:
             per = {kk: v / max(1, work["launches"]) for kk, v in work.items() if kk != "launches"}
-            bytes_match = per["candidates"] * 28 + per["rows"] * 8 + nq * (24 + 24 + 48)
+            bytes_match = per["candidates"] * 32 + per["rows"] * 8 + nq * (24 + 24 + 48)
             extra = {"candidates_per_query": per["candidates"] / nq, "grid_rows_per_query": per["rows"] / nq}
         else:
             bytes_match = pmc.get("k_grid_nn") or bytes_bruteforce

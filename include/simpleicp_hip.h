@@ -225,14 +225,14 @@ int sicp_xyz_write(const char *path, const double *data, int64_t n, int cols, in
 #define SICP_K_NORMALEQ 2   /* fused residual + normal-equation reduce  */
 #define SICP_K_SELECT   3   /* median / MAD selection                   */
 #define SICP_K_COUNT    4
-int sicp_timing_enable(sicp_ctx *ctx, int on);
+int sicp_timing_enable(sicp_ctx *ctx, int on);   /* 0 off, 1 kernel timing, 2 timing + the grid search's work tallies (sicp_match_work) */
 /* which 1-NN flavour the last sicp_knn(k=1) / sicp_icp_iterate used: 0 exact scan, 1 filtered scan
  * with inline verification, 2 grid search, 3 filtered scan with recorded candidates + fix-up kernel
  * (all return identical results) */
 int sicp_last_match_kernel(sicp_ctx *ctx, int *kind_out);
 int sicp_timing_reset(sicp_ctx *ctx);
 /* Work the pruned grid search did in its launches since sicp_timing_reset, counted by the kernel itself while
- * timing is enabled: out3[0] candidates evaluated (one 32-byte record read each), out3[1] non-empty grid rows
+ * sicp_timing_enable(ctx, 2) is in force: out3[0] candidates evaluated (one 32-byte record read each), out3[1] non-empty grid rows
  * visited (two 4-byte offsets each), out3[2] launches -- the bytes the bench prices the search's roofline on. */
 int sicp_match_work(sicp_ctx *ctx, uint64_t out3[3]);
 int sicp_timing_get(sicp_ctx *ctx, int kernel, double *total_ms_out, int64_t *launches_out);

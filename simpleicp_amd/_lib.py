@@ -349,8 +349,10 @@ class Context:
         return d2, idx, xyz
 
     # -- timing --
-    def timing_enable(self, on=True):
-        self._chk(self._L.sicp_timing_enable(self._h, int(on)))
+    def timing_enable(self, on=True, count_work=False):
+        """Kernel timing with HIP events on the library's stream; count_work also makes the grid search tally the
+        candidates and rows it touches (slower: a separate pass)."""
+        self._chk(self._L.sicp_timing_enable(self._h, 2 if (on and count_work) else int(bool(on))))
 
     def timing_reset(self):
         self._chk(self._L.sicp_timing_reset(self._h))

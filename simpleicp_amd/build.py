@@ -14,8 +14,8 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libsimpleicp_hip.so"
-SOURCES = [CSRC / "sicp_api.cpp", CSRC / "sicp_kernels.hip", CSRC / "sicp_grid.hip", CSRC / "sicp_tail.hip", CSRC / "sicp_io.cpp"]
-HEADERS = [CSRC / "sicp_internal.h", CSRC / "sicp_lanes.h", PKG.parent / "include" / "simpleicp_hip.h"]
+SOURCES = [CSRC / "sicp_api.cpp", CSRC / "sicp_kernels.hip", CSRC / "sicp_grid.hip", CSRC / "sicp_tail.hip", CSRC / "sicp_lm.hip", CSRC / "sicp_io.cpp"]
+HEADERS = [CSRC / "sicp_internal.h", CSRC / "sicp_lanes.h", CSRC / "sicp_solver.h", PKG.parent / "include" / "simpleicp_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fvisibility=hidden", "-Wall", "-pthread"]
 

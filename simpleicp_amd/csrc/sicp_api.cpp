@@ -233,6 +233,11 @@ struct sicp_ctx {
     bool solve_trace = false;      // SICP_SOLVE_TRACE: the fused kernel's cycle counters on stderr
     long solve_seq = 0;            // completion tickets of the fused kernel
     DevBuf<IcpDev> icp_dev;        // device-resident loop state of a chained run (sicp_tail.hip)
+    DevBuf<LmDev> lm_dev;          // solver state of the multi-workgroup evaluation chain (sicp_lm.hip)
+    LmDev *h_lm = nullptr;         // pinned staging of it
+    DevBuf<double> resid2;         // second residual buffer of that chain (trial / accepted alternate)
+    int resid_slot = 0;            // which buffer holds the last iteration's accepted residuals
+    int lm_evals = 4;              // evaluations enqueued per iteration for Q > SOLVE_MAX_Q (SICP_LM_EVALS; k_lm_finish completes the rest)
     double *h_rec = nullptr;       // pinned ring of per-iteration records the tail kernel streams to the host
     IcpDev *h_state = nullptr;     // pinned staging of the loop state
     int chain_depth = 4;           // iterations enqueued ahead of the last record read (SICP_CHAIN_DEPTH)
@@ -242,6 +247,7 @@ struct sicp_ctx {
     int rank = 0, world = 1, gn_shard = 0;
     // timing
     bool timing = false;
+    bool count_work = false;       // sicp_timing_enable(ctx, 2): the grid search also tallies its candidates / rows
     std::vector<EventPair> pending, pool;
     double t_ms[SICP_K_COUNT] = {0};
     int64_t t_n[SICP_K_COUNT] = {0};
@@ -565,7 +571,7 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
             Timed t(c, SICP_K_KNN1);
             launch_grid_nn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, prev_p2, gr.g, gr.cell_start.p, gr.rec.p, H,
                            H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out, p2_out,
-                           c->timing ? c->match_work.p : nullptr);
+                           c->count_work ? c->match_work.p : nullptr);
         }
         HIPCHK(hipGetLastError());
         return SICP_OK;
@@ -781,9 +787,11 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipStreamCreate failed"); }
     if (hipHostMalloc((void **)&c->h_small, 256 * sizeof(double), hipHostMallocMapped) != hipSuccess) { delete c; return fail(SICP_ERR_HIP, "hipHostMalloc failed"); }
     int rc = c->small.reserve(128);
-    if (rc == SICP_OK) rc = c->ne_partial.reserve((size_t)NE_MAX_GRID * 32);
+    if (rc == SICP_OK) rc = c->ne_partial.reserve((size_t)NE_MAX_GRID * 64);
     if (rc == SICP_OK) rc = c->ticket.reserve(4);
     if (rc == SICP_OK) rc = c->icp_dev.reserve(1);
+    if (rc == SICP_OK) rc = c->lm_dev.reserve(1);
+    if (rc == SICP_OK && hipHostMalloc((void **)&c->h_lm, sizeof(LmDev), hipHostMallocDefault) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc == SICP_OK) rc = c->match_work.reserve(4);
     if (rc == SICP_OK && hipMemsetAsync(c->match_work.p, 0, 4 * sizeof(unsigned long long), c->stream) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc == SICP_OK && hipHostMalloc((void **)&c->h_rec, (size_t)REC_RING * REC_DOUBLES * sizeof(double), hipHostMallocMapped) != hipSuccess) rc = SICP_ERR_HIP;
@@ -791,6 +799,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (rc == SICP_OK) std::memset(c->h_rec, 0, (size_t)REC_RING * REC_DOUBLES * sizeof(double));
     if (rc == SICP_OK && hipMemsetAsync(c->ticket.p, 0, 4 * sizeof(unsigned), c->stream) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
+    if (const char *e = std::getenv("SICP_LM_EVALS")) { const int d = std::atoi(e); if (d >= 0 && d <= 32) c->lm_evals = d; }
     if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
     if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : 0;
     if (const char *e = std::getenv("SICP_FSCAN_CAP")) c->fscan_cap = std::atol(e);
@@ -817,7 +826,8 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->hit_cnt.release(); c->hit_list.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
     c->resid.release(); c->flag.release(); c->keep.release(); c->small.release(); c->ne_partial.release();
-    c->ticket.release(); c->icp_dev.release();
+    c->ticket.release(); c->icp_dev.release(); c->lm_dev.release(); c->resid2.release();
+    if (c->h_lm) (void)hipHostFree(c->h_lm);
     if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->h_state) (void)hipHostFree(c->h_state);
@@ -1096,6 +1106,8 @@ SICP_EXPORT int sicp_icp_setup(sicp_ctx *c, const int64_t *sel_idx, int64_t Q, c
     CHK(c->normals.reserve((size_t)3 * Q)); CHK(c->planarity.reserve(Q));
     CHK(c->m_idx.reserve(Q)); CHK(c->m_d2.reserve(Q)); CHK(c->m_p2.reserve((size_t)3 * Q));
     CHK(c->dist.reserve(Q)); CHK(c->resid.reserve(Q)); CHK(c->flag.reserve(Q)); CHK(c->keep.reserve(Q));
+    if (Q > SOLVE_MAX_Q) CHK(c->resid2.reserve(Q));
+    c->resid_slot = 0;
     HIPCHK(hipMemcpyAsync(c->m_idx.p, sel_idx, (size_t)Q * sizeof(int64_t), hipMemcpyDefault, c->stream));
     launch_gather_queries(c->stream, cl.x(), cl.y(), cl.z(), c->m_idx.p, Q, c->qpad, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad);
     HIPCHK(hipGetLastError());
@@ -1124,14 +1136,17 @@ int check_iter_args(sicp_ctx *c, const sicp_iter_params *P)
 }
 
 // does this configuration run the single-launch tail (sicp_tail.hip) with the loop state on the device?
-bool device_tail(const sicp_ctx *c) { return c->Q <= SOLVE_MAX_Q && !(c->gn_shard && c->xfn) && c->solve_mode != 2; }
+bool device_tail(const sicp_ctx *c) { return !(c->gn_shard && c->xfn) && c->solve_mode != 2; }
 
-// ---- Q <= SOLVE_MAX_Q: match + ONE tail launch per iteration, iterations enqueued back to back --------------
-// The tail kernel reads the estimate it starts from out of the device-resident loop state and leaves the next
-// one there (with H(x), its inverse, the frozen weight, the convergence verdict); with the grid search the
-// match kernel takes its transform from that state too, so `chain_depth` iterations are in flight ahead of the
-// record the host is reading and nothing waits for a host round trip.  Launches after the end of the run
-// (converged / failed) see the stop flag and exit at once.  min_change < 0: no convergence test.
+// ---- iterations enqueued back to back, loop state on the device --------------------------------------------------
+// Q <= SOLVE_MAX_Q: match + ONE tail launch per iteration (sicp_tail.hip).  Larger Q: match, distances, rejection,
+// statistics, `lm_evals` multi-workgroup evaluations whose last block advances the solver, and a finishing launch
+// (sicp_lm.hip).  Either way the last kernel of an iteration reads the estimate it starts from out of the
+// device-resident loop state and leaves the next one there (with H(x), its inverse, the frozen weight, the
+// convergence verdict); with the grid search the match kernel takes its transform from that state too, so
+// `chain_depth` iterations are in flight ahead of the record the host is reading and nothing waits for a host
+// round trip.  Launches after the end of the run (converged / failed) see the stop flag and exit at once.
+// min_change < 0: no convergence test.
 int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, double min_change, sicp_iter_result *results,
                     int64_t *done_out)
 {
@@ -1142,7 +1157,8 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
     // the pruned exact search on the static grid serves every rigid H, i.e. every H(x) of the loop
     const bool grid = (c->knn1_mode == 0 || c->knn1_mode == 3) && cl.n < (1LL << 31);
     if (grid) CHK(grid_build(c, SICP_MOV));
-    const int depth = grid ? c->chain_depth : 1;
+    const bool small_q = Q <= SOLVE_MAX_Q;
+    const int depth = !grid ? 1 : small_q ? c->chain_depth : std::min(c->chain_depth, 2);
 
     IcpDev &hs = *c->h_state;
     std::memset(&hs, 0, sizeof hs);
@@ -1157,6 +1173,13 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
     }
     hs.w = (P0->distance_weight > 0) ? P0->distance_weight : -1.0;
     HIPCHK(hipMemcpyAsync(c->icp_dev.p, &hs, sizeof hs, hipMemcpyHostToDevice, c->stream));
+    if (!small_q) {
+        LmDev &hl = *c->h_lm;
+        std::memset(&hl, 0, sizeof hl);
+        for (int j = 0; j < 6; ++j) { hl.x[j] = hl.xt[j] = hs.x[j]; hl.sc[j] = hl.sct[j] = hs.sc[j]; }
+        hl.w = hs.w; hl.first = 1;
+        HIPCHK(hipMemcpyAsync(c->lm_dev.p, &hl, sizeof hl, hipMemcpyHostToDevice, c->stream));
+    }
 
     TailArgs A;
     for (int j = 0; j < 6; ++j) { A.obs[j] = P0->obs[j]; A.ow[j] = P0->obs_weight[j]; }
@@ -1182,7 +1205,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 Timed t(c, SICP_K_KNN1);
                 launch_grid_nn_chained(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, Q, prev, cl.grid.g,
                                        cl.grid.cell_start.p, cl.grid.rec.p, c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p,
-                                       c->m_idx.p, c->m_p2.p, c->timing ? c->match_work.p : nullptr);
+                                       c->m_idx.p, c->m_p2.p, c->count_work ? c->match_work.p : nullptr);
             } else {
                 // brute-force flavours take H by value: one iteration in flight, H from the last record
                 params_to_H12(xcur, H12);
@@ -1195,11 +1218,39 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
             CHK(exchange_best(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
             A.seq = (double)(++c->solve_seq);
             seqs[launched % REC_RING] = A.seq;
-            {
+            double *rec = c->h_rec + (launched % REC_RING) * REC_DOUBLES;
+            const double *qx = c->q.p, *qy = c->q.p + c->qpad, *qz = c->q.p + 2 * c->qpad;
+            if (small_q) {
                 Timed t(c, SICP_K_NORMALEQ);
-                launch_icp_tail(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, c->m_p2.p,
-                                c->m_idx.p, A, c->icp_dev.p, c->dist.p, c->keep.p, c->resid.p,
-                                c->h_rec + (launched % REC_RING) * REC_DOUBLES);
+                launch_icp_tail(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, A, c->icp_dev.p, c->dist.p,
+                                c->keep.p, c->resid.p, rec);
+            } else {
+                // distances + rejections (corrpts.py:139-211), kept-distance statistics, then the solver chain
+                Xf unused = {};
+                launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
+                                 A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
+                {
+                    Timed t(c, SICP_K_SELECT);
+                    if (Q > REJECT_MAX_Q) {
+                        const size_t sb = (reject_select_scratch_bytes() + 7) / 8;
+                        CHK(c->rj_keys.reserve((size_t)Q + sb));
+                        if (reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->rj_keys.p, c->rj_keys.p + Q,
+                                             (unsigned long long *)(c->small.p + 56), c->icp_dev.p) != hipSuccess)
+                            return fail(SICP_ERR_HIP, "rejection by radix selection failed");
+                    } else {
+                        launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->icp_dev.p);
+                    }
+                }
+                launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4, nullptr, nullptr, 0.0, c->ne_partial.p, c->ticket.p,
+                             c->icp_dev.p);
+                {
+                    Timed t(c, SICP_K_NORMALEQ);
+                    for (int e = 0; e < c->lm_evals; ++e)
+                        launch_lm_eval(c->stream, qx, qy, qz, c->normals.p, c->m_p2.p, c->keep.p, Q, A, c->icp_dev.p, c->lm_dev.p,
+                                       c->small.p + 4, c->ne_partial.p, c->ticket.p, c->resid.p, c->resid2.p);
+                    launch_lm_finish(c->stream, qx, qy, qz, c->normals.p, c->m_p2.p, c->keep.p, Q, A, c->icp_dev.p, c->lm_dev.p,
+                                     c->small.p, c->small.p + 4, c->resid.p, c->resid2.p, rec);
+                }
             }
             HIPCHK(hipGetLastError());
             ++launched;
@@ -1235,7 +1286,8 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
         std::memcpy(c->last_ow, P0->obs_weight, sizeof c->last_ow);
         std::memcpy(c->last_ne, o + 20, sizeof c->last_ne);
         c->have_last_ne = true;
-        if (c->solve_trace)
+        c->resid_slot = small_q ? 0 : (int)o[REC_RESID_SLOT];
+        if (c->solve_trace && small_q)
             std::fprintf(stderr, "[tail] cycles: load+dist %.0f select %.0f (median %.0f in %.0f rounds, MAD %.0f in %.0f) stats %.0f lm %.0f "
                                  "(%lld evals %.0f, %lld steps, solves %.0f) final %.0f\n",
                          o[50], o[51], o[55], o[56], o[57], o[58], o[52], o[53], (long long)R.ne_evals, o[59], (long long)R.lm_steps, o[60], o[54]);
@@ -1249,6 +1301,7 @@ int iterate_host_lm(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
 {
     std::memset(R, 0, sizeof *R);
     const long Q = c->Q;
+    c->resid_slot = 0;
     int nfree = 0, freeidx[6];
     for (int j = 0; j < 6; ++j)
         if (std::isfinite(P->obs_weight[j])) freeidx[nfree++] = j;
@@ -1420,7 +1473,7 @@ SICP_EXPORT int sicp_icp_get_state(sicp_ctx *c, int64_t *pc2_idx, double *dist, 
     if (pc2_idx) HIPCHK(hipMemcpyAsync(pc2_idx, c->m_idx.p, Q * sizeof(int64_t), hipMemcpyDefault, c->stream));
     if (dist) HIPCHK(hipMemcpyAsync(dist, c->dist.p, Q * sizeof(double), hipMemcpyDefault, c->stream));
     if (keep) HIPCHK(hipMemcpyAsync(keep, c->keep.p, Q * sizeof(uint8_t), hipMemcpyDefault, c->stream));
-    if (residual) HIPCHK(hipMemcpyAsync(residual, c->resid.p, Q * sizeof(double), hipMemcpyDefault, c->stream));
+    if (residual) HIPCHK(hipMemcpyAsync(residual, c->resid_slot ? c->resid2.p : c->resid.p, Q * sizeof(double), hipMemcpyDefault, c->stream));
     return sync(c);
 }
 
@@ -1512,6 +1565,7 @@ SICP_EXPORT int sicp_timing_enable(sicp_ctx *c, int on)
 {
     if (!c) return fail(SICP_ERR_INVALID, "null ctx");
     c->timing = on != 0;
+    c->count_work = on == 2;
     return SICP_OK;
 }
 SICP_EXPORT int sicp_last_match_kernel(sicp_ctx *c, int *kind_out)

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
                 len = cell_start[row + hi[0] + 1] - b;
             }
             unsigned long long todo = __ballot(len > 0);          // rows of this batch that hold points
-            if (work) { n_rows += (unsigned long long)__popcll((long long)todo); }
+            if (work && len > 0) n_rows += 1;                     // (per-lane tallies, summed once at the end)
             while (todo) {
                 // up to four rows per step: ranges by register broadcast, one record per lane and row
                 uint32_t rbv[4], rlv[4];
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
                         const uint32_t oi = (uint32_t)__double_as_longlong(P[u].w);
                         if (d2 < best || (d2 == best && oi < bidx)) { best = d2; bidx = oi; bx = P[u].x; by = P[u].y; bz = P[u].z; }
                     }
-                    if (work) { for (int u = 0; u < 4; ++u) n_cand += (unsigned long long)__popcll((long long)__ballot(ok[u])); }
+                    if (work) { for (int u = 0; u < 4; ++u) n_cand += ok[u] ? 1 : 0; }
                 }
             }
         }
@@ -399,6 +399,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     }
     (void)lim_is_bound;
     if (work) {
+        n_cand = wsum_u64(n_cand); n_rows = wsum_u64(n_rows);
         if (lane == 0) { atomicAdd(work, n_cand); atomicAdd(work + 1, n_rows); }
         if (q == 0 && lane == 0) atomicAdd(work + 2, 1ull);
     }
@@ -524,8 +525,9 @@ __device__ __forceinline__ void block_add_u64(unsigned long long c, unsigned lon
 // keys of flagged distances (or of |d - med| when center != null), ~0 for the rest; counts the flagged
 __global__ __launch_bounds__(256) void k_reject_keys(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
                                                      const double *__restrict__ center, unsigned long long *__restrict__ keys,
-                                                     unsigned long long *__restrict__ count)
+                                                     unsigned long long *__restrict__ count, const IcpDev *__restrict__ st)
 {
+    if (st && st->stop) return;
     unsigned long long c = 0;
     const double ctr = center ? center[0] : 0.0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < Q; i += (long)gridDim.x * 256) {
@@ -539,8 +541,9 @@ __global__ __launch_bounds__(256) void k_reject_keys(const double *__restrict__ 
 
 __global__ __launch_bounds__(256) void k_reject_keep(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
                                                      const double *__restrict__ med_mad, uint8_t *__restrict__ keep,
-                                                     unsigned long long *__restrict__ kept)
+                                                     unsigned long long *__restrict__ kept, const IcpDev *__restrict__ st)
 {
+    if (st && st->stop) return;
     unsigned long long c = 0;
     const double med = med_mad[0], bound = 3 * med_mad[1];
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < Q; i += (long)gridDim.x * 256) {
@@ -551,8 +554,9 @@ __global__ __launch_bounds__(256) void k_reject_keep(const double *__restrict__ 
 }
 
 __global__ void k_reject_finish(const unsigned long long *__restrict__ counts /*[0]=m,[1]=kept*/,
-                                const double *__restrict__ med_mad, double *__restrict__ out4)
+                                const double *__restrict__ med_mad, double *__restrict__ out4, const IcpDev *__restrict__ st)
 {
+    if (st && st->stop) return;
     out4[0] = (double)counts[0]; out4[1] = med_mad[0]; out4[2] = med_mad[1]; out4[3] = (double)counts[1];
 }
 
@@ -583,9 +587,11 @@ __device__ __forceinline__ bool last_block_arrives(unsigned *ticket, int *is_las
 }
 
 __global__ __launch_bounds__(256) void k_rsel_pass(const unsigned long long *__restrict__ keys, long Q, int pass,
-                                                   RselState *__restrict__ S, const unsigned long long *__restrict__ count)
+                                                   RselState *__restrict__ S, const unsigned long long *__restrict__ count,
+                                                   const IcpDev *__restrict__ st)
 {
     __shared__ unsigned hist[RSEL_BINS];
+    if (st && st->stop) return;
     __shared__ unsigned scan[4];               // wave totals of the last block's prefix scan
     __shared__ int is_last;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -642,9 +648,10 @@ __global__ __launch_bounds__(256) void k_rsel_pass(const unsigned long long *__r
 // second middle value + their mean: dst[0] = np.median of the keys' values (NaN when there are none)
 __global__ __launch_bounds__(256) void k_rsel_finish(const unsigned long long *__restrict__ keys, long Q,
                                                      RselState *__restrict__ S, const unsigned long long *__restrict__ count,
-                                                     double *__restrict__ dst)
+                                                     double *__restrict__ dst, const IcpDev *__restrict__ st)
 {
     __shared__ int is_last;
+    if (st && st->stop) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long ka = S->st[0];
     unsigned long long le = 0, nxt = ~0ull;
@@ -681,11 +688,12 @@ size_t reject_select_scratch_bytes() { return sizeof(RselState); }
 
 // scratch: keys (Q u64), state (reject_select_scratch_bytes), small (4 u64/doubles: m, kept, med, mad)
 hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
-                            unsigned long long *keys, void *state, unsigned long long *small)
+                            unsigned long long *keys, void *state, unsigned long long *small, const IcpDev *st)
 {
     unsigned long long *counts = small;            // [0] m, [1] kept
     double *med_mad = (double *)(small + 2);       // [0] median, [1] mad
     RselState *S = (RselState *)state;
+    // (a chained launch that finds the run over skips every kernel below: the zeroed scratch is never read)
     hipError_t e = hipMemsetAsync(small, 0, 4 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(state, 0, sizeof(RselState), s);
@@ -694,15 +702,15 @@ hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *fl
     const unsigned gs = (unsigned)std::min<long>(512, (Q + 1023) / 1024);
     for (int stat = 0; stat < 2; ++stat) {
         hipLaunchKernelGGL(k_reject_keys, dim3(g), dim3(256), 0, s, dist, flag, Q, stat ? (const double *)med_mad : nullptr, keys,
-                           stat ? (unsigned long long *)nullptr : counts);
+                           stat ? (unsigned long long *)nullptr : counts, st);
         for (int pass = 0; pass < 6; ++pass)
             hipLaunchKernelGGL(k_rsel_pass, dim3(gs), dim3(256), 0, s, (const unsigned long long *)keys, Q, pass, S,
-                               (const unsigned long long *)counts);
+                               (const unsigned long long *)counts, st);
         hipLaunchKernelGGL(k_rsel_finish, dim3(gs), dim3(256), 0, s, (const unsigned long long *)keys, Q, S,
-                           (const unsigned long long *)counts, med_mad + stat);
+                           (const unsigned long long *)counts, med_mad + stat, st);
     }
-    hipLaunchKernelGGL(k_reject_keep, dim3(g), dim3(256), 0, s, dist, flag, Q, (const double *)med_mad, keep, counts + 1);
-    hipLaunchKernelGGL(k_reject_finish, dim3(1), dim3(1), 0, s, counts, (const double *)med_mad, out4);
+    hipLaunchKernelGGL(k_reject_keep, dim3(g), dim3(256), 0, s, dist, flag, Q, (const double *)med_mad, keep, counts + 1, st);
+    hipLaunchKernelGGL(k_reject_finish, dim3(1), dim3(1), 0, s, counts, (const double *)med_mad, out4, st);
     return hipGetLastError();
 }
 

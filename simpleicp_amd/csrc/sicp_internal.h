@@ -53,11 +53,30 @@ struct TailArgs {
 // 10..15 x, 16 res_mean, 17 res_std, 18 status, 19 converged, 20..49 normal equations at x, 50..54 phase cycles
 constexpr int REC_STATUS = 18;      // 0 ok / 1 too few correspondences / 2 objective not finite / 3 skipped (run already over)
 constexpr int REC_CONVERGED = 19;
+constexpr int REC_RESID_SLOT = 61;  // larger Q: which of the two residual buffers holds the accepted residuals
 constexpr int REC_TICKET = 63;
 constexpr int REC_DOUBLES = 64;
 void launch_icp_tail(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
                      const float *planarity, const double *p2, const int64_t *idx, const TailArgs &A, IcpDev *st, double *dist,
                      uint8_t *keep, double *resid, double *rec);
+
+// solver state of the multi-workgroup evaluation chain (sicp_lm.hip, Q > SOLVE_MAX_Q)
+struct LmDev {
+    double x[6], sc[6];           // accepted estimate, sin / cos of its angles
+    double xt[6], sct[6];         // trial the next evaluation runs at
+    double G[2][64];              // 8x8 Gram matrices of the rows [a0..a5 | r | 1]: [cur] accepted, [cur ^ 1] trial
+    double stat[2][2];            // per slot: sum (r - shift), sum (r - shift)^2
+    double shift;                 // the kept distances' mean: residual statistics are accumulated relative to it
+    double w, cost, lambda, dxmax;
+    int cur, first, tries, steps, evals, done, pad[2];
+};
+int  lm_eval_grid(long Q);
+void launch_lm_eval(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
+                    const uint8_t *keep, long Q, const TailArgs &A, const IcpDev *st, LmDev *L, const double *stats, double *partial,
+                    unsigned *ticket, double *resid0, double *resid1);
+void launch_lm_finish(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
+                      const uint8_t *keep, long Q, const TailArgs &A, IcpDev *st, LmDev *L, const double *rj4, const double *stats,
+                      double *resid0, double *resid1, double *rec);
 
 // uniform grid over a cloud in its own frame (sicp_grid.hip)
 struct GridGeom { double mn[3]; double h, inv_h; int dim[3]; };
@@ -85,7 +104,7 @@ void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const
 void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, double *d2, int64_t *idx, double *p2);
 size_t reject_select_scratch_bytes();
 hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
-                            unsigned long long *keys, void *state, unsigned long long *small);
+                            unsigned long long *keys, void *state, unsigned long long *small, const IcpDev *st = nullptr);
 void launch_aos_to_soa(hipStream_t s, const double *aos, long n, long npad, double *x, double *y, double *z);
 void launch_found_mask(hipStream_t s, const int64_t *idx, long Q, uint8_t *out);
 void launch_pad_fill(hipStream_t s, double *x, double *y, double *z, long n, long npad);
@@ -123,10 +142,12 @@ void launch_normals(hipStream_t s, const double *px, const double *py, const dou
                     int64_t idx_base, float *normals, float *planarity);
 void launch_postmatch(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
                       const float *planarity, const double *p2, const int64_t *idx, long Q, const Xf &H,
-                      float min_planarity, const float *pl2, long pl2_n, double *dist, uint8_t *flag);
-void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4);
+                      float min_planarity, const float *pl2, long pl2_n, double *dist, uint8_t *flag, const IcpDev *st = nullptr);
+// st (nullable): loop state of a chained run -- H comes from it (postmatch) and every kernel exits at once when the run is over
+void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, const IcpDev *st = nullptr);
 void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3, const double *also4 = nullptr,
-                  double *host_out = nullptr, double seq = 0.0, double *partial = nullptr, unsigned *ticket = nullptr);
+                  double *host_out = nullptr, double seq = 0.0, double *partial = nullptr, unsigned *ticket = nullptr,
+                  const IcpDev *st = nullptr);
 int  ne_grid_for(long count);
 void launch_normal_eq(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
                       const double *p2, const uint8_t *keep, long lo, long hi, const double H12[12], const double dR[27],

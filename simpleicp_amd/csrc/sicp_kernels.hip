@@ -705,9 +705,11 @@ __global__ void k_postmatch(const double *__restrict__ qx, const double *__restr
                             const float *__restrict__ planarity, const double *__restrict__ p2,
                             const int64_t *__restrict__ idx, long Q, Xf H, float min_planarity,
                             const float *__restrict__ pl2 /* movable cloud's column by global index, or null */,
-                            long pl2_n, double *__restrict__ dist, uint8_t *__restrict__ flag)
+                            long pl2_n, double *__restrict__ dist, uint8_t *__restrict__ flag,
+                            const IcpDev *__restrict__ st /* nullable: chained run -> its H, its stop flag */)
 {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (st) { if (st->stop) return; H = st->H; }
     if (q >= Q) return;
     double X, Y, Z;
     xform(H, p2[3 * q], p2[3 * q + 1], p2[3 * q + 2], X, Y, Z);
@@ -833,9 +835,11 @@ __device__ uint64_t lds_next_rank(RejectShared &S, int n, long r, uint64_t ka)
 }
 
 __global__ __launch_bounds__(1024) void k_reject(const double *__restrict__ dist, const uint8_t *__restrict__ flag,
-                                                 long Q, uint8_t *__restrict__ keep, double *__restrict__ out)
+                                                 long Q, uint8_t *__restrict__ keep, double *__restrict__ out,
+                                                 const IcpDev *__restrict__ st)
 {
     __shared__ RejectShared S;
+    if (st && st->stop) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int n = (int)Q;
     if (tid == 0) S.sh[2] = 0;
@@ -891,10 +895,11 @@ __global__ __launch_bounds__(1024) void k_reject(const double *__restrict__ dist
 // instead of paying a copy + stream synchronisation.
 __global__ __launch_bounds__(1024) void k_stats(const double *__restrict__ v, const uint8_t *__restrict__ keep,
                                                 long Q, double *__restrict__ out, const double *__restrict__ also4,
-                                                double *__restrict__ host_out, double seq)
+                                                double *__restrict__ host_out, double seq, const IcpDev *__restrict__ st)
 {
     __shared__ double red[16];
     __shared__ double bc[2];
+    if (st && st->stop) return;
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     double s = 0, n = 0;
     for (long i = tid; i < Q; i += blockDim.x) if (keep[i]) { s += v[i]; n += 1; }
@@ -936,10 +941,11 @@ template <int PHASE>
 __global__ __launch_bounds__(256) void k_stats_mb(const double *__restrict__ v, const uint8_t *__restrict__ keep, long Q,
                                                   double *__restrict__ out, double *__restrict__ partial /*[2][NE_MAX_GRID]*/,
                                                   unsigned *__restrict__ ticket, const double *__restrict__ also4,
-                                                  double *__restrict__ host_out, double seq)
+                                                  double *__restrict__ host_out, double seq, const IcpDev *__restrict__ st)
 {
     __shared__ double red[4][2];
     __shared__ int is_last;
+    if (st && st->stop) return;
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const double mean = PHASE == 1 ? out[1] : 0.0;
     double a = 0, b = 0;
@@ -1321,10 +1327,10 @@ void launch_normals(hipStream_t s, const double *px, const double *py, const dou
 
 void launch_postmatch(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
                       const float *planarity, const double *p2, const int64_t *idx, long Q, const Xf &H,
-                      float min_planarity, const float *pl2, long pl2_n, double *dist, uint8_t *flag)
+                      float min_planarity, const float *pl2, long pl2_n, double *dist, uint8_t *flag, const IcpDev *st)
 {
     hipLaunchKernelGGL(k_postmatch, dim3(cdiv(Q, 256)), dim3(256), 0, s, qx, qy, qz, normals, planarity, p2, idx, Q, H,
-                       min_planarity, pl2, pl2_n, dist, flag);
+                       min_planarity, pl2, pl2_n, dist, flag, st);
 }
 
 void launch_fill_f32(hipStream_t s, float *dst, long n, float v)
@@ -1336,21 +1342,21 @@ void launch_scatter_f32(hipStream_t s, float *dst, const int64_t *rows, const fl
     if (m > 0) hipLaunchKernelGGL(k_scatter_f32, dim3(cdiv(m, 256)), dim3(256), 0, s, dst, rows, vals, m);
 }
 
-void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4)
+void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, const IcpDev *st)
 {
-    hipLaunchKernelGGL(k_reject, dim3(1), dim3(1024), 0, s, dist, flag, Q, keep, out4);
+    hipLaunchKernelGGL(k_reject, dim3(1), dim3(1024), 0, s, dist, flag, Q, keep, out4, st);
 }
 
 void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3, const double *also4,
-                  double *host_out, double seq, double *partial, unsigned *ticket)
+                  double *host_out, double seq, double *partial, unsigned *ticket, const IcpDev *st)
 {
     if (partial && ticket && Q > STATS_MB_MIN_Q) {
         const int g = (int)std::min<long>(NE_MAX_GRID, (Q + 1023) / 1024);
-        hipLaunchKernelGGL(k_stats_mb<0>, dim3(g), dim3(256), 0, s, v, keep, Q, out3, partial, ticket, also4, host_out, seq);
-        hipLaunchKernelGGL(k_stats_mb<1>, dim3(g), dim3(256), 0, s, v, keep, Q, out3, partial, ticket, also4, host_out, seq);
+        hipLaunchKernelGGL(k_stats_mb<0>, dim3(g), dim3(256), 0, s, v, keep, Q, out3, partial, ticket, also4, host_out, seq, st);
+        hipLaunchKernelGGL(k_stats_mb<1>, dim3(g), dim3(256), 0, s, v, keep, Q, out3, partial, ticket, also4, host_out, seq, st);
         return;
     }
-    hipLaunchKernelGGL(k_stats, dim3(1), dim3(1024), 0, s, v, keep, Q, out3, also4, host_out, seq);
+    hipLaunchKernelGGL(k_stats, dim3(1), dim3(1024), 0, s, v, keep, Q, out3, also4, host_out, seq, st);
 }
 
 int ne_grid_for(long count)

@@ -1,0 +1,374 @@
+// sicp_lm.hip -- the Levenberg-Marquardt minimisation of one ICP iteration for Q > SOLVE_MAX_Q, entirely on the
+// device and chained like the small-Q tail (optimization.py:65-124,172-288; simpleicp.py:229-234,356-379):
+//
+//   k_lm_eval    one evaluation of the normal equations at the trial estimate, over many workgroups: every block
+//                stages its rows [a0..a5 | r - shift | 1] in LDS and forms their 8x8 Gram matrix on the FP64 matrix
+//                pipe (v_mfma_f64_16x16x4_f64, A = B), block partials go to memory, and the LAST block to arrive
+//                (agent-scope release / acquire ticket) folds them in a fixed order and advances the solver's state
+//                machine (accept / reject the trial, 6x6 LDL^T step, next trial or done) in device memory;
+//   k_lm_finish  one workgroup: completes the minimisation itself in the rare case the enqueued evaluations did not
+//                (so correctness never depends on how many were enqueued), then residual statistics, the convergence
+//                test, the iteration's record (pinned host memory + ticket) and the next iteration's start.
+//
+// The host enqueues  match, distances, rejection, statistics, k_lm_eval x E, k_lm_finish  per iteration and several
+// iterations ahead; evaluations that find the solver done (or the run over) exit at once.  Nothing waits for the host.
+// Residuals are accumulated relative to a shift (the kept distances' mean) so that their variance comes out of the
+// same pass without cancellation: no separate statistics launches.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sicp_internal.h"
+#include "sicp_lanes.h"
+#include "sicp_solver.h"
+
+namespace sicp {
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int LB = 256;                     // lanes per block, one correspondence per lane and chunk
+
+struct LmShared {
+    double ja[LB][8];                       // this chunk's rows
+    double gp[4][2][64];                    // per-wave Gram blocks
+    double gb[64];                          // this block's Gram (shifted residual column)
+    double G[2][64];                        // last block / finish: accepted and trial Gram, unshifted
+    double sc[16];                          // broadcast scalars
+    int is_last;
+};
+
+// rows of the correspondences  chunk*LB + lane  for chunk = first, first + step, ... < nchunks, their Gram matrix
+// (shifted residual column) summed over the block into S.gb; writes the plain residuals of the trial
+__device__ void block_gram(LmShared &S, const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+                           const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep, long Q,
+                           const double (&x)[6], const double (&sc)[6], double shift, long first, long step, long nchunks,
+                           double *__restrict__ resid_t)
+{
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    double H[12];
+    euler_H(x, sc, H);
+    const double s1 = sc[0], c1 = sc[1], s2 = sc[2], c2 = sc[3];
+    const double w3y = -s1 * c2, w3z = c1 * c2;
+    v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+    for (long ch = first; ch < nchunks; ch += step) {
+        const long i = ch * LB + tid;
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double r = 0.0;
+        if (i < Q && keep[i]) {
+            const double px = p2[3 * i], py = p2[3 * i + 1], pz = p2[3 * i + 2];
+            const float fx = normals[3 * i], fy = normals[3 * i + 1], fz = normals[3 * i + 2];
+            double X, Y, Z;
+            xfm(H, px, py, pz, X, Y, Z);
+            r = pdist(X - qx[i], Y - qy[i], Z - qz[i], fx, fy, fz);
+            const double nx = fx, ny = fy, nz = fz;
+            const double ux = X - x[3], uy = Y - x[4], uz = Z - x[5];          // R p
+            const double cx = uy * nz - uz * ny, cy = uz * nx - ux * nz, cz = ux * ny - uy * nx;   // (R p) x n
+            a[0] = cx;
+            a[1] = c1 * cy + s1 * cz;
+            a[2] = s2 * cx + w3y * cy + w3z * cz;
+            a[3] = nx; a[4] = ny; a[5] = nz;
+            a[6] = r - shift;
+            a[7] = 1.0;
+        }
+        if (i < Q) resid_t[i] = r;
+        __syncthreads();                                  // the previous chunk's rows have been consumed
+        double2 *row = reinterpret_cast<double2 *>(&S.ja[tid][0]);
+        row[0] = make_double2(a[0], a[1]); row[1] = make_double2(a[2], a[3]);
+        row[2] = make_double2(a[4], a[5]); row[3] = make_double2(a[6], a[7]);
+        __syncthreads();
+        // Gram product on the FP64 matrix pipe (layout: see sicp_tail.hip::eval_ne)
+        const double *src = &S.ja[wid * 64 + 4 * ((lane >> 3) & 1) + (lane >> 4)][lane & 7];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double v = src[0], u = src[64];
+            src += 128;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(u, u, acc2, 0, 0, 0);
+        }
+    }
+    acc += acc2;
+    {
+        const int n = lane & 15;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int m = (lane >> 4) + 4 * rg;
+            if ((m >> 3) == (n >> 3)) S.gp[wid][m >> 3][(m & 7) * 8 + (n & 7)] = acc[rg];
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double g = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) g += S.gp[w][0][tid] + S.gp[w][1][tid];
+        S.gb[tid] = g;
+    }
+    __syncthreads();
+}
+
+// The solver's state machine, one transition: the trial's Gram matrix (shifted residual column) is in S.gb.
+// Run by the 64 lanes of wave 0 (uniform values; lane 0 stores the scalars, every lane its Gram entry).
+// Same acceptance rules as the single-launch tail and the host solver.
+__device__ void lm_advance(LmShared &S, LmDev *__restrict__ L, const TailArgs &A, const double *__restrict__ stats, double shift)
+{
+    const int lane = threadIdx.x;                          // caller guarantees threadIdx.x < 64
+    int cur = L->cur;
+    // un-shift the residual column: sum a r = sum a r' + s sum a, sum r = sum r' + s n, sum r^2 = sum r'^2 + 2 s sum r' + n s^2
+    {
+        const double g = S.gb[lane];
+        const int u = lane >> 3, v = lane & 7;
+        const double n = S.gb[7 * 8 + 7], s1r = S.gb[6 * 8 + 7];
+        double out = g;
+        if (v == 6 && u < 6) out = g + shift * S.gb[u * 8 + 7];
+        if (u == 6 && v == 7) out = g + shift * n;
+        if (u == 6 && v == 6) out = g + 2.0 * shift * s1r + n * shift * shift;
+        S.G[cur ^ 1][lane] = out;
+        S.G[cur][lane] = L->G[cur][lane];
+    }
+    const double S1 = S.gb[6 * 8 + 7], S2 = S.gb[6 * 8 + 6];
+    double x[6], sc[6], xt[6], sct[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { x[j] = L->x[j]; sc[j] = L->sc[j]; xt[j] = L->xt[j]; sct[j] = L->sct[j]; }
+    double w = L->w;
+    if (!(w > 0)) { const double dstd = stats[2]; w = 1.0 / (dstd * dstd); }          // simpleicp.py:233-234 (frozen afterwards)
+    double cost = L->cost, lambda = L->lambda, dxmax = L->dxmax;
+    int first = L->first, tries = L->tries, steps = L->steps, evals = L->evals + 1, done = 0;
+    int nfree = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) nfree += (A.ow[j] < __builtin_inf()) ? 1 : 0;
+
+    const double costn = objective(S.G[cur ^ 1], w, xt, A);
+    if (first || costn <= cost * (1 + 1e-12) || dxmax < 1e-15) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { x[j] = xt[j]; sc[j] = sct[j]; }
+        cur ^= 1; cost = costn; tries = 0;
+        L->G[cur][lane] = S.G[cur][lane];
+        if (lane == 0) { L->stat[cur][0] = S1; L->stat[cur][1] = S2; }
+        if (!first) {
+            lambda = lambda > 0 ? lambda * 0.1 : 0.0;
+            if (lambda < 1e-12) lambda = 0.0;
+            ++steps;
+            double xmax = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) xmax = fmax(xmax, fabs(x[j]));
+            if (dxmax <= 1e-13 * (1.0 + xmax)) done = 1;
+        }
+        first = 0;
+        if (steps >= A.max_steps || nfree == 0) done = 1;
+    } else {
+        lambda = lambda > 0 ? lambda * 10 : 1e-6;
+        if (++tries >= 40) done = 1;
+    }
+    if (!done) {
+        bool ok = false;
+        double dstep[6];
+        for (; tries < 40; ++tries) {
+            ok = lm_step(S.G[cur], w, x, lambda, A, dstep);
+            dxmax = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { xt[j] = x[j] + dstep[j]; dxmax = fmax(dxmax, fabs(dstep[j])); }
+            ok = ok && (dxmax < __builtin_inf());
+            if (ok) break;
+            lambda = lambda > 0 ? lambda * 10 : 1e-6;
+        }
+        double xm = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) xm = fmax(xm, fabs(x[j]));
+        if (!ok) done = 1;
+        else if (lambda == 0.0 && dxmax <= 1e-10 * (1.0 + xm)) done = 1;      // x is the minimiser to 1e-10 (the reference stops at 1e-8)
+        else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sincos_step(xt[j], dstep[j], sc[2 * j], sc[2 * j + 1], sct[2 * j], sct[2 * j + 1]);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { L->x[j] = x[j]; L->sc[j] = sc[j]; L->xt[j] = xt[j]; L->sct[j] = sct[j]; }
+        L->w = w; L->cost = cost; L->lambda = lambda; L->dxmax = dxmax; L->shift = shift;
+        L->cur = cur; L->first = first; L->tries = tries; L->steps = steps; L->evals = evals; L->done = done;
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(LB) void k_lm_eval(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+    const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep, long Q, TailArgs A,
+    const IcpDev *__restrict__ st, LmDev *__restrict__ L, const double *__restrict__ stats /* n, mean, std of the kept distances */,
+    double *__restrict__ partial /* [gridDim.x][64] */, unsigned *__restrict__ ticket, double *__restrict__ resid0,
+    double *__restrict__ resid1)
+{
+    __shared__ LmShared S;
+    if (st->stop || L->done || stats[0] < 6.0) return;             // uniform: run over / solver finished / too few correspondences
+    const int tid = threadIdx.x;
+    double x[6], sc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { x[j] = L->xt[j]; sc[j] = L->sct[j]; }
+    const int slot = L->cur ^ 1;
+    const double shift = L->first ? stats[1] : L->shift;
+    const long nchunks = (Q + LB - 1) / LB;
+    block_gram(S, qx, qy, qz, normals, p2, keep, Q, x, sc, shift, blockIdx.x, gridDim.x, nchunks, slot ? resid1 : resid0);
+    if (tid < 64) partial[(long)blockIdx.x * 64 + tid] = S.gb[tid];
+    // publish this block's partial, then take a ticket (stores -> vmcnt(0) -> barrier -> one-lane agent release ->
+    // ticket; last arriver: agent acquire -> plain loads)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        S.is_last = (t == gridDim.x - 1) ? 1 : 0;
+        if (S.is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!S.is_last) return;
+    // fold the block partials: lane t sums entry t over the blocks, four independent chains (fixed order for a given grid)
+    if (tid < 64) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        unsigned b = 0;
+        for (; b + 4 <= gridDim.x; b += 4) {
+            s0 += partial[(long)b * 64 + tid]; s1 += partial[(long)(b + 1) * 64 + tid];
+            s2 += partial[(long)(b + 2) * 64 + tid]; s3 += partial[(long)(b + 3) * 64 + tid];
+        }
+        for (; b < gridDim.x; ++b) s0 += partial[(long)b * 64 + tid];
+        S.gb[tid] = (s0 + s1) + (s2 + s3);
+        if (tid == 0) *ticket = 0;                          // re-arm for the next launch on this stream
+        lm_advance(S, L, A, stats, shift);
+    }
+}
+
+// One workgroup.  rj4: (m, median, mad, n_kept) of the rejection; stats: (n, mean, std) of the kept distances.
+__global__ __launch_bounds__(LB) void k_lm_finish(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+    const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep, long Q, TailArgs A,
+    IcpDev *__restrict__ st, LmDev *__restrict__ L, const double *__restrict__ rj4, const double *__restrict__ stats,
+    double *__restrict__ resid0, double *__restrict__ resid1, double *__restrict__ rec)
+{
+    __shared__ LmShared S;
+    __shared__ double out[64];
+    const int tid = threadIdx.x;
+    if (tid < 64) out[tid] = 0.0;
+    if (st->stop) {
+        if (tid == 0) {
+            rec[REC_STATUS] = 3.0;
+            __threadfence_system();
+            __hip_atomic_store(rec + REC_TICKET, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    const double nk = stats[0];
+    const bool too_few = nk < 6.0;
+    // the enqueued evaluations normally finish the minimisation; if they did not, finish it here (one workgroup over
+    // all correspondences per evaluation: slow, rare, and it keeps the result independent of how many were enqueued)
+    if (!too_few) {
+        const long nchunks = (Q + LB - 1) / LB;
+        while (!__hip_atomic_load(&L->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            double x[6], sc[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { x[j] = L->xt[j]; sc[j] = L->sct[j]; }
+            const int slot = L->cur ^ 1;
+            const double shift = L->first ? stats[1] : L->shift;
+            block_gram(S, qx, qy, qz, normals, p2, keep, Q, x, sc, shift, 0, 1, nchunks, slot ? resid1 : resid0);
+            if (tid < 64) lm_advance(S, L, A, stats, shift);
+            __threadfence();
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    // ---- wave 0: residual statistics, convergence test, record, next iteration's start ----
+    const int cur = L->cur;
+    double x[6], sc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { x[j] = too_few ? st->x[j] : L->x[j]; sc[j] = too_few ? st->sc[j] : L->sc[j]; }
+    const double gn = L->G[cur][7 * 8 + 7], S1 = L->stat[cur][0], S2 = L->stat[cur][1];
+    const double rmean = L->shift + S1 / gn;
+    const double rvar = (S2 - S1 * S1 / gn) / gn;
+    const double rstd = sqrt(rvar > 0.0 ? rvar : 0.0);
+    const double cost = L->cost, w = L->w;
+    const bool finite = too_few || cost < __builtin_inf();
+    const int done_iters = st->done_iters;
+    bool conv = false;
+    if (!too_few && A.min_change >= 0.0 && done_iters > 0 && finite) {
+        const double pm = st->prev_mean, ps = st->prev_std;
+        const double cm = pm == 0.0 ? (rmean == 0.0 ? 0.0 : __builtin_inf()) : fabs((rmean - pm) / pm * 100.0);
+        const double cs = ps == 0.0 ? (rstd == 0.0 ? 0.0 : __builtin_inf()) : fabs((rstd - ps) / ps * 100.0);
+        conv = cm < A.min_change && cs < A.min_change;
+    }
+    if (tid < 30 && !too_few) {
+        int u = 0, v = 0;
+        if (tid < 21) { int t = tid; while (t >= 6 - u) { t -= 6 - u; ++u; } v = u + t; }
+        else if (tid < 27) { u = tid - 21; v = 6; }
+        else if (tid == 27) { u = 6; v = 7; }
+        else if (tid == 28) { u = 6; v = 6; }
+        else { u = 7; v = 7; }
+        out[20 + tid] = L->G[cur][u * 8 + v];
+    }
+    if (tid == 0) {
+        out[0] = rj4[0]; out[1] = rj4[1]; out[2] = rj4[2]; out[3] = rj4[3]; out[4] = stats[1]; out[5] = stats[2];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) out[10 + j] = x[j];
+        if (too_few) out[REC_STATUS] = 1.0;
+        else {
+            out[6] = w; out[7] = cost; out[8] = L->steps; out[9] = L->evals;
+            out[16] = rmean; out[17] = rstd;
+            out[REC_STATUS] = finite ? 0.0 : 2.0;
+            out[REC_CONVERGED] = conv ? 1.0 : 0.0;
+            out[REC_RESID_SLOT] = cur;
+        }
+    }
+    rec[tid] = out[tid];                                   // (tid < 64; the ticket word is overwritten last, below)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+        __threadfence_system();
+        __hip_atomic_store(rec + REC_TICKET, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // the next iteration's start
+        if (too_few || !finite) { st->stop = 1; }
+        else {
+            double Hn[12];
+            euler_H(x, sc, Hn);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { st->x[j] = x[j]; st->sc[j] = sc[j]; }
+#pragma unroll
+            for (int j = 0; j < 12; ++j) st->H.m[j] = Hn[j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) st->Hinv.m[4 * i + j] = Hn[4 * j + i];
+                st->Hinv.m[4 * i + 3] = -(Hn[i] * Hn[3] + Hn[4 + i] * Hn[7] + Hn[8 + i] * Hn[11]);
+            }
+            st->w = w; st->prev_mean = rmean; st->prev_std = rstd;
+            st->done_iters = done_iters + 1;
+            if (conv) st->stop = 1;
+            // and the solver's: trial = the new estimate, always accepted
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { L->xt[j] = x[j]; L->sct[j] = sc[j]; }
+            L->w = w; L->cost = 0.0; L->lambda = 0.0; L->dxmax = 0.0;
+            L->first = 1; L->tries = 0; L->steps = 0; L->evals = 0; L->done = 0;
+        }
+    }
+}
+
+int lm_eval_grid(long Q)
+{
+    long g = (Q + LB - 1) / LB;
+    if (g < 1) g = 1;
+    if (g > NE_MAX_GRID) g = NE_MAX_GRID;
+    return (int)g;
+}
+
+void launch_lm_eval(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
+                    const uint8_t *keep, long Q, const TailArgs &A, const IcpDev *st, LmDev *L, const double *stats, double *partial,
+                    unsigned *ticket, double *resid0, double *resid1)
+{
+    hipLaunchKernelGGL(k_lm_eval, dim3(lm_eval_grid(Q)), dim3(LB), 0, s, qx, qy, qz, normals, p2, keep, Q, A, st, L, stats, partial,
+                       ticket, resid0, resid1);
+}
+
+void launch_lm_finish(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
+                      const uint8_t *keep, long Q, const TailArgs &A, IcpDev *st, LmDev *L, const double *rj4, const double *stats,
+                      double *resid0, double *resid1, double *rec)
+{
+    hipLaunchKernelGGL(k_lm_finish, dim3(1), dim3(LB), 0, s, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, resid0, resid1, rec);
+}
+
+}  // namespace sicp
