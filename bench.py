@@ -128,6 +128,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=2)
+    ap.add_argument("--partition", choices=["auto", "cloud", "queries"], default="auto",
+                    help="N > 1: shard the movable cloud (north-star scheme, default below 1e5 correspondences) or the "
+                         "queries (cloud replicated, default from 1e5 correspondences)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="register the multi-GPU exchange even with one rank (measures its overhead on one GPU)")
     ap.add_argument("--out", type=str, default=None, help="also write the JSON line to this file")
@@ -182,15 +185,18 @@ def run(args):
 
     Xf, Xm, H_true, Q, k, kw, desc = load_workload(args.config, args.points, args.correspondences)
     Nf, Nm = len(Xf), len(Xm)
+    qshard = exchange and (args.partition == "queries" or (args.partition == "auto" and Q >= 100_000))
     ctx = _lib.Context(local_rank)
     setup = {}
     t0 = time.perf_counter()
     ctx.upload(_lib.FIX, Xf)
-    lo, hi = dist.shard_bounds(Nm, rank, world)
+    lo, hi = (0, Nm) if qshard else dist.shard_bounds(Nm, rank, world)
     ctx.upload(_lib.MOV, Xm[lo:hi], index_base=lo)
     setup["upload_ms"] = (time.perf_counter() - t0) * 1e3
+    transport = None
     if exchange:
-        ctx.set_exchange(dist.make_exchange(ctx), rank, world, gn_shard=Q >= 262144)
+        transport = dist.attach(ctx, gn_shard=(not qshard) and Q >= 262144,
+                                partition=_lib.PART_QUERIES if qshard else _lib.PART_CLOUD)
 
     # selection: partial-overlap pre-pass (simpleicp.py:155-170) + select_n_points (pointcloud.py:132-147)
     sel = np.arange(Nf)
@@ -276,6 +282,10 @@ def run(args):
 
     H = _lib.params_to_H(x)
     n_local, nq = hi - lo, len(sel)
+    if qshard:
+        nq_local = (nq + world - 1) // world                     # queries this rank's match launch handles
+    else:
+        nq_local = nq
     avg = {kname: v["ms"] / max(1, v["launches"]) for kname, v in timing.items()}
     match_ms, solve_ms, select_ms = avg["match"], avg["solve"], avg["reject_select"]
     fused = nq <= 2048
@@ -340,7 +350,9 @@ def run(args):
         "data": "synthetic" if H_true is not None else "bundled reference data sets (tests/golden/data)",
         "config": {"workload": f"{desc}, correspondences={Q}, neighbors={k}, exact 1-NN (bit-identical to brute force)",
                    "name": args.config, "n_fixed": Nf, "n_movable": Nm, "correspondences": nq, "neighbors": k,
-                   "parallelism": f"movable-cloud index shards x{world}, queries replicated"},
+                   "parallelism": (f"query shards x{world}, movable cloud replicated" if qshard else
+                                   f"movable-cloud index shards x{world}, queries replicated")
+                                  + (f"; collectives: {transport}" if transport else "")},
         "correspondences_per_s": nq * args.steps / elapsed,
         "repeat_stats": {"repeats": len(times), "ms_per_step_median": elapsed / args.steps * 1e3,
                          "ms_per_step_p10": float(np.percentile(times, 10)) / args.steps * 1e3,

@@ -180,7 +180,7 @@ int sicp_icp_normal_equations(sicp_ctx *ctx, const double x[6], double out[30]);
 int sicp_params_to_H(const double x[6], double H_out[16]);
 
 /* ---- multi-GPU exchange hook (one process per GPU; collectives supplied by the host) -- */
-/* The library never links RCCL: the host binding (torch.distributed over RCCL/xGMI in
+/* Variant 1 -- collectives supplied by the host: the host binding (torch.distributed over RCCL/xGMI in
  * simpleicp_amd/dist.py) registers a callback the iteration calls at its exchange points.
  * All pointers handed to the callback are DEVICE pointers owned by the ctx.  The callback must either
  * ENQUEUE the collective in order on the library's stream (sicp_ctx_stream; e.g. under
@@ -199,6 +199,25 @@ typedef int (*sicp_exchange_fn)(void *user, int what, void *a, void *b, void *c,
  * gn_shard: 0 = every rank reduces all correspondences (no collective in the solver),
  *           1 = rank r reduces slice r of the correspondences + SUM exchange per step.   */
 int sicp_set_exchange(sicp_ctx *ctx, sicp_exchange_fn fn, void *user, int rank, int world, int gn_shard);
+/* The same exchange issued by the library itself: one RCCL communicator per ctx (one process per GPU), collectives
+ * enqueued on the ctx's stream between its kernels -- no host callback, nothing blocks (SURVEY 8b `sicp_comm_init`).
+ * librccl is loaded on demand; it is not a link-time dependency.
+ *   sicp_comm_unique_id : rank 0 obtains the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any
+ *                         transport (simpleicp_amd/dist.py broadcasts it over torch.distributed);
+ *   sicp_comm_init      : collective over all ranks (ncclCommInitRank); replaces a registered callback;
+ *   sicp_comm_destroy   : back to single-GPU behaviour. */
+int sicp_comm_unique_id(void *id128);
+int sicp_comm_init(sicp_ctx *ctx, const void *id128, int rank, int world, int gn_shard);
+int sicp_comm_destroy(sicp_ctx *ctx);
+/* What the ranks shard:
+ *   SICP_PART_CLOUD   (default) every rank holds a contiguous index range of the searched cloud and all Q queries; one
+ *                     all-gather of per-query winners + lexicographic minimum per iteration;
+ *   SICP_PART_QUERIES every rank holds the WHOLE searched cloud (index_base 0) and matches Q / world of the queries;
+ *                     one all-gather of the slices per iteration, no reduction.  Pays off when the match dominates
+ *                     (Q >= ~1e5); needs the default grid search.  sicp_knn / sicp_select_in_range are then local. */
+#define SICP_PART_CLOUD   0
+#define SICP_PART_QUERIES 1
+int sicp_set_partition(sicp_ctx *ctx, int mode);
 /* the HIP stream (hipStream_t) every kernel and copy of this ctx is issued on */
 int sicp_ctx_stream(sicp_ctx *ctx, void **stream_out);
 

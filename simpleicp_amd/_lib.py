@@ -17,6 +17,7 @@ LIB_PATH = PKG / "libsimpleicp_hip.so"
 FIX, MOV = 0, 1
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_TOO_FEW, ERR_NUMERIC, ERR_EXCHANGE = 0, -1, -2, -3, -4, -5, -6
 XCHG_ALLGATHER_F64, XCHG_SUM_F64 = 1, 2
+PART_CLOUD, PART_QUERIES = 0, 1
 K_KNN1, K_KNNK, K_NORMALEQ, K_SELECT = 0, 1, 2, 3
 KERNEL_NAMES = {K_KNN1: "match", K_KNNK: "knnk_scan", K_NORMALEQ: "solve", K_SELECT: "reject_select"}
 MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1_frec"}
@@ -26,7 +27,7 @@ EXPORTS = [
     "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_upload_columns", "sicp_cloud_size", "sicp_cloud_transform",
     "sicp_cloud_download", "sicp_cloud_set_planarity", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
-    "sicp_set_exchange", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_last_match_kernel",
+    "sicp_set_exchange", "sicp_comm_unique_id", "sicp_comm_init", "sicp_comm_destroy", "sicp_set_partition", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_last_match_kernel",
     "sicp_xyz_count", "sicp_xyz_read", "sicp_xyz_write",
 ]
 
@@ -97,6 +98,10 @@ def load():
     L.sicp_icp_normal_equations.argtypes = [vp, vp, vp]
     L.sicp_params_to_H.argtypes = [vp, vp]
     L.sicp_set_exchange.argtypes = [vp, EXCHANGE_FN, vp, cint, cint, cint]
+    L.sicp_comm_unique_id.argtypes = [vp]
+    L.sicp_comm_init.argtypes = [vp, vp, cint, cint, cint]
+    L.sicp_comm_destroy.argtypes = [vp]
+    L.sicp_set_partition.argtypes = [vp, cint]
     L.sicp_ctx_stream.argtypes = [vp, C.POINTER(vp)]
     L.sicp_lexmin_gathered.argtypes = [vp, vp, cint, i64, vp, vp, vp]
     L.sicp_timing_enable.argtypes = [vp, cint]
@@ -338,6 +343,31 @@ class Context:
                     return 1
             self._cb = EXCHANGE_FN(tramp)
         self._chk(self._L.sicp_set_exchange(self._h, self._cb, None, int(rank), int(world), int(bool(gn_shard))))
+
+    # -- the library's own RCCL communicator (no host callback) --
+    @staticmethod
+    def comm_unique_id():
+        """128-byte ncclUniqueId (rank 0 creates it, every rank passes the same bytes to comm_init)."""
+        buf = C.create_string_buffer(128)
+        L = load()
+        rc = L.sicp_comm_unique_id(buf)
+        if rc != OK:
+            raise BackendError(L.sicp_last_error().decode(), rc)
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world, gn_shard=False):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        self._cb = None
+        self._chk(self._L.sicp_comm_init(self._h, C.c_char_p(bytes(unique_id)), int(rank), int(world), int(bool(gn_shard))))
+
+    def comm_destroy(self):
+        self._chk(self._L.sicp_comm_destroy(self._h))
+
+    def set_partition(self, mode):
+        """PART_CLOUD: ranks hold index ranges of the searched cloud; PART_QUERIES: ranks hold the whole cloud and
+        match a slice of the queries each."""
+        self._chk(self._L.sicp_set_partition(self._h, int(mode)))
 
     def lexmin_gathered(self, gathered):
         """gathered: (world, Q, 5) float64 records (d2, idx bits, x, y, z) -> (d2, idx, xyz)."""

@@ -3,6 +3,8 @@
 // that the fused GPU reductions feed.  No CPU compute fallback exists: without a gfx950 device
 // sicp_ctx_create fails with SICP_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>          // types and prototypes only: librccl is loaded on demand (sicp_comm_init), never linked
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -107,6 +109,37 @@ struct Cloud {
     double *y() { return xyz.p + npad; }
     double *z() { return xyz.p + 2 * npad; }
 };
+
+// RCCL entry points, resolved the first time a communicator is asked for (single-GPU users never load the library)
+struct Rccl {
+    void *h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl *rccl()
+{
+    static Rccl R;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) { R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (R.h) break; }
+        if (R.h) {
+            R.GetUniqueId = (decltype(R.GetUniqueId))dlsym(R.h, "ncclGetUniqueId");
+            R.CommInitRank = (decltype(R.CommInitRank))dlsym(R.h, "ncclCommInitRank");
+            R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.h, "ncclCommDestroy");
+            R.AllGather = (decltype(R.AllGather))dlsym(R.h, "ncclAllGather");
+            R.AllReduce = (decltype(R.AllReduce))dlsym(R.h, "ncclAllReduce");
+            R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.h, "ncclGetErrorString");
+            if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather || !R.AllReduce || !R.GetErrorString) R.h = nullptr;
+        }
+    }
+    return R.h ? &R : nullptr;
+}
 
 struct EventPair { hipEvent_t a, b; int kernel; };
 constexpr int REC_RING = 16;     // records in flight + being read
@@ -241,10 +274,13 @@ struct sicp_ctx {
     double *h_rec = nullptr;       // pinned ring of per-iteration records the tail kernel streams to the host
     IcpDev *h_state = nullptr;     // pinned staging of the loop state
     int chain_depth = 4;           // iterations enqueued ahead of the last record read (SICP_CHAIN_DEPTH)
-    // exchange
+    // exchange: an RCCL communicator of the library's own (sicp_comm_init) or a host callback (sicp_set_exchange)
     sicp_exchange_fn xfn = nullptr;
     void *xuser = nullptr;
+    ncclComm_t comm = nullptr;
     int rank = 0, world = 1, gn_shard = 0;
+    int partition = SICP_PART_CLOUD;   // what is sharded over the ranks: the searched cloud or the queries
+    bool collective() const { return xfn != nullptr || comm != nullptr; }
     // timing
     bool timing = false;
     bool count_work = false;       // sicp_timing_enable(ctx, 2): the grid search also tallies its candidates / rows
@@ -328,17 +364,63 @@ struct Timed {
 
 // job-wide winner per query: pack (d2, idx, xyz) records, all-gather through the host's callback
 // (torch.distributed over RCCL), reduce lexicographically on the device -- one collective per call
+// recv[world][count] <- every rank's send[count], enqueued in order on the library's stream
+int all_gather_f64(sicp_ctx *c, double *send, double *recv, long count)
+{
+    if (c->comm) {
+        const ncclResult_t r = rccl()->AllGather(send, recv, (size_t)count, ncclDouble, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(SICP_ERR_EXCHANGE, "ncclAllGather failed: %s", rccl()->GetErrorString(r));
+        return SICP_OK;
+    }
+    // no host wait: the callback enqueues the collective in order on this stream (or synchronises itself)
+    if (c->xfn(c->xuser, SICP_XCHG_ALLGATHER_F64, send, recv, nullptr, count) != 0)
+        return fail(SICP_ERR_EXCHANGE, "exchange callback (ALLGATHER_F64) failed");
+    return SICP_OK;
+}
+int all_reduce_sum_f64(sicp_ctx *c, double *buf, long count)
+{
+    if (c->comm) {
+        const ncclResult_t r = rccl()->AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(SICP_ERR_EXCHANGE, "ncclAllReduce failed: %s", rccl()->GetErrorString(r));
+        return SICP_OK;
+    }
+    if (c->xfn(c->xuser, SICP_XCHG_SUM_F64, buf, nullptr, nullptr, count) != 0)
+        return fail(SICP_ERR_EXCHANGE, "exchange callback (SUM_F64) failed");
+    return SICP_OK;
+}
+
+// cloud shards: job-wide winner per query = lexicographic minimum over the ranks' local winners
 int exchange_best(sicp_ctx *c, double *d2, int64_t *idx, double *p2, long Q)
 {
-    if (!c->xfn) return SICP_OK;
+    if (!c->collective() || c->partition != SICP_PART_CLOUD) return SICP_OK;
     CHK(c->x_send.reserve((size_t)5 * Q));
     CHK(c->x_recv.reserve((size_t)5 * Q * c->world));
     launch_pack_best(c->stream, d2, idx, p2, Q, c->x_send.p);
     HIPCHK(hipGetLastError());
-    // no host wait: the callback enqueues the collective in order on this stream (or synchronises itself)
-    if (c->xfn(c->xuser, SICP_XCHG_ALLGATHER_F64, c->x_send.p, c->x_recv.p, nullptr, 5 * Q) != 0)
-        return fail(SICP_ERR_EXCHANGE, "exchange callback (ALLGATHER_F64) failed");
+    CHK(all_gather_f64(c, c->x_send.p, c->x_recv.p, 5 * Q));
     launch_lexmin_gathered(c->stream, c->x_recv.p, c->world, Q, d2, idx, p2);
+    HIPCHK(hipGetLastError());
+    return SICP_OK;
+}
+
+// query shards (cloud replicated): rank r matched queries [r * per, (r + 1) * per); the slices are gathered in rank
+// order, which IS query order, so every rank ends up with all Q results
+long query_slice(const sicp_ctx *c, long Q, long *lo)
+{
+    const long per = (Q + c->world - 1) / c->world;
+    *lo = std::min<long>(Q, per * c->rank);
+    return std::min<long>(Q, *lo + per) - *lo;
+}
+int exchange_query_slices(sicp_ctx *c, double *d2, int64_t *idx, double *p2, long Q)
+{
+    const long per = (Q + c->world - 1) / c->world;
+    long lo; const long cnt = query_slice(c, Q, &lo);
+    CHK(c->x_send.reserve((size_t)5 * per));
+    CHK(c->x_recv.reserve((size_t)5 * per * c->world));
+    if (cnt > 0) launch_pack_best(c->stream, d2 + lo, idx + lo, p2 + 3 * lo, cnt, c->x_send.p);
+    HIPCHK(hipGetLastError());
+    CHK(all_gather_f64(c, c->x_send.p, c->x_recv.p, 5 * per));
+    launch_lexmin_gathered(c->stream, c->x_recv.p, 1, Q, d2, idx, p2);     // world = 1: a plain unpack of the Q records
     HIPCHK(hipGetLastError());
     return SICP_OK;
 }
@@ -713,7 +795,7 @@ int normal_eq_host(sicp_ctx *c, const double x[6], bool write_resid, bool allow_
     params_to_H12(x, H12);
     euler_dR(x, dR);
     long lo = 0, hi = c->Q;
-    const bool shard = allow_shard && c->gn_shard && c->xfn;
+    const bool shard = allow_shard && c->gn_shard && c->collective();
     if (shard) {
         const long per = (c->Q + c->world - 1) / c->world;
         lo = std::min<long>(c->Q, per * c->rank);
@@ -734,10 +816,7 @@ int normal_eq_host(sicp_ctx *c, const double x[6], bool write_resid, bool allow_
         std::memcpy(out, h_ne, 30 * sizeof(double));
         return SICP_OK;
     }
-    if (shard) {
-        if (c->xfn(c->xuser, SICP_XCHG_SUM_F64, d_out, nullptr, nullptr, 30) != 0)
-            return fail(SICP_ERR_EXCHANGE, "exchange callback (SUM_F64) failed");
-    }
+    if (shard) CHK(all_reduce_sum_f64(c, d_out, 30));
     HIPCHK(hipMemcpyAsync(c->h_small + 8, d_out, 30 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     CHK(sync(c));
     std::memcpy(out, c->h_small + 8, 30 * sizeof(double));
@@ -818,6 +897,7 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     if (!c) return SICP_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { (void)rccl()->CommDestroy(c->comm); c->comm = nullptr; }
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &cl : c->cloud) { cl.xyz.release(); cl.pl.release(); cl.grid.cell_start.release(); cl.grid.rec.release(); }
@@ -1136,7 +1216,7 @@ int check_iter_args(sicp_ctx *c, const sicp_iter_params *P)
 }
 
 // does this configuration run the single-launch tail (sicp_tail.hip) with the loop state on the device?
-bool device_tail(const sicp_ctx *c) { return !(c->gn_shard && c->xfn) && c->solve_mode != 2; }
+bool device_tail(const sicp_ctx *c) { return !(c->gn_shard && c->collective()) && c->solve_mode != 2; }
 
 // ---- iterations enqueued back to back, loop state on the device --------------------------------------------------
 // Q <= SOLVE_MAX_Q: match + ONE tail launch per iteration (sicp_tail.hip).  Larger Q: match, distances, rejection,
@@ -1200,12 +1280,21 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
         while (launched < max_it && launched - completed < depth && !over) {
             const auto h0 = std::chrono::steady_clock::now();
             const double *prev = c->have_prev_match ? c->m_p2.p : nullptr;
+            const bool qshard = c->collective() && c->partition == SICP_PART_QUERIES;
             if (grid) {
+                // (query shards: this rank searches its slice of the queries in the whole cloud, results land in
+                // their place in the full arrays)
+                long lo = 0, cnt = Q;
+                if (qshard) cnt = query_slice(c, Q, &lo);
                 c->last_match_kernel = 2;
                 Timed t(c, SICP_K_KNN1);
-                launch_grid_nn_chained(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, Q, prev, cl.grid.g,
-                                       cl.grid.cell_start.p, cl.grid.rec.p, c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p,
-                                       c->m_idx.p, c->m_p2.p, c->count_work ? c->match_work.p : nullptr);
+                if (cnt > 0)
+                    launch_grid_nn_chained(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt,
+                                           prev ? prev + 3 * lo : nullptr, cl.grid.g, cl.grid.cell_start.p, cl.grid.rec.p,
+                                           c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo, c->m_p2.p + 3 * lo,
+                                           c->count_work ? c->match_work.p : nullptr);
+            } else if (qshard) {
+                return fail(SICP_ERR_INVALID, "query shards need the grid search (SICP_KNN1 forces another kernel)");
             } else {
                 // brute-force flavours take H by value: one iteration in flight, H from the last record
                 params_to_H12(xcur, H12);
@@ -1215,7 +1304,8 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
             }
             HIPCHK(hipGetLastError());
             c->have_prev_match = true;          // (after an exchange: the job-wide winner's coordinates -- still a valid bound)
-            CHK(exchange_best(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
+            if (qshard) CHK(exchange_query_slices(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
+            else CHK(exchange_best(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
             A.seq = (double)(++c->solve_seq);
             seqs[launched % REC_RING] = A.seq;
             double *rec = c->h_rec + (launched % REC_RING) * REC_DOUBLES;
@@ -1525,7 +1615,59 @@ SICP_EXPORT int sicp_set_exchange(sicp_ctx *c, sicp_exchange_fn fn, void *user, 
     if (!c) return fail(SICP_ERR_INVALID, "null ctx");
     if (world < 1 || rank < 0 || rank >= world) return fail(SICP_ERR_INVALID, "bad rank/world");
     if (world > 1 && !fn) return fail(SICP_ERR_INVALID, "world > 1 needs an exchange callback");
+    if (c->comm) CHK(sicp_comm_destroy(c));                // a callback replaces the library's own communicator
     c->xfn = fn; c->xuser = user; c->rank = rank; c->world = world; c->gn_shard = gn_shard ? 1 : 0;
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(SICP_ERR_INVALID, "null argument");
+    Rccl *R = rccl();
+    if (!R) return fail(SICP_ERR_EXCHANGE, "librccl could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+    ncclUniqueId id;
+    const ncclResult_t r = R->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(SICP_ERR_EXCHANGE, "ncclGetUniqueId failed: %s", R->GetErrorString(r));
+    static_assert(sizeof id == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, sizeof id);
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_comm_destroy(sicp_ctx *c)
+{
+    if (!c) return fail(SICP_ERR_INVALID, "null ctx");
+    if (c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)rccl()->CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    if (!c->xfn) { c->rank = 0; c->world = 1; c->gn_shard = 0; }
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_comm_init(sicp_ctx *c, const void *id128, int rank, int world, int gn_shard)
+{
+    if (!c || !id128) return fail(SICP_ERR_INVALID, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(SICP_ERR_INVALID, "bad rank/world");
+    Rccl *R = rccl();
+    if (!R) return fail(SICP_ERR_EXCHANGE, "librccl could not be loaded");
+    CHK(sicp_comm_destroy(c));
+    HIPCHK(hipSetDevice(c->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    const ncclResult_t r = R->CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) { c->comm = nullptr; return fail(SICP_ERR_EXCHANGE, "ncclCommInitRank failed: %s", R->GetErrorString(r)); }
+    c->xfn = nullptr; c->xuser = nullptr;
+    c->rank = rank; c->world = world; c->gn_shard = gn_shard ? 1 : 0;
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_set_partition(sicp_ctx *c, int mode)
+{
+    if (!c) return fail(SICP_ERR_INVALID, "null ctx");
+    if (mode != SICP_PART_CLOUD && mode != SICP_PART_QUERIES) return fail(SICP_ERR_INVALID, "mode must be SICP_PART_CLOUD or SICP_PART_QUERIES");
+    c->partition = mode;
     return SICP_OK;
 }
 

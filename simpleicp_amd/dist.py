@@ -116,6 +116,58 @@ def allgather_into(recv, send, group=None):
     return recv
 
 
+def attach(ctx, gn_shard=False, partition=None, group=None):
+    """Give `ctx` the job's collectives.  Default: the library's OWN RCCL communicator -- rank 0's ncclUniqueId is
+    broadcast over the existing torch.distributed group and every rank calls sicp_comm_init; all-gather / all-reduce
+    are then enqueued by the library on its stream between its kernels, no Python in the loop.  SICP_XCHG=callback
+    (or a group without GPUs) registers the torch.distributed callback of `make_exchange` instead.
+    Returns "rccl" or "callback"."""
+    import os
+    import torch.distributed as td
+    rank, world = td.get_rank(group), td.get_world_size(group)
+    if partition is not None:
+        ctx.set_partition(partition)
+    if os.environ.get("SICP_XCHG", "rccl") != "callback":
+        box = [ctx.comm_unique_id() if rank == 0 else None]
+        td.broadcast_object_list(box, src=td.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ctx.comm_init(box[0], rank, world, gn_shard=gn_shard)
+        return "rccl"
+    ctx.set_exchange(make_exchange(ctx, group), rank, world, gn_shard=gn_shard)
+    return "callback"
+
+
+def detach(ctx):
+    """Back to single-GPU behaviour (the exchange lives on the process-wide context)."""
+    ctx.comm_destroy()
+    ctx.set_exchange(None, 0, 1)
+    ctx.set_partition(_lib.PART_CLOUD)
+
+
+def exchange_query_slices(d2, idx, xyz, group=None):
+    """Query-sharded mode in torch ops (the reference the tests hold the library's path against): rank r matched the
+    queries [r * per, (r + 1) * per), per = ceil(Q / world); gathering the slices in rank order restores query order.
+    In place on the full-size (Q) tensors."""
+    import torch
+    import torch.distributed as td
+    world, rank = td.get_world_size(group), td.get_rank(group)
+    Q = d2.shape[0]
+    per = (Q + world - 1) // world
+    lo = min(Q, per * rank)
+    hi = min(Q, lo + per)
+
+    def gather(t, fill):
+        pad = torch.full((per,) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=t.device)
+        pad[: hi - lo] = t[lo:hi]
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        td.all_gather(parts, pad, group=group)
+        return torch.cat(parts)[:Q]
+
+    d2.copy_(gather(d2, float("inf")))
+    idx.copy_(gather(idx, -1))
+    xyz.copy_(gather(xyz, 0.0))
+    return d2, idx, xyz
+
+
 def make_exchange(ctx, group=None, synchronous=None):
     """Callback for Context.set_exchange.  The library hands over DEVICE pointers it owns (stable
     across iterations, so the zero-copy tensor views are cached) and reduces the gathered records

@@ -111,25 +111,30 @@ class SimpleICP:
         n_search = len(msel) if partial else pc2.num_points
         rank, world = dist.rank_world() if sharded else (0, 1)
 
+        # what the ranks shard: index ranges of the movable cloud by default; the QUERIES (cloud
+        # replicated on every rank) when the match dominates, i.e. for large correspondence counts
+        qshard = sharded and (os.environ.get("SICP_PARTITION", "") == "queries"
+                              or (os.environ.get("SICP_PARTITION", "") != "cloud" and correspondences >= 100_000))
+
         def upload_movable(rows=None):
             n = pc2.num_points if rows is None else len(rows)
-            lo, hi = dist.shard_bounds(n, rank, world)
+            lo, hi = (0, n) if qshard else dist.shard_bounds(n, rank, world)
             pc2._upload(ctx, _lib.MOV, lo, hi, index_base=lo, rows=rows)
 
         upload_movable()
         if sharded:
-            ctx.set_exchange(dist.make_exchange(ctx), rank, world,
-                             gn_shard=correspondences >= 262144 or os.environ.get("SICP_GN_SHARD") == "1")
+            dist.attach(ctx, gn_shard=(not qshard) and (correspondences >= 262144 or os.environ.get("SICP_GN_SHARD") == "1"),
+                        partition=_lib.PART_QUERIES if qshard else _lib.PART_CLOUD)
         else:
-            ctx.set_exchange(None, 0, 1)
+            dist.detach(ctx)
         try:
             return self._run_uploaded(ctx, sharded, msel, n_search, upload_movable, t_start, obs, ow, H,
                                       correspondences, neighbors, min_planarity, max_overlap_distance, min_change,
                                       max_iterations, distance_weights, debug_dirpath)
         finally:
-            # the exchange callback lives on the process-wide context: a later standalone PointCloud operator must not
-            # issue a collective the other ranks never join
-            ctx.set_exchange(None, 0, 1)
+            # the exchange lives on the process-wide context: a later standalone PointCloud operator must not issue a
+            # collective the other ranks never join
+            dist.detach(ctx)
 
     def _run_uploaded(self, ctx, sharded, msel, n_search, upload_movable, t_start, obs, ow, H, correspondences, neighbors,
                       min_planarity, max_overlap_distance, min_change, max_iterations, distance_weights, debug_dirpath):

@@ -53,6 +53,19 @@ def _worker(rank, world, port, tmp):
             if np.isfinite(max_dist):
                 assert (~ok).any() and ok.any()
 
+        # query shards (SURVEY 8e "alternative"): every rank matches its slice of the queries in the WHOLE cloud;
+        # gathering the slices in rank order restores the full result -- no reduction, bit-exact by construction
+        fidx, fd2 = orc.knn(Xm, Qp, k=1, H=H)
+        per = (q + world - 1) // world
+        a, b = min(q, per * rank), min(q, per * rank + per)
+        sidx, sd2 = orc.knn(Xm, Qp[a:b], k=1, H=H)
+        t_d2 = torch.full((q,), float("nan"), dtype=torch.float64); t_idx = torch.full((q,), -7, dtype=torch.int64)
+        t_xyz = torch.full((q, 3), float("nan"), dtype=torch.float64)
+        t_d2[a:b] = torch.from_numpy(sd2[:, 0]); t_idx[a:b] = torch.from_numpy(sidx[:, 0]); t_xyz[a:b] = torch.from_numpy(Xm[sidx[:, 0]])
+        dist.exchange_query_slices(t_d2, t_idx, t_xyz)
+        assert np.array_equal(t_idx.numpy(), fidx[:, 0]) and np.array_equal(t_d2.numpy(), fd2[:, 0])
+        assert np.array_equal(t_xyz.numpy(), Xm[fidx[:, 0]])
+
         # sharded 6x6 normal-equation reduction + SUM exchange == unsharded (to rounding)
         p1 = rng.uniform(-5, 5, (q, 3))
         n1 = rng.normal(size=(q, 3)); n1 = (n1 / np.linalg.norm(n1, axis=1, keepdims=True)).astype(np.float32)

@@ -1,6 +1,8 @@
 """GPU side of the multi-GPU path that one GPU can exercise: the lexicographic reduce kernel, and the
-full exchange plumbing (device-pointer views for torch, NCCL/RCCL all_gather on library-owned
-buffers, callback through ctypes) with a 1-rank process group."""
+full exchange plumbing with a 1-rank process group -- the library's own RCCL communicator (sicp_comm_init:
+ncclUniqueId broadcast over torch.distributed, ncclAllGather / ncclAllReduce enqueued by the library), the
+host-callback variant (device-pointer views for torch, all_gather on library-owned buffers), cloud shards and
+query shards."""
 import os
 import subprocess
 import sys
@@ -53,14 +55,23 @@ del os.environ["SICP_SOLVE"]; backend.reset_context()
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%(port)d", SICP_FORCE_EXCHANGE="1")
 torch.cuda.set_device(0)
 td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-H1, X1, r1, it1 = run()                                # same job through the exchange (all_gather of 1 rank)
-td.destroy_process_group()
+H1, X1, r1, it1 = run()                                # same job through the library's own RCCL communicator (1 rank)
 assert it0 == it1 and np.array_equal(H0, H1) and np.array_equal(X0, X1) and np.array_equal(r0, r1), (H0 - H1)
 assert ith == it0 and np.abs(Hh - H0).max() < 1e-9     # device LM vs host LM: same minimiser
 os.environ["SICP_GN_SHARD"] = "1"
-td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 H2, X2, r2, it2 = run()                                # + sharded 6x6 reduction with a SUM all-reduce per solver step
 assert it2 == ith and np.array_equal(H2, Hh) and np.array_equal(r2, rh), (H2 - Hh)
+del os.environ["SICP_GN_SHARD"]
+os.environ["SICP_PARTITION"] = "queries"
+H4, X4, r4, it4 = run()                                # query shards (cloud replicated): slices gathered in rank order
+assert it4 == it0 and np.array_equal(H4, H0) and np.array_equal(r4, r0), (H4 - H0)
+del os.environ["SICP_PARTITION"]
+os.environ["SICP_XCHG"] = "callback"
+H5, X5, r5, it5 = run()                                # collectives supplied by the host: torch.distributed callback
+assert it5 == it0 and np.array_equal(H5, H0) and np.array_equal(r5, r0)
+os.environ["SICP_GN_SHARD"] = "1"
+H6, X6, r6, it6 = run()
+assert it6 == ith and np.array_equal(H6, Hh) and np.array_equal(r6, rh), (H6 - Hh)
 os.environ["SICP_XCHG_SYNC"] = "1"; del os.environ["SICP_GN_SHARD"]
 H3, X3, r3, it3 = run()                                # blocking variant of the callback
 td.destroy_process_group()
