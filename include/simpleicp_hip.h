@@ -246,8 +246,8 @@ int sicp_xyz_write(const char *path, const double *data, int64_t n, int cols, in
 #define SICP_K_COUNT    4
 int sicp_timing_enable(sicp_ctx *ctx, int on);   /* 0 off, 1 kernel timing, 2 timing + the grid search's work tallies (sicp_match_work) */
 /* which 1-NN flavour the last sicp_knn(k=1) / sicp_icp_iterate used: 0 exact scan, 1 filtered scan
- * with inline verification, 2 grid search, 3 filtered scan with recorded candidates + fix-up kernel
- * (all return identical results) */
+ * with inline verification, 2 grid search, 3 filtered scan (VALU filter) with recorded candidates + fix-up kernel,
+ * 4 the same with the filter on the FP32 matrix pipe (all return identical results) */
 int sicp_last_match_kernel(sicp_ctx *ctx, int *kind_out);
 int sicp_timing_reset(sicp_ctx *ctx);
 /* Work the pruned grid search did in its launches since sicp_timing_reset, counted by the kernel itself while

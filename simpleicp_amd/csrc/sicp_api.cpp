@@ -235,7 +235,8 @@ struct sicp_ctx {
     DevBuf<double> x_send, x_recv; // exchange records: [Q][5] and [world][Q][5]
     int fs_blocks_per_cu[2] = {0, 0};   // occupancy of k_knn1_fscan<128>, <256>
     int fr_blocks_per_cu[2] = {0, 0};   // occupancy of k_knn1_frec<128>, <256>
-    int fscan_variant = 0;         // SICP_FSCAN = record (default) | inline: which filtered-scan kernel
+    int fscan_variant = 0;         // SICP_FSCAN = record (default: VALU filter, candidates recorded) | mfma (filter on the FP32 matrix pipe) | inline
+    int fm_blocks_per_cu = 0;      // occupancy of k_knn1_fmfma
     long fscan_cap = 0;            // SICP_FSCAN_CAP: recorded groups per query (tests force overflow with tiny values)
     DevBuf<uint32_t> hit_cnt, hit_list;
     int knn1_mode = 0;             // SICP_KNN1 = exact | filter | grid: force one 1-NN flavour (A/B + tests); 0 = auto
@@ -700,11 +701,16 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
     const int blk = (Q > 1024) ? 256 : 128;                  // 8 queries per lane either way
     const long qblocks = (Q + blk * FS_R - 1) / (blk * FS_R);
     const int ftiles = (int)(cl.npad / FS_TILE);
-    // (a) record + fix-up: the streaming kernel carries no FP64 state; exact work in a second, tiny kernel
+    // (a) record + fix-up: the streaming kernel carries no FP64 state; exact work in a second, tiny kernel.
+    //     Default: the filter on the VALU (k_knn1_frec, the faster one as measured); SICP_FSCAN=mfma runs it on the
+    //     FP32 matrix pipe (k_knn1_fmfma).
     if (c->fscan_variant != 1) {
-        int &bpr = c->fr_blocks_per_cu[blk == 256];
-        if (bpr == 0) bpr = frec_blocks_per_cu(blk);
-        long nparts = std::max<long>(1, ((long)cus * bpr) / qblocks);
+        const bool mfma = c->fscan_variant == 2;
+        const int blk_r = mfma ? 256 : blk;
+        const long qblocks_r = mfma ? (Q + 1023) / 1024 : qblocks;
+        int &bpr = mfma ? c->fm_blocks_per_cu : c->fr_blocks_per_cu[blk == 256];
+        if (bpr == 0) bpr = mfma ? fmfma_blocks_per_cu() : frec_blocks_per_cu(blk);
+        long nparts = std::max<long>(1, ((long)cus * bpr) / qblocks_r);
         nparts = std::min<long>(nparts, ftiles);
         uint32_t cap = c->fscan_cap > 0 ? (uint32_t)c->fscan_cap
                                         : (uint32_t)std::max<long>(32, std::min<long>(4096, (256L << 20) / qpad));
@@ -714,16 +720,20 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
         uint32_t *d_over = c->hit_cnt.p + qpad;
         {
             Timed t(c, SICP_K_KNN1);
-            launch_knn1_frec(c->stream, blk, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, (int)qblocks, c->bound.p, cl.x(), cl.y(),
-                             cl.z(), ftiles, (int)nparts, H, rmax_t, c->hit_cnt.p, c->hit_list.p, cap);
+            if (mfma)
+                launch_knn1_fmfma(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, (int)qblocks_r, c->bound.p, cl.x(), cl.y(), cl.z(),
+                                  ftiles, (int)nparts, H, rmax_t, c->hit_cnt.p, c->hit_list.p, cap);
+            else
+                launch_knn1_frec(c->stream, blk_r, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, (int)qblocks_r, c->bound.p, cl.x(), cl.y(),
+                                 cl.z(), ftiles, (int)nparts, H, rmax_t, c->hit_cnt.p, c->hit_list.p, cap);
         }
         launch_knn1_fixup(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, cl.x(), cl.y(), cl.z(), H, c->hit_cnt.p,
-                          c->hit_list.p, cap, max_d2, cl.idx_base, d2_out, idx_out, p2_out, d_over);
+                          c->hit_list.p, cap, mfma ? 1u : (uint32_t)FS_G, max_d2, cl.idx_base, d2_out, idx_out, p2_out, d_over);
         HIPCHK(hipGetLastError());
         uint32_t *h_over = (uint32_t *)(c->h_small + 62);
         HIPCHK(hipMemcpyAsync(h_over, d_over, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         CHK(sync(c));
-        if (*h_over == 0) { c->last_match_kernel = 3; return SICP_OK; }
+        if (*h_over == 0) { c->last_match_kernel = mfma ? 4 : 3; return SICP_OK; }
         // some query's candidate list overflowed (poor bound): fall through to the self-contained kernel
     }
     // (b) self-contained variant: exact re-evaluation inside the scan (tightens its own threshold)
@@ -880,7 +890,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
     if (const char *e = std::getenv("SICP_LM_EVALS")) { const int d = std::atoi(e); if (d >= 0 && d <= 32) c->lm_evals = d; }
     if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
-    if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : 0;
+    if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : !std::strcmp(e, "mfma") ? 2 : 0;
     if (const char *e = std::getenv("SICP_FSCAN_CAP")) c->fscan_cap = std::atol(e);
     if (const char *e = std::getenv("SICP_GRID_TARGET")) { const double t = std::atof(e); if (t >= 0.25 && t <= 1024) c->grid_target = t; }
     c->host_trace = std::getenv("SICP_HOST_TRACE") != nullptr;

@@ -125,8 +125,12 @@ void launch_knn1_frec(hipStream_t s, int block, const double *qx, const double *
                       const Xf *H, double rmax, uint32_t *hit_cnt, uint32_t *hit_list, uint32_t cap);
 void launch_knn1_fixup(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *px,
                        const double *py, const double *pz, const Xf *H, const uint32_t *hit_cnt, const uint32_t *hit_list,
-                       uint32_t cap, double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out,
-                       uint32_t *overflow);
+                       uint32_t cap, uint32_t group, double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out,
+                       double *p2_out, uint32_t *overflow);
+void launch_knn1_fmfma(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int qblocks, const double *bound,
+                       const double *px, const double *py, const double *pz, int ntiles, int nparts, const Xf *H, double rmax,
+                       uint32_t *hit_cnt, uint32_t *hit_list, uint32_t cap);
+int  fmfma_blocks_per_cu();
 int  frec_blocks_per_cu(int block);
 void launch_bound_prev(hipStream_t s, const double *qx, const double *qy, const double *qz, const double *p2, long Q,
                        long qpad, const Xf &H, double *bound);

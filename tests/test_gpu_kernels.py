@@ -400,10 +400,11 @@ def test_large_q_iteration_multi_kernel_path(ctx, quantised, odd):
         assert abs(R.res_mean - resid[keep].mean()) < 1e-15 and abs(R.res_std - resid[keep].std()) < 1e-14
 
 
-@pytest.mark.parametrize("variant,cap", [("inline", None), ("record", 1), ("record", None)])
+@pytest.mark.parametrize("variant,cap", [("inline", None), ("record", 1), ("record", None), ("mfma", 1), ("mfma", None)])
 def test_filtered_scan_variants_and_overflow_fallback(variant, cap):
-    """Both filtered-scan kernels (exact work inline / recorded + fixed up) and the overflow fallback
-    (candidate lists forced to one entry per query) return the brute-force answer."""
+    """All filtered-scan kernels (exact work inline / recorded + fixed up with the filter on the VALU or on the FP32
+    matrix pipe) and the overflow fallback (candidate lists forced to one entry per query) return the brute-force
+    answer."""
     import os
     from simpleicp_amd import _lib
     env = {"SICP_KNN1": "filter", "SICP_FSCAN": variant}
@@ -422,6 +423,8 @@ def test_filtered_scan_variants_and_overflow_fallback(variant, cap):
         idx, d2 = c.knn(_lib.MOV, Qp, k=1, H=Hm)
         ridx, rd2 = orc.knn(P, Qp, k=1, H=Hm)
         assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+        if cap is None:
+            assert c.last_match_kernel() == {"inline": "k_knn1_fscan", "record": "k_knn1_frec", "mfma": "k_knn1_fmfma"}[variant]
     c.close()
 
 
