@@ -1326,23 +1326,26 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                                 c->keep.p, c->resid.p, rec);
             } else {
                 // distances + rejections (corrpts.py:139-211), kept-distance statistics, then the solver chain
-                Xf unused = {};
-                launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
-                                 A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
-                {
+                if (Q <= REJECT_MAX_Q) {
                     Timed t(c, SICP_K_SELECT);
-                    if (Q > REJECT_MAX_Q) {
+                    launch_dist_reject_stats(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q,
+                                             A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->keep.p, c->small.p,
+                                             c->small.p + 4, c->icp_dev.p);
+                } else {
+                    Xf unused = {};
+                    launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
+                                     A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
+                    {
+                        Timed t(c, SICP_K_SELECT);
                         const size_t sb = (reject_select_scratch_bytes() + 7) / 8;
                         CHK(c->rj_keys.reserve((size_t)Q + sb));
                         if (reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->rj_keys.p, c->rj_keys.p + Q,
                                              (unsigned long long *)(c->small.p + 56), c->icp_dev.p) != hipSuccess)
                             return fail(SICP_ERR_HIP, "rejection by radix selection failed");
-                    } else {
-                        launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->icp_dev.p);
                     }
+                    launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4, nullptr, nullptr, 0.0, c->ne_partial.p, c->ticket.p,
+                                 c->icp_dev.p);
                 }
-                launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4, nullptr, nullptr, 0.0, c->ne_partial.p, c->ticket.p,
-                             c->icp_dev.p);
                 {
                     Timed t(c, SICP_K_NORMALEQ);
                     for (int e = 0; e < c->lm_evals; ++e)

@@ -849,15 +849,16 @@ __global__ void k_scatter_f32(float *__restrict__ dst, const int64_t *__restrict
 // K6: median / raw-MAD rejection      corrpts.py:165-188  (np.median: mean of the two
 // middle values for even counts; scipy median_abs_deviation with scale = 1.0)
 //
-// One 1024-lane workgroup, one launch, Q <= REJECT_MAX_Q: the order-preserving uint64 images of the
-// flagged distances are staged in LDS ONCE (128 KB of the CU's 160 KB; unflagged rows hold an
-// all-ones sentinel that sorts last) and every later pass reads LDS, not L2.  Exact order statistics by
-// 8-bit-digit radix selection (8 passes: LDS histogram + wave scan); the SECOND middle value of an even
-// count costs one more pass (how many keys <= the first, and the smallest key above it) instead of
-// eight.  Distances share sign/exponent bytes, so whole waves hit one histogram bin in the early
-// passes: lanes with the leader's bin are counted by ballot and added once (two rounds), the rest add
-// individually -- without this the pass serialises ~Q atomics on one LDS word.
-// out[0]=m (planarity survivors) out[1]=median out[2]=mad out[3]=n_kept
+// One 1024-lane workgroup, one launch, Q <= REJECT_MAX_Q: the order-preserving uint64 images of the flagged
+// distances are staged in LDS ONCE (128 KB of the CU's 160 KB; unflagged rows hold an all-ones sentinel) and every
+// later pass reads LDS.  Exact order statistics by RANGE-HISTOGRAM SELECTION (the small-Q tail's algorithm,
+// sicp_tail.hip): 256 bins over the current key interval -- counted in 16 privatised copies, because distances share
+// their leading bits and same-address LDS atomics serialise per lane --, the bin that holds the wanted rank becomes
+// the next interval (2-3 rounds on real distances instead of 8 radix passes), the last <= 8 keys are ranked with one
+// ballot.  FUSED (chained runs): the kernel also computes the point-to-plane distances and planarity flags it
+// rejects on (corrpts.py:139-163,195-211; H from the device loop state) and the kept distances' count / mean /
+// std (simpleicp.py:233-234) -- three launches of the multi-kernel tail in one.
+// out4[0]=m (planarity survivors) out4[1]=median out4[2]=mad out4[3]=n_kept;  out3 = n, mean, std of the kept
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t ord_key(double v)
 {
@@ -870,134 +871,236 @@ __device__ __forceinline__ double ord_val(uint64_t k)
     return __longlong_as_double((long long)b);
 }
 
+constexpr int RJ_BLOCK = 1024, RJ_WAVES = RJ_BLOCK / 64, RJ_HC = 16, RJ_CAND = 8;
 struct RejectShared {
     uint64_t key[REJECT_MAX_Q];
-    unsigned hist[256];
-    unsigned long long sh[4];
+    unsigned hc[RJ_HC * 257];
+    unsigned tot[256];
+    uint64_t cand[RJ_CAND];
+    unsigned ncand;
+    uint64_t wmin[RJ_WAVES];
+    double red[2][RJ_WAVES][4];
+    unsigned wcnt[RJ_WAVES];
 };
 
-// key of rank `rank` (0-based) among the n LDS keys
-__device__ uint64_t lds_radix_select(RejectShared &S, int n, long rank)
+__device__ __forceinline__ uint64_t rj_wmin_u64(uint64_t v)
 {
-    const int tid = threadIdx.x, lane = tid & 63;
-    uint64_t prefix = 0;
-    for (int pass = 0; pass < 8; ++pass) {
-        const int shift = 56 - 8 * pass;
-        if (tid < 256) S.hist[tid] = 0;
+    unsigned long long o;
+    o = lane_xor64<32>(v); v = o < v ? o : v;  o = lane_xor64<16>(v); v = o < v ? o : v;
+    o = lane_xor64<8>(v);  v = o < v ? o : v;  o = lane_xor64<4>(v);  v = o < v ? o : v;
+    o = lane_xor64<2>(v);  v = o < v ? o : v;  o = lane_xor64<1>(v);  v = o < v ? o : v;
+    return v;
+}
+__device__ __forceinline__ double rj_wmin_f64(double v)
+{
+    v = fmin(v, lane_xor_f64<32>(v)); v = fmin(v, lane_xor_f64<16>(v)); v = fmin(v, lane_xor_f64<8>(v));
+    v = fmin(v, lane_xor_f64<4>(v));  v = fmin(v, lane_xor_f64<2>(v));  v = fmin(v, lane_xor_f64<1>(v));
+    return v;
+}
+__device__ __forceinline__ uint64_t rj_readlane_u64(uint64_t v, int l)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// keys of rank r and (want2) r + 1 among the member keys (!= ~0) of S.key[0..n); [lo, hi] contains them all.
+// S.hc and S.ncand are zero on entry and on exit.
+__device__ void lds_range_select(RejectShared &S, int n, long r, bool want2, uint64_t lo, uint64_t hi, uint64_t &ka, uint64_t &kb)
+{
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const uint64_t NOKEY = ~0ull;
+    uint64_t below = 0;
+    unsigned cs = 0;
+    int sh = 0;
+    unsigned *mycopy = S.hc + (lane & (RJ_HC - 1)) * 257;
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t range = hi - lo;
+        sh = range < 256ull ? 0 : (64 - __clzll((long long)range)) - 8;
+        for (int i = tid; i < n; i += RJ_BLOCK) {
+            const uint64_t k = S.key[i];
+            if (k != NOKEY && k >= lo && k <= hi) atomicAdd(&mycopy[(unsigned)((k - lo) >> sh)], 1u);
+        }
         __syncthreads();
-        for (int base = 0; base < n; base += 1024) {           // wave-uniform trip count (ballots below)
-            const int i = base + tid;
-            const uint64_t k = i < n ? S.key[i] : 0;
-            bool act = i < n && (pass == 0 || (k >> (shift + 8)) == (prefix >> (shift + 8)));
-            const unsigned bin = (unsigned)(k >> shift) & 255u;
+        if (tid < 256) {
+            unsigned tot = 0;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const unsigned long long am = __ballot(act);
-                if (am == 0) break;
-                const int leader = __ffsll((long long)am) - 1;
-                const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
-                const unsigned long long same = __ballot(act && bin == b0);
-                if (lane == leader) atomicAdd(&S.hist[b0], (unsigned)__popcll(same));
-                act = act && bin != b0;
-            }
-            if (act) atomicAdd(&S.hist[bin], 1u);
+            for (int c = 0; c < RJ_HC; ++c) { tot += S.hc[c * 257 + tid]; S.hc[c * 257 + tid] = 0u; }
+            S.tot[tid] = tot;
         }
         __syncthreads();
-        if (tid < 64) {
-            // wave 0: lane l owns bins 4l..4l+3
-            const unsigned h0 = S.hist[4 * tid], h1 = S.hist[4 * tid + 1], h2 = S.hist[4 * tid + 2], h3 = S.hist[4 * tid + 3];
-            const unsigned mine = h0 + h1 + h2 + h3;
-            const unsigned incl = wscan_u32(mine);
-            const unsigned long long excl = incl - mine;
-            const unsigned long long r = (unsigned long long)rank;
-            if (r >= excl && r < excl + mine) {
-                unsigned long long acc = excl; int bin = 4 * tid;
-                if (r >= acc + h0) { acc += h0; bin++; if (r >= acc + h1) { acc += h1; bin++; if (r >= acc + h2) { acc += h2; bin++; } } }
-                S.sh[0] = (unsigned long long)bin;
-                S.sh[1] = r - acc;
-            }
+        const uint4 h4 = *reinterpret_cast<const uint4 *>(&S.tot[4 * lane]);
+        const unsigned mine = h4.x + h4.y + h4.z + h4.w;
+        const unsigned incl = wscan_u32(mine);
+        const uint64_t t = (uint64_t)r - below;
+        const unsigned long long gt = __ballot((uint64_t)incl > t);
+        const int L = __ffsll((long long)gt) - 1;
+        const unsigned eL = (unsigned)__builtin_amdgcn_readlane((int)(incl - mine), L);
+        const unsigned a0 = (unsigned)__builtin_amdgcn_readlane((int)h4.x, L), a1 = (unsigned)__builtin_amdgcn_readlane((int)h4.y, L);
+        const unsigned a2 = (unsigned)__builtin_amdgcn_readlane((int)h4.z, L), a3 = (unsigned)__builtin_amdgcn_readlane((int)h4.w, L);
+        unsigned acc = eL; int j = 0; cs = a0;
+        if (t >= (uint64_t)acc + a0) { acc += a0; j = 1; cs = a1;
+            if (t >= (uint64_t)acc + a1) { acc += a1; j = 2; cs = a2;
+                if (t >= (uint64_t)acc + a2) { acc += a2; j = 3; cs = a3; } } }
+        below += acc;
+        lo = lo + ((uint64_t)(4u * (unsigned)L + (unsigned)j) << sh);
+        if (sh > 0) { const uint64_t top = lo + ((1ull << sh) - 1ull); hi = top < hi ? top : hi; } else hi = lo;
+        if (cs <= (unsigned)RJ_CAND || sh == 0) break;
+    }
+    const uint64_t t = (uint64_t)r - below;
+    const bool need_above = want2 && t + 1 >= cs;
+    if (sh == 0 || lo == hi) {
+        ka = lo; kb = lo;
+    } else {
+        for (int i = tid; i < n; i += RJ_BLOCK) {
+            const uint64_t k = S.key[i];
+            if (k != NOKEY && k >= lo && k <= hi) { const unsigned slot = atomicAdd(&S.ncand, 1u); if (slot < (unsigned)RJ_CAND) S.cand[slot] = k; }
         }
         __syncthreads();
-        prefix |= ((uint64_t)S.sh[0]) << shift;
-        rank = (long)S.sh[1];
+        if (tid == 0) S.ncand = 0u;
+        const int ci = lane >> 3, cj = lane & 7;
+        const uint64_t vi = S.cand[ci], vj = S.cand[cj];
+        const bool before = ci != cj && (unsigned)ci < cs && (unsigned)cj < cs && (cj < ci ? vj <= vi : vj < vi);
+        const unsigned long long M = __ballot(before);
+        const unsigned rk = (unsigned)__popcll((long long)((M >> (8 * (lane & 7))) & 0xffull));
+        const uint64_t mine = S.cand[lane & 7];
+        const bool valid = lane < 8 && (unsigned)lane < cs;
+        const unsigned long long ha = __ballot(valid && (uint64_t)rk == t);
+        ka = rj_readlane_u64(mine, __ffsll((long long)ha) - 1);
+        kb = ka;
+        if (want2 && !need_above) {
+            const unsigned long long hb = __ballot(valid && (uint64_t)rk == t + 1);
+            kb = rj_readlane_u64(mine, __ffsll((long long)hb) - 1);
+        }
+    }
+    if (need_above) {
+        uint64_t nx = NOKEY;
+        for (int i = tid; i < n; i += RJ_BLOCK) { const uint64_t k = S.key[i]; if (k != NOKEY && k > hi) nx = k < nx ? k : nx; }
+        nx = rj_wmin_u64(nx);
+        if (lane == 0) S.wmin[wid] = nx;
         __syncthreads();
+        uint64_t bmin = S.wmin[0];
+#pragma unroll
+        for (int w = 1; w < RJ_WAVES; ++w) { const uint64_t a = S.wmin[w]; bmin = a < bmin ? a : bmin; }
+        kb = bmin;
     }
-    return prefix;
+    __syncthreads();                          // S.cand / S.wmin consumed
 }
 
-// key of rank r+1 given ka = the key of rank r: ka again if enough keys are <= ka, else the smallest key above it
-__device__ uint64_t lds_next_rank(RejectShared &S, int n, long r, uint64_t ka)
-{
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid == 0) { S.sh[2] = 0; S.sh[3] = ~0ull; }
-    __syncthreads();
-    unsigned long long le = 0, nxt = ~0ull;
-    for (int i = tid; i < n; i += 1024) {
-        const uint64_t k = S.key[i];
-        if (k <= ka) le += 1; else nxt = k < nxt ? k : nxt;
-    }
-    le = wsum_u64(le);
-    { unsigned long long o;
-      o = lane_xor64<32>(nxt); nxt = o < nxt ? o : nxt;  o = lane_xor64<16>(nxt); nxt = o < nxt ? o : nxt;
-      o = lane_xor64<8>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<4>(nxt);  nxt = o < nxt ? o : nxt;
-      o = lane_xor64<2>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<1>(nxt);  nxt = o < nxt ? o : nxt; }
-    if (lane == 0) { atomicAdd(&S.sh[2], le); atomicMin(&S.sh[3], nxt); }
-    __syncthreads();
-    const uint64_t kb = ((long)S.sh[2] >= r + 2) ? ka : (uint64_t)S.sh[3];
-    __syncthreads();
-    return kb;
-}
-
-__global__ __launch_bounds__(1024) void k_reject(const double *__restrict__ dist, const uint8_t *__restrict__ flag,
-                                                 long Q, uint8_t *__restrict__ keep, double *__restrict__ out,
-                                                 const IcpDev *__restrict__ st)
+template <bool FUSED>
+__global__ __launch_bounds__(RJ_BLOCK) void k_reject(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, const float *__restrict__ normals,
+    const float *__restrict__ planarity, const double *__restrict__ p2, const int64_t *__restrict__ idx, float min_planarity,
+    const float *__restrict__ pl2, long pl2_n,
+    double *__restrict__ dist, uint8_t *__restrict__ flag, long Q, uint8_t *__restrict__ keep, double *__restrict__ out4,
+    double *__restrict__ out3, const IcpDev *__restrict__ st)
 {
     __shared__ RejectShared S;
     if (st && st->stop) return;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const int n = (int)Q;
-    if (tid == 0) S.sh[2] = 0;
-    __syncthreads();
-    unsigned long long local = 0;
-    for (int i = tid; i < n; i += 1024) {
-        const bool f = flag[i] != 0;
-        S.key[i] = f ? ord_key(dist[i]) : ~0ull;
-        local += f ? 1 : 0;
+    for (int i = tid; i < RJ_HC * 257; i += RJ_BLOCK) S.hc[i] = 0u;
+    if (tid == 0) S.ncand = 0u;
+    Xf H;
+    if (FUSED) H = st->H;
+    unsigned cnt = 0;
+    double dmn = __builtin_inf(), dmx = -__builtin_inf();
+    // four rows per lane and step: their loads are issued together (one workgroup has to cover the memory latency itself)
+    for (int base = tid; base < n; base += 4 * RJ_BLOCK) {
+        double d[4];
+        bool f[4];
+        if (FUSED) {
+            double P[4][3], Qp[4][3];
+            float N[4][3], pl[4];
+            int64_t mi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * RJ_BLOCK;
+                const int ic = i < n ? i : n - 1;
+                P[u][0] = p2[3 * ic]; P[u][1] = p2[3 * ic + 1]; P[u][2] = p2[3 * ic + 2];
+                Qp[u][0] = qx[ic]; Qp[u][1] = qy[ic]; Qp[u][2] = qz[ic];
+                N[u][0] = normals[3 * ic]; N[u][1] = normals[3 * ic + 1]; N[u][2] = normals[3 * ic + 2];
+                pl[u] = planarity[ic]; mi[u] = idx[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double X, Y, Z;
+                xform(H, P[u][0], P[u][1], P[u][2], X, Y, Z);
+                d[u] = plane_dist(X - Qp[u][0], Y - Qp[u][1], Z - Qp[u][2], N[u][0], N[u][1], N[u][2]);
+                f[u] = mi[u] >= 0 && pl[u] >= min_planarity;
+                if (f[u] && pl2) f[u] = mi[u] < pl2_n && pl2[mi[u]] >= min_planarity;          // corrpts.py:158-163 (NaN fails)
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * RJ_BLOCK;
+                const int ic = i < n ? i : n - 1;
+                d[u] = dist[ic]; f[u] = flag[ic] != 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * RJ_BLOCK;
+            if (i >= n) continue;
+            if (FUSED) { dist[i] = d[u]; flag[i] = f[u] ? 1 : 0; }
+            S.key[i] = f[u] ? ord_key(d[u]) : ~0ull;
+            if (f[u]) { cnt += 1; dmn = fmin(dmn, d[u]); dmx = fmax(dmx, d[u]); }
+        }
     }
-    local = wsum_u64(local);
-    if (lane == 0 && local) atomicAdd(&S.sh[2], local);
+    cnt = (unsigned)wsum_u64(cnt);
+    dmn = rj_wmin_f64(dmn); dmx = rj_wmin_f64(-dmx);
+    if (lane == 0) { S.wcnt[wid] = cnt; S.red[0][wid][0] = dmn; S.red[0][wid][1] = dmx; }
     __syncthreads();
-    const long m = (long)S.sh[2];
+    long m = 0;
+#pragma unroll
+    for (int w = 0; w < RJ_WAVES; ++w) { m += S.wcnt[w]; dmn = fmin(dmn, S.red[0][w][0]); dmx = fmin(dmx, S.red[0][w][1]); }
     __syncthreads();
     if (m == 0) {
-        for (int i = tid; i < n; i += 1024) keep[i] = 0;
-        if (tid == 0) { out[0] = 0; out[1] = __builtin_nan(""); out[2] = __builtin_nan(""); out[3] = 0; }
+        for (int i = tid; i < n; i += RJ_BLOCK) keep[i] = 0;
+        if (tid == 0) {
+            out4[0] = 0; out4[1] = __builtin_nan(""); out4[2] = __builtin_nan(""); out4[3] = 0;
+            if (FUSED) { out3[0] = 0; out3[1] = __builtin_nan(""); out3[2] = __builtin_nan(""); }
+        }
         return;
     }
-    const uint64_t ka = lds_radix_select(S, n, (m - 1) / 2);
-    const uint64_t kb = (m & 1) ? ka : lds_next_rank(S, n, (m - 1) / 2, ka);
+    uint64_t ka, kb;
+    lds_range_select(S, n, (m - 1) / 2, (m & 1) == 0, ord_key(dmn), ord_key(-dmx), ka, kb);
     const double med = (ord_val(ka) + ord_val(kb)) / 2.0;
-    for (int i = tid; i < n; i += 1024) {
+    for (int i = tid; i < n; i += RJ_BLOCK) {
         const uint64_t k = S.key[i];
         if (k != ~0ull) S.key[i] = ord_key(fabs(ord_val(k) - med));
     }
     __syncthreads();
-    const uint64_t kc = lds_radix_select(S, n, (m - 1) / 2);
-    const uint64_t ke = (m & 1) ? kc : lds_next_rank(S, n, (m - 1) / 2, kc);
-    const double mad = (ord_val(kc) + ord_val(ke)) / 2.0;
-    const double bound = 3 * mad;
-    if (tid == 0) S.sh[2] = 0;
-    __syncthreads();
-    local = 0;
-    for (int i = tid; i < n; i += 1024) {
-        const uint64_t k = S.key[i];
-        const uint8_t kq = (k != ~0ull && ord_val(k) <= bound) ? 1 : 0;      // key = |d - med| of a flagged row
-        keep[i] = kq; local += kq;
+    {   // |d - med| is monotone in d on either side of med: its range follows from the distances' own
+        const double u = fabs(dmn - med), v = fabs(-dmx - med);
+        lds_range_select(S, n, (m - 1) / 2, (m & 1) == 0, ord_key(0.0), ord_key(u > v ? u : v), ka, kb);
     }
-    local = wsum_u64(local);
-    if (lane == 0 && local) atomicAdd(&S.sh[2], local);
+    const double mad = (ord_val(ka) + ord_val(kb)) / 2.0;
+    const double bound = 3 * mad;
+    // keep mask (key = |d - med| of a flagged row) + statistics of the kept distances, one pass over deviations from
+    // the median (a shift within a few MAD of the mean: var = (S2 - S1^2 / n) / n loses nothing to cancellation)
+    double v3[3] = {0.0, 0.0, 0.0};
+    for (int i = tid; i < n; i += RJ_BLOCK) {
+        const uint64_t k = S.key[i];
+        const uint8_t kq = (k != ~0ull && ord_val(k) <= bound) ? 1 : 0;
+        keep[i] = kq;
+        if (kq) {
+            v3[0] += 1.0;
+            if (FUSED) { const double dev = dist[i] - med; v3[1] += dev; v3[2] = fma(dev, dev, v3[2]); }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { v3[j] = wsum(v3[j]); if (lane == 0) S.red[1][wid][j] = v3[j]; }
     __syncthreads();
-    if (tid == 0) { out[0] = (double)m; out[1] = med; out[2] = mad; out[3] = (double)S.sh[2]; }
+    if (tid == 0) {
+        double t[3] = {0.0, 0.0, 0.0};
+        for (int w = 0; w < RJ_WAVES; ++w) for (int j = 0; j < 3; ++j) t[j] += S.red[1][w][j];
+        out4[0] = (double)m; out4[1] = med; out4[2] = mad; out4[3] = t[0];
+        if (FUSED) {
+            const double var = (t[2] - t[1] * t[1] / t[0]) / t[0];
+            out3[0] = t[0]; out3[1] = med + t[1] / t[0]; out3[2] = sqrt(var > 0.0 ? var : 0.0);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1479,7 +1582,18 @@ void launch_scatter_f32(hipStream_t s, float *dst, const int64_t *rows, const fl
 
 void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, const IcpDev *st)
 {
-    hipLaunchKernelGGL(k_reject, dim3(1), dim3(1024), 0, s, dist, flag, Q, keep, out4, st);
+    hipLaunchKernelGGL(k_reject<false>, dim3(1), dim3(RJ_BLOCK), 0, s, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
+                       nullptr, 0L, (double *)dist, (uint8_t *)flag, Q, keep, out4, nullptr, st);
+}
+
+// chained runs, 2048 < Q <= REJECT_MAX_Q: distances + flags + rejection + kept-distance statistics in one launch
+void launch_dist_reject_stats(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
+                              const float *planarity, const double *p2, const int64_t *idx, long Q, float min_planarity,
+                              const float *pl2, long pl2_n, double *dist, uint8_t *flag, uint8_t *keep, double *out4, double *out3,
+                              const IcpDev *st)
+{
+    hipLaunchKernelGGL(k_reject<true>, dim3(1), dim3(RJ_BLOCK), 0, s, qx, qy, qz, normals, planarity, p2, idx, min_planarity, pl2, pl2_n,
+                       dist, flag, Q, keep, out4, out3, st);
 }
 
 void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3, const double *also4,
