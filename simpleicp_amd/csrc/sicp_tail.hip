@@ -408,9 +408,13 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
     const double bound = 3 * mad;
     tk[2] = clock64();
 
-    // ---- keep mask, mean / population std (ddof 0) of the kept distances: ONE pass over deviations from the median
-    //      (a shift within a few MAD of the mean: var = (S2 - S1^2 / n) / n loses nothing to cancellation) ----
+    // ---- keep mask.  The kept distances' count / mean / std (simpleicp.py:233-234) are only needed NOW when the
+    //      weight is still automatic (first iteration of such a run): then one pass over deviations from the median
+    //      (a shift within a few MAD of the mean: var = (S2 - S1^2 / n) / n loses nothing to cancellation).  Otherwise
+    //      they come for free out of the first evaluation's Gram matrix below (r = d at the start estimate). ----
+    const bool need_w = !(w_state > 0);
     double v3[3] = {0.0, 0.0, 0.0};
+    unsigned nkeep = 0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + e * TB;
@@ -419,11 +423,19 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         C.keep[e] = kq;
         if (i < Q) keep[i] = kq ? 1 : 0;
         if (kq) { v3[0] += 1.0; v3[1] += dev; v3[2] = fma(dev, dev, v3[2]); }
+        nkeep += (unsigned)__popcll((long long)__ballot(kq));
     }
-    block_sum<3>(v3, S.red[0]);
-    const double nk = v3[0], dmean = med + v3[1] / nk;
-    const double dvar = (v3[2] - v3[1] * v3[1] / nk) / nk;
-    const double dstd = sqrt(dvar > 0.0 ? dvar : 0.0);
+    double nk, dmean = 0.0, dstd = 0.0;
+    if (need_w) {
+        block_sum<3>(v3, S.red[0]);
+        nk = v3[0]; dmean = med + v3[1] / nk;
+        const double dvar = (v3[2] - v3[1] * v3[1] / nk) / nk;
+        dstd = sqrt(dvar > 0.0 ? dvar : 0.0);
+    } else {
+        if ((tid & 63) == 0) S.wcnt[wid] = nkeep;        // (its earlier content was consumed two barriers ago)
+        __syncthreads();
+        nk = (double)((S.wcnt[0] + S.wcnt[1]) + (S.wcnt[2] + S.wcnt[3]));
+    }
     if (tid == 0) { S.out[0] = (double)m; S.out[1] = med; S.out[2] = mad; S.out[3] = nk; S.out[4] = dmean; S.out[5] = dstd; }
     if (nk < 6.0) {
 #pragma unroll
@@ -436,7 +448,7 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         if (wid == 0) { flush_out(S, rec, REC_TICKET); publish(rec, A.seq); }
         return;
     }
-    const double w = (w_state > 0) ? w_state : 1.0 / (dstd * dstd);          // simpleicp.py:233-234 (frozen afterwards)
+    const double w = need_w ? 1.0 / (dstd * dstd) : w_state;          // simpleicp.py:233-234 (frozen afterwards)
     tk[3] = clock64();
 
     // ---- Levenberg-Marquardt on the fused 6x6 reductions (same acceptance rules as the host solver);
@@ -450,13 +462,16 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
     int steps = 0, evals = 0, cur = 1, tries = 0;
     bool first = true;
     double cost = 0.0, lambda = 0.0, dxmax = 0.0;
-    long long t_eval = 0, t_step = 0;
 #pragma unroll 1
     for (;;) {
-        long long tq = clock64();
         eval_ne<EPT>(S, xn, scn, C, rrn, cur ^ 1); ++evals;      // (its first barrier orders it after the last one's LDS reads)
-        t_eval += clock64() - tq;
         const double costn = objective(S.gf[wid][cur ^ 1], w, xn, A);
+        if (first && !need_w && tid == 0) {
+            // r = d at the start estimate: sum r, sum r^2, n of this evaluation ARE the kept distances' statistics
+            const double *G0 = S.gf[wid][cur ^ 1];
+            const double n0 = G0[7 * 8 + 7], mean0 = G0[6 * 8 + 7] / n0, var0 = G0[6 * 8 + 6] / n0 - mean0 * mean0;
+            S.out[4] = mean0; S.out[5] = sqrt(var0 > 0.0 ? var0 : 0.0);
+        }
         if (first || costn <= cost * (1 + 1e-12) || dxmax < 1e-15) {          // 1e-12: rounding noise of the sums
 #pragma unroll
             for (int j = 0; j < 6; ++j) { x[j] = xn[j]; sc[j] = scn[j]; }
@@ -483,9 +498,7 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         double dstep[6];
 #pragma unroll 1
         for (; tries < 40; ++tries) {
-            tq = clock64();
             ok = lm_step(S.gf[wid][cur], w, x, lambda, A, dstep);
-            t_step += clock64() - tq;
             dxmax = 0.0;
 #pragma unroll
             for (int j = 0; j < 6; ++j) { xn[j] = x[j] + dstep[j]; dxmax = fmax(dxmax, fabs(dstep[j])); }
@@ -504,19 +517,19 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
     }
     tk[4] = clock64();
 
-    // ---- residuals at the optimum (rr belongs to x: rejected trials only wrote rrn) + their mean / std ----
+    // ---- residuals at the optimum (rr belongs to x: rejected trials only wrote rrn); their mean / std (ddof 0) come
+    //      out of the accepted evaluation's Gram matrix: sum r, sum r^2, n (at the optimum |mean| is well below std, so
+    //      sum r^2 / n - mean^2 keeps its digits) ----
     const double *G = S.gf[wid][cur];
     const double gn = G[7 * 8 + 7];
     const double rmean = G[6 * 8 + 7] / gn;
-    double rss[1] = {0.0};
+    const double rvar = G[6 * 8 + 6] / gn - rmean * rmean;
+    const double rstd = sqrt(rvar > 0.0 ? rvar : 0.0);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + e * TB;
         if (i < Q) resid[i] = rr[e];
-        if (C.keep[e]) { const double t = rr[e] - rmean; rss[0] += t * t; }
     }
-    block_sum<1>(rss, S.red[1]);
-    const double rstd = sqrt(rss[0] / gn);
     const bool finite = cost < __builtin_inf();
     // convergence test of simpleicp.py:356-379 on (mean, std) of this and the previous iteration's residuals
     bool conv = false;
@@ -547,7 +560,7 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         tk[5] = clock64();
         for (int k = 0; k < 5; ++k) S.out[50 + k] = (double)(tk[k + 1] - tk[k]);
         S.out[55] = (double)(tsel - tk[1]); S.out[56] = rounds[0]; S.out[57] = (double)(tk[2] - tsel); S.out[58] = rounds[1];
-        S.out[59] = (double)t_eval; S.out[60] = (double)t_step;
+
     }
     flush_out(S, rec, REC_TICKET);
     publish(rec, A.seq);
