@@ -56,6 +56,25 @@ for tagc, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
             o.write(f"{k},{counter},{n},{v:.6g},{v / n:.6g}\n")
             per[k][counter] = v / n * 1024.0
 
+# SQ counter passes -> one text summary (per-launch averages of the kernels of the default path and the brute-force leg)
+lines = []
+for tagc in ("pmc_sq1", "pmc_sq2"):
+    files = newest(str(src / tagc / "**" / "*counter_collection.csv"))
+    if not files:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for r in csv.DictReader(open(files[0])):
+        k = short(r["Kernel_Name"])
+        if not any(x in k for x in ("grid_nn", "icp_tail", "knn1_f", "lm_eval", "lm_finish", "k_reject", "k_scatter", "k_cell_ids", "k_cloud_stats")):
+            continue
+        a = agg[k][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+    lines.append(f"# {tagc}: rocprofv3 --pmc pass over bench.py (scripts/gpu_profile.sh), per-launch averages")
+    for k, d in sorted(agg.items()):
+        lines.append(k + " " + str({c: f"{v / n:.4g}" for c, (v, n) in sorted(d.items())}))
+if lines:
+    (dst / "pmc_sq_summary.txt").write_text("\n".join(lines) + "\n")
+
 bench = {}
 try:
     bench = json.loads((src / "bench_trace.json").read_text().strip().splitlines()[-1])
