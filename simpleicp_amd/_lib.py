@@ -7,12 +7,14 @@ the host.  (The CPU oracle under oracle/ is test infrastructure and is not impor
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libsimpleicp_hip.so"
+# SICP_LIBRARY: load another build of the same ABI (the sanitizer build of tests/test_asan.py)
+LIB_PATH = Path(os.environ["SICP_LIBRARY"]) if os.environ.get("SICP_LIBRARY") else PKG / "libsimpleicp_hip.so"
 
 FIX, MOV = 0, 1
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_TOO_FEW, ERR_NUMERIC, ERR_EXCHANGE = 0, -1, -2, -3, -4, -5, -6

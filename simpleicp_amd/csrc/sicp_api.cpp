@@ -244,6 +244,9 @@ struct sicp_ctx {
     DevBuf<unsigned long long> match_work;                // [0] candidates evaluated, [1] grid rows visited, [2] launches (instrumented runs)
     DevBuf<unsigned long long> rj_keys;   // large-Q rejection scratch: Q keys + the selection state
     bool have_prev_match = false;  // m_p2 holds last iteration's winners (bound source)
+    DevBuf<uint32_t> q_order;      // large query sets: the queries [q_order_lo, +q_order_cnt) in cell order (search locality)
+    long q_order_lo = -1, q_order_cnt = 0;
+    long order_min_q = 32768;      // SICP_ORDER_MIN_Q: from this many queries per launch on (0: never)
     int last_match_kernel = 0;     // 0 exact scan, 1 filtered scan (inline), 2 grid, 3 filtered scan (record + fix-up)
     // ICP state (selected fixed points and per-iteration products)
     int64_t Q = 0, qpad = 0;
@@ -585,6 +588,53 @@ int grid_build(sicp_ctx *c, int slot)
     return SICP_OK;
 }
 
+// Permutation of the queries [lo, lo + cnt) by cell of a grid over their own bounding box (cell size: the cloud grid's, the
+// two frames differ by a near-rigid H), once per setup.  Only the ORDER in which waves take the queries changes -- every
+// result still lands at the query's own index -- so neighbouring waves walk the same rows of the cloud's grid.
+int query_order_build(sicp_ctx *c, long lo, long cnt, double h)
+{
+    if (c->q_order_lo == lo && c->q_order_cnt == cnt) return SICP_OK;
+    const double *qx = c->q.p + lo, *qy = c->q.p + c->qpad + lo, *qz = c->q.p + 2 * c->qpad + lo;
+    unsigned long long *d_st = (unsigned long long *)(c->small.p + 40);       // 7 u64
+    unsigned long long h_init[7] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull, 0ull};
+    HIPCHK(hipMemcpyAsync(d_st, h_init, sizeof h_init, hipMemcpyHostToDevice, c->stream));
+    launch_cloud_stats(c->stream, qx, qy, qz, cnt, d_st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_small + 40, d_st, 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CHK(sync(c));
+    unsigned long long hk[7]; std::memcpy(hk, c->h_small + 40, sizeof hk);
+    GridGeom G;
+    double ex[3];
+    for (int a = 0; a < 3; ++a) { G.mn[a] = key_to_double(hk[a]); ex[a] = key_to_double(hk[3 + a]) - G.mn[a]; }
+    if (!(h > 0) || !std::isfinite(h)) h = 1.0;
+    long ncells = 1;
+    for (;;) {
+        ncells = 1;
+        for (int a = 0; a < 3; ++a) {
+            double d = std::floor(ex[a] / h) + 1.0;
+            if (!(d >= 1.0)) d = 1.0;
+            if (d > 1.0e6) d = 1.0e6;
+            G.dim[a] = (int)d; ncells *= (long)G.dim[a];
+            if (ncells > (1L << 40)) ncells = 1L << 40;
+        }
+        if (ncells <= (1L << 25)) break;
+        h *= 1.3;
+    }
+    G.h = h; G.inv_h = 1.0 / h;
+    CHK(c->g_ids.reserve(cnt));
+    CHK(c->g_counts.reserve((size_t)ncells + 1));
+    CHK(c->g_cursor.reserve((size_t)ncells + 1));
+    CHK(c->g_blk.reserve((size_t)grid_scan_blocks(ncells) + 1));
+    CHK(c->q_order.reserve(cnt));
+    HIPCHK(hipMemsetAsync(c->g_counts.p, 0, ((size_t)ncells + 1) * sizeof(uint32_t), c->stream));
+    launch_cell_ids(c->stream, qx, qy, qz, cnt, G, c->g_ids.p, c->g_counts.p, nullptr);
+    launch_grid_scan(c->stream, c->g_counts.p, ncells, c->g_blk.p, nullptr, c->g_cursor.p);
+    launch_scatter_order(c->stream, c->g_ids.p, cnt, c->g_cursor.p, c->q_order.p);
+    HIPCHK(hipGetLastError());
+    c->q_order_lo = lo; c->q_order_cnt = cnt;
+    return SICP_OK;
+}
+
 // H (rows 0..2) rigid to working precision?  Then Hinv = [R^T | -R^T t].
 bool rigid_inverse(const Xf &H, Xf *inv)
 {
@@ -889,6 +939,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (rc == SICP_OK && hipMemsetAsync(c->ticket.p, 0, 4 * sizeof(unsigned), c->stream) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
     if (const char *e = std::getenv("SICP_LM_EVALS")) { const int d = std::atoi(e); if (d >= 0 && d <= 32) c->lm_evals = d; }
+    if (const char *e = std::getenv("SICP_ORDER_MIN_Q")) c->order_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
     if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : !std::strcmp(e, "mfma") ? 2 : 0;
     if (const char *e = std::getenv("SICP_FSCAN_CAP")) c->fscan_cap = std::atol(e);
@@ -911,7 +962,7 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &cl : c->cloud) { cl.xyz.release(); cl.pl.release(); cl.grid.cell_start.release(); cl.grid.rec.release(); }
-    c->g_ids.release(); c->g_counts.release(); c->g_cursor.release(); c->g_blk.release(); c->match_work.release(); c->rj_keys.release();
+    c->q_order.release(); c->g_ids.release(); c->g_counts.release(); c->g_cursor.release(); c->g_blk.release(); c->match_work.release(); c->rj_keys.release();
     c->stage.release(); c->part_d2.release(); c->part_idx.release(); c->kq.release(); c->k_d2.release();
     c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->hit_cnt.release(); c->hit_list.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
@@ -1205,6 +1256,7 @@ SICP_EXPORT int sicp_icp_setup(sicp_ctx *c, const int64_t *sel_idx, int64_t Q, c
     HIPCHK(hipMemcpyAsync(c->planarity.p, planarity, (size_t)Q * sizeof(float), hipMemcpyDefault, c->stream));
     c->have_iter = false;
     c->have_prev_match = false;
+    c->q_order_lo = -1; c->q_order_cnt = 0;
     return sync(c);
 }
 
@@ -1297,12 +1349,14 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 long lo = 0, cnt = Q;
                 if (qshard) cnt = query_slice(c, Q, &lo);
                 c->last_match_kernel = 2;
+                const bool ordered = c->order_min_q > 0 && cnt >= c->order_min_q;
+                if (ordered) CHK(query_order_build(c, lo, cnt, cl.grid.g.h));
                 Timed t(c, SICP_K_KNN1);
                 if (cnt > 0)
                     launch_grid_nn_chained(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt,
                                            prev ? prev + 3 * lo : nullptr, cl.grid.g, cl.grid.cell_start.p, cl.grid.rec.p,
                                            c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo, c->m_p2.p + 3 * lo,
-                                           c->count_work ? c->match_work.p : nullptr);
+                                           c->count_work ? c->match_work.p : nullptr, ordered ? c->q_order.p : nullptr);
             } else if (qshard) {
                 return fail(SICP_ERR_INVALID, "query shards need the grid search (SICP_KNN1 forces another kernel)");
             } else {
@@ -1336,15 +1390,14 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                     launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
                                      A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
                     {
+                        // median / MAD by digit selection over many workgroups, keep mask + kept statistics in one more pass
                         Timed t(c, SICP_K_SELECT);
-                        const size_t sb = (reject_select_scratch_bytes() + 7) / 8;
-                        CHK(c->rj_keys.reserve((size_t)Q + sb));
-                        if (reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->rj_keys.p, c->rj_keys.p + Q,
-                                             (unsigned long long *)(c->small.p + 56), c->icp_dev.p) != hipSuccess)
-                            return fail(SICP_ERR_HIP, "rejection by radix selection failed");
+                        CHK(c->rj_keys.reserve((reject_select_scratch_bytes() + 7) / 8));
+                        if (reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
+                                             (unsigned long long *)(c->small.p + 56), c->ne_partial.p, c->ticket.p, nullptr, 0.0,
+                                             c->icp_dev.p) != hipSuccess)
+                            return fail(SICP_ERR_HIP, "rejection by digit selection failed");
                     }
-                    launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4, nullptr, nullptr, 0.0, c->ne_partial.p, c->ticket.p,
-                                 c->icp_dev.p);
                 }
                 {
                     Timed t(c, SICP_K_NORMALEQ);
@@ -1421,23 +1474,23 @@ int iterate_host_lm(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
     launch_postmatch(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, c->m_p2.p,
                      c->m_idx.p, Q, X, (float)P->min_planarity, c->cloud[SICP_MOV].pl_n > 0 ? c->cloud[SICP_MOV].pl.p : nullptr,
                      c->cloud[SICP_MOV].pl_n, c->dist.p, c->flag.p);
+    double *h_st = c->h_small + 160;                      // pinned: [0..3] rejection, [4..6] n / mean / std, [15] ticket
+    double seq = (double)(++c->solve_seq);
     {
         Timed t(c, SICP_K_SELECT);
         if (Q > REJECT_MAX_Q) {
-            // one workgroup cannot chew a million distances: exact order statistics by multi-workgroup radix selection
-            const size_t sb = (reject_select_scratch_bytes() + 7) / 8;
-            CHK(c->rj_keys.reserve((size_t)Q + sb));
-            unsigned long long *small = (unsigned long long *)(c->small.p + 56);
-            if (reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->rj_keys.p, c->rj_keys.p + Q,
-                                 small) != hipSuccess)
-                return fail(SICP_ERR_HIP, "rejection by radix selection failed");
+            // one workgroup cannot chew a million distances: exact order statistics by multi-workgroup digit selection,
+            // keep mask and kept-distance statistics in its last pass
+            CHK(c->rj_keys.reserve((reject_select_scratch_bytes() + 7) / 8));
+            CHK(c->ne_partial.reserve((size_t)NE_MAX_GRID * 64));
+            if (reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
+                                 (unsigned long long *)(c->small.p + 56), c->ne_partial.p, c->ticket.p, h_st, seq) != hipSuccess)
+                return fail(SICP_ERR_HIP, "rejection by digit selection failed");
         } else {
             launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p);
+            launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4, c->small.p, h_st, seq, c->ne_partial.p, c->ticket.p);
         }
     }
-    double *h_st = c->h_small + 160;                      // pinned: [0..3] rejection, [4..6] n / mean / std, [15] ticket
-    double seq = (double)(++c->solve_seq);
-    launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4, c->small.p, h_st, seq, c->ne_partial.p, c->ticket.p);
     HIPCHK(hipGetLastError());
     CHK(wait_ticket(c, h_st + 15, seq));
     R->n_queries = Q;

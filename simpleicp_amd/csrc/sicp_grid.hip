@@ -18,6 +18,7 @@
 // full-size inputs).  The reference instead rebuilds a cKDTree on the transformed cloud every iteration
 // (corrpts.py:131, simpleicp.py:188-202).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <algorithm>
 #include <stdint.h>
 
@@ -27,6 +28,8 @@
 namespace sicp {
 
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+// from this many queries per launch on the search runs four queries per wave (k_grid_nn16); SICP_NN16_MIN_Q overrides (A/B runs)
+static const long GRID_NN16_MIN_Q = [] { const char *e = std::getenv("SICP_NN16_MIN_Q"); return e ? std::atol(e) : 32768L; }();
 
 __device__ __forceinline__ unsigned long long okey(double v)
 {
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void k_scan_blocks(uint32_t *__restrict__ bloc
         __syncthreads();
     }
 }
-// out[i] = sum of in[0..i) for i in [0, n]  (entry n = the grand total); cursor (nullable) receives a copy
+// out[i] = sum of in[0..i) for i in [0, n]  (entry n = the grand total); cursor receives a copy (either may be null)
 __global__ __launch_bounds__(256) void k_scan_final(const uint32_t *__restrict__ in, long n, const uint32_t *__restrict__ block_off,
                                                     uint32_t *__restrict__ out, uint32_t *__restrict__ cursor)
 {
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t *__restrict__
     unsigned run = block_off[blockIdx.x] + block_excl_scan(s, &total);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        if (base + k <= n) { out[base + k] = run; if (cursor && base + k < n) cursor[base + k] = run; }
+        if (base + k <= n) { if (out) out[base + k] = run; if (cursor && base + k < n) cursor[base + k] = run; }
         run += v[k];
     }
 }
@@ -234,6 +237,16 @@ __global__ __launch_bounds__(256) void k_scatter(const double *__restrict__ x, c
     if (i >= n) return;
     const uint32_t pos = atomicAdd(cursor + ids[i], 1u);
     rec[pos] = make_double4(x[i], y[i], z[i], __longlong_as_double((long long)i));
+}
+
+// the same counting sort for QUERIES, keeping only the permutation: order[slot] = query (large query sets are searched
+// in cell order so that waves running side by side read the same rows of the cloud's grid)
+__global__ __launch_bounds__(256) void k_scatter_order(const uint32_t *__restrict__ ids, long n, uint32_t *__restrict__ cursor,
+                                                       uint32_t *__restrict__ order)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    order[atomicAdd(cursor + ids[i], 1u)] = (uint32_t)i;
 }
 
 // ------------------------------------------------------------------------------------
@@ -263,10 +276,19 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     GridGeom G, const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
     Xf H, Xf Hinv, double rmax, double max_d2, int64_t idx_base,
     double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
-    const IcpDev *__restrict__ st, unsigned long long *__restrict__ work /* nullable: [0] candidates, [1] rows, [2] launches */)
+    const IcpDev *__restrict__ st, unsigned long long *__restrict__ work /* nullable: [0] candidates, [1] rows, [2] launches */,
+    const uint32_t *__restrict__ order /* nullable: queries in cell order (grid size is a multiple of 8 then) */)
 {
     const int lane = threadIdx.x & 63;
-    const long q = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    long q = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (order) {
+        // workgroups are dealt round-robin to the 8 XCDs: give each XCD one contiguous eighth of the ordered queries, so that
+        // the rows a neighbourhood of queries shares are fetched into ONE L2
+        const long per_xcd = gridDim.x >> 3;
+        q = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (q >= Q) return;
+        q = order[q];
+    }
     if (q >= Q) return;                                   // whole wave leaves together
     const double ax = qx[q], ay = qy[q], az = qz[q];      // (issued before the loop state is waited for)
     double px0 = 0, py0 = 0, pz0 = 0;
@@ -279,7 +301,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     if (XFORM) xf(Hinv, ax, ay, az, cxq, cyq, czq);
     // covers rounding of H^-1 q and |R^T R - I| ~ 1e-16: distances in the two frames agree to
     // ~1e-15 * scale; 1e-12 * scale leaves three orders of magnitude
-    const double scale = rmax + sqrt(fma(czq, czq, fma(cyq, cyq, cxq * cxq))) + 1.0;
+    const double scale = rmax + (fabs(cxq) + fabs(cyq) + fabs(czq)) + 1.0;     // (1-norm: an upper bound of |q| is all the slack needs)
     const double slack = 1e-12 * scale;
     double r_lim = (max_d2 < __builtin_inf()) ? sqrt(max_d2) * (1.0 + 1e-12) + slack : __builtin_inf();
     bool lim_is_bound = false;                            // r_lim is the distance to a cloud point: that ball is never empty
@@ -301,7 +323,8 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     double best = __builtin_inf(), bx = 0, by = 0, bz = 0;
     uint32_t bidx = 0xffffffffu;
     unsigned long long n_cand = 0, n_rows = 0;
-    for (int pass = 0; pass < 64; ++pass) {
+    bool last = false;
+    for (int pass = 0; pass < 4096; ++pass) {                 // (ends by itself: the radius doubles until it hits, then one more pass)
         int lo[3], hi[3];
         const double c3[3] = {cxq, cyq, czq};
         bool all = true;
@@ -378,9 +401,13 @@ __global__ __launch_bounds__(256) void k_grid_nn(
 #undef SICP_LEXMIN_STEP
         const bool found = bidx != 0xffffffffu;
         const bool winner = found && lbest == best && lidx == bidx;         // exactly one lane (indices are unique)
-        const double r_eff = (r - slack) / (1.0 + 1e-12);
-        const bool done = (found && sqrt(best) <= r_eff)      // nothing outside the ball can beat or tie it
-                          || all || r >= r_lim;               // searched everything that may qualify
+        // sqrt(best) + margin <= r, tested on the squares (no sqrt, no division).  The relative margin is HALF the one a
+        // follow-up radius carries (r = sqrt(best) * (1 + 1e-12) + slack below), so the pass after a shrink terminates.
+        const double r_eff = (r - slack) * (1.0 - 5e-13);
+        const double r_eff2 = r_eff > 0.0 ? r_eff * r_eff * (1.0 - 1e-15) : -1.0;
+        const bool done = (found && best <= r_eff2)           // nothing outside the ball can beat or tie it
+                          || all || r >= r_lim                // searched everything that may qualify
+                          || last;                            // this ball was sized to hold the previous pass's hit: it holds the answer
         if (done) {
             const bool ok = found && (best < max_d2);
             if (winner || (!found && lane == 0)) {
@@ -395,6 +422,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
             break;
         }
         r = found ? sqrt(best) * (1.0 + 1e-12) + slack : 2.0 * r;
+        last = found;
         if (r > r_lim) r = r_lim;
     }
     (void)lim_is_bound;
@@ -402,6 +430,158 @@ __global__ __launch_bounds__(256) void k_grid_nn(
         n_cand = wsum_u64(n_cand); n_rows = wsum_u64(n_rows);
         if (lane == 0) { atomicAdd(work, n_cand); atomicAdd(work + 1, n_rows); }
         if (q == 0 && lane == 0) atomicAdd(work + 2, 1ull);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// FOUR queries per wave (16 lanes each) -- the throughput flavour of k_grid_nn for large query sets.  With one wave
+// per query the search is bound by VALU issue once the machine is full (about 590 instructions per query of which
+// most lanes execute a handful usefully: a ball holds ~70 candidates in 2-3 rows); sharing the wave between four
+// queries divides the bookkeeping by four.  Same algorithm, same arithmetic, same answers: the 16 lanes of a group
+// are one DPP row, so the lexicographic minimum stays a register butterfly; row ranges travel inside the group by
+// ds_bpermute (per-group source lane: no uniform readlane).  Groups of a wave run in lock step and idle once done.
+// ------------------------------------------------------------------------------------
+template <bool XFORM, bool CHAINED>
+__global__ __launch_bounds__(256, 4) void k_grid_nn16(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, long Q,
+    const double *__restrict__ prev_p2, GridGeom G, const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
+    Xf H, Xf Hinv, double rmax, double max_d2, int64_t idx_base,
+    double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
+    const IcpDev *__restrict__ st, unsigned long long *__restrict__ work, const uint32_t *__restrict__ order)
+{
+    const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48;
+    long blk = blockIdx.x;
+    if (order) blk = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);     // one contiguous eighth per XCD
+    const long slot = (blk * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool active = slot < Q;
+    if (!__any(active)) return;
+    const long q = active ? (order ? (long)order[slot] : slot) : 0;
+    const double ax = qx[q], ay = qy[q], az = qz[q];
+    double px0 = 0, py0 = 0, pz0 = 0;
+    if (prev_p2) { px0 = prev_p2[3 * q]; py0 = prev_p2[3 * q + 1]; pz0 = prev_p2[3 * q + 2]; }
+    if (CHAINED) {
+        H = st->H; Hinv = st->Hinv;
+        if (st->stop) return;
+    }
+    double cxq = ax, cyq = ay, czq = az;
+    if (XFORM) xf(Hinv, ax, ay, az, cxq, cyq, czq);
+    const double scale = rmax + (fabs(cxq) + fabs(cyq) + fabs(czq)) + 1.0;     // (1-norm: an upper bound of |q| is all the slack needs)
+    const double slack = 1e-12 * scale;
+    double r_lim = (max_d2 < __builtin_inf()) ? sqrt(max_d2) * (1.0 + 1e-12) + slack : __builtin_inf();
+    if (prev_p2) {
+        double X = px0, Y = py0, Z = pz0;
+        if (XFORM) { double u, v, w; xf(H, X, Y, Z, u, v, w); X = u; Y = v; Z = w; }
+        const double dx = X - ax, dy = Y - ay, dz = Z - az;
+        const double bnd = fma(dz, dz, fma(dy, dy, dx * dx));
+        if (bnd < __builtin_inf()) {
+            const double rb = sqrt(bnd) * (1.0 + 1e-12) + slack;
+            if (rb < r_lim) r_lim = rb;
+        }
+    }
+    double r = 0.75 * G.h;
+    if (r > r_lim) r = r_lim;
+
+    bool done = !active, last = false;
+    unsigned long long n_cand = 0, n_rows = 0;
+    for (int pass = 0; pass < 4096 && __any(!done); ++pass) {
+        int lo[3], hi[3];
+        const double c3[3] = {cxq, cyq, czq};
+        bool all = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double fl = floor((c3[a] - r - G.mn[a]) * G.inv_h - 1e-6);
+            const double fh = floor((c3[a] + r - G.mn[a]) * G.inv_h + 1e-6);
+            lo[a] = fl < 0.0 ? 0 : (fl > (double)(G.dim[a] - 1) ? G.dim[a] - 1 : (int)fl);
+            hi[a] = fh < 0.0 ? 0 : (fh > (double)(G.dim[a] - 1) ? G.dim[a] - 1 : (int)fh);
+            all = all && (fl <= 0.0) && (fh >= (double)(G.dim[a] - 1));
+        }
+        double best = __builtin_inf();
+        uint32_t bidx = 0xffffffffu, bpos = 0;         // (record position: the group's winner re-reads its coordinates at the end)
+        const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
+        const long nrows = done ? 0 : (long)ny * nz;
+        for (long rb = 0; __any(rb < nrows); rb += 16) {
+            uint32_t b = 0, len = 0;
+            if (rb + gl < nrows) {
+                const long rr = rb + gl;
+                const int cy = lo[1] + (int)(rr % ny), cz = lo[2] + (int)(rr / ny);
+                const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
+                b = cell_start[row + lo[0]];
+                len = cell_start[row + hi[0] + 1] - b;
+            }
+            unsigned todo = (unsigned)(__ballot(len > 0) >> gbase) & 0xffffu;      // this group's rows that hold points
+            if (work && len > 0) n_rows += 1;
+            while (__any(todo != 0u)) {
+                uint32_t rbv[2], rlv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bool has = todo != 0u;
+                    const int j = has ? __ffs((int)todo) - 1 : 0;
+                    todo &= todo - 1u;
+                    const uint32_t vb = (uint32_t)__shfl((int)b, gbase + j), vl = (uint32_t)__shfl((int)len, gbase + j);
+                    rbv[u] = has ? vb : 0u; rlv[u] = has ? vl : 0u;
+                }
+                const uint32_t longest = rlv[0] > rlv[1] ? rlv[0] : rlv[1];
+                for (uint32_t o = 0; __any(o < longest); o += 16) {
+                    double4 P[2];
+                    bool ok[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        ok[u] = o + (uint32_t)gl < rlv[u];
+                        P[u] = rec[ok[u] ? rbv[u] + o + (uint32_t)gl : 0u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (!ok[u]) continue;
+                        double X = P[u].x, Y = P[u].y, Z = P[u].z;
+                        if (XFORM) { double a2, b2, c2; xf(H, X, Y, Z, a2, b2, c2); X = a2; Y = b2; Z = c2; }
+                        const double dx = X - ax, dy = Y - ay, dz = Z - az;
+                        const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                        const uint32_t oi = (uint32_t)__double_as_longlong(P[u].w);
+                        if (d2 < best || (d2 == best && oi < bidx)) { best = d2; bidx = oi; bpos = rbv[u] + o + (uint32_t)gl; }
+                    }
+                    if (work) { for (int u = 0; u < 2; ++u) n_cand += ok[u] ? 1 : 0; }
+                }
+            }
+        }
+        // lexicographic (d2, original index) minimum over the group's 16 lanes (one DPP row)
+        const double lbest = best; const uint32_t lidx = bidx;
+#define SICP_LEXMIN_STEP(J)                                                                       \
+        {                                                                                         \
+            const double od = lane_xor_f64<J>(best);                                              \
+            const uint32_t oi = lane_xor32<J>(bidx);                                              \
+            if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; }                 \
+        }
+        SICP_LEXMIN_STEP(8) SICP_LEXMIN_STEP(4) SICP_LEXMIN_STEP(2) SICP_LEXMIN_STEP(1)
+#undef SICP_LEXMIN_STEP
+        if (!done) {
+            const bool found = bidx != 0xffffffffu;
+            const bool winner = found && lbest == best && lidx == bidx;
+            const double r_eff = (r - slack) * (1.0 - 5e-13);
+            const double r_eff2 = r_eff > 0.0 ? r_eff * r_eff * (1.0 - 1e-15) : -1.0;
+            const bool fin = (found && best <= r_eff2) || all || r >= r_lim || last;
+            if (fin) {
+                const bool ok = found && (best < max_d2);
+                if (winner || (!found && gl == 0)) {
+                    d2_out[q] = ok ? best : __builtin_inf();
+                    idx_out[q] = ok ? idx_base + (int64_t)bidx : (int64_t)-1;
+                    if (p2_out) {
+                        double4 W = make_double4(0.0, 0.0, 0.0, 0.0);
+                        if (ok) W = rec[bpos];
+                        p2_out[3 * q] = W.x; p2_out[3 * q + 1] = W.y; p2_out[3 * q + 2] = W.z;
+                    }
+                }
+                done = true;
+            } else {
+                r = found ? sqrt(best) * (1.0 + 1e-12) + slack : 2.0 * r;
+                last = found;
+                if (r > r_lim) r = r_lim;
+            }
+        }
+    }
+    if (work) {
+        n_cand = wsum_u64(n_cand); n_rows = wsum_u64(n_rows);
+        if (lane == 0) { atomicAdd(work, n_cand); atomicAdd(work + 1, n_rows); }
+        if (slot == 0 && gl == 0) atomicAdd(work + 2, 1ull);
     }
 }
 
@@ -499,9 +679,18 @@ __global__ __launch_bounds__(256) void k_grid_knn(
 }
 
 // ------------------------------------------------------------------------------------
-// median / raw-MAD rejection for LARGE Q (corrpts.py:165-188): exact order statistics by radix
-// SELECTION over many workgroups on the order-preserving uint64 image of the distances, everything
-// chained on the stream without a host round trip.  out4 = (m, median, mad, n_kept) like k_reject.
+// median / raw-MAD rejection for LARGE Q (corrpts.py:165-188): exact order statistics by digit SELECTION over many
+// workgroups on the order-preserving uint64 image of the distances -- keys are formed on the fly from (dist, flag),
+// nothing is sorted, nothing but ~35 KB of state is written -- everything chained on the stream without a host
+// round trip.  out4 = (m, median, mad, n_kept), out3 = (n, mean, std) of the kept distances.
+//
+// One statistic = up to six digit passes (12 + 12 + 12 + 12 + 12 + 4 bits from the top) and one finishing launch.
+// A pass histograms the digit of every key that still matches the prefix (LDS, wave-aggregated: distances share sign
+// and exponent, whole waves hit one bin), adds its non-empty bins to the global histogram, and the LAST block to
+// arrive (agent-scope ticket) picks the bin that holds the wanted rank.  As soon as that bin holds <= HS_CAP keys the
+// statistic is `done`: the remaining pass launches exit at once (they are enqueued anyway: no host decision inside a
+// chained iteration), and the finishing launch collects the few survivors, ranks them exactly and takes the mean of
+// the two middle values.  Real distances need two passes (sign/exponent, then 12 mantissa bits leave ~Q/4096 keys).
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ double oval64(unsigned long long k)
 {
@@ -509,67 +698,21 @@ __device__ __forceinline__ double oval64(unsigned long long k)
     return __longlong_as_double((long long)b);
 }
 
-// one atomic per BLOCK: 16 k waves adding to one word serialise in L2 for hundreds of microseconds at Q = 1 M
-__device__ __forceinline__ void block_add_u64(unsigned long long c, unsigned long long *dst)
-{
-    __shared__ unsigned long long part[4];
-    c = wsum_u64(c);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long t = (part[0] + part[1]) + (part[2] + part[3]);
-        if (t) atomicAdd(dst, t);
-    }
-}
-
-// keys of flagged distances (or of |d - med| when center != null), ~0 for the rest; counts the flagged
-__global__ __launch_bounds__(256) void k_reject_keys(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
-                                                     const double *__restrict__ center, unsigned long long *__restrict__ keys,
-                                                     unsigned long long *__restrict__ count, const IcpDev *__restrict__ st)
-{
-    if (st && st->stop) return;
-    unsigned long long c = 0;
-    const double ctr = center ? center[0] : 0.0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < Q; i += (long)gridDim.x * 256) {
-        const bool f = flag[i] != 0;
-        const double v = center ? fabs(dist[i] - ctr) : dist[i];
-        keys[i] = f ? okey(v) : ~0ull;
-        c += f ? 1 : 0;
-    }
-    if (count) block_add_u64(c, count);
-}
-
-__global__ __launch_bounds__(256) void k_reject_keep(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
-                                                     const double *__restrict__ med_mad, uint8_t *__restrict__ keep,
-                                                     unsigned long long *__restrict__ kept, const IcpDev *__restrict__ st)
-{
-    if (st && st->stop) return;
-    unsigned long long c = 0;
-    const double med = med_mad[0], bound = 3 * med_mad[1];
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < Q; i += (long)gridDim.x * 256) {
-        const uint8_t k = (flag[i] && fabs(dist[i] - med) <= bound) ? 1 : 0;
-        keep[i] = k; c += k;
-    }
-    block_add_u64(c, kept);
-}
-
-__global__ void k_reject_finish(const unsigned long long *__restrict__ counts /*[0]=m,[1]=kept*/,
-                                const double *__restrict__ med_mad, double *__restrict__ out4, const IcpDev *__restrict__ st)
-{
-    if (st && st->stop) return;
-    out4[0] = (double)counts[0]; out4[1] = med_mad[0]; out4[2] = med_mad[1]; out4[3] = (double)counts[1];
-}
-
-// ---- exact order statistics over many workgroups: 11-bit-digit radix selection ------------------------
-// State (device): st[0] = key prefix selected so far, st[1] = rank inside it, st[2] = #keys <= the selected
-// key, st[3] = smallest key above it; hist = 2048 global bins; one ticket.  Every pass is one launch: each
-// block histograms the keys that still match the prefix in LDS (wave-aggregated: distances share their
-// sign/exponent bits, so whole waves hit one bin in the early passes), adds its non-empty bins to the
-// global histogram, and the LAST block to arrive picks the bin holding the rank, extends the prefix and
-// clears the histogram for the next launch.  Six passes (5 x 11 + 9 bits) read the keys six times --
-// against two full 64-bit device sorts before (0.75 ms at Q = 1 M).
-constexpr int RSEL_BINS = 2048;
-struct RselState { unsigned long long st[8]; unsigned hist[RSEL_BINS]; unsigned ticket; };
+constexpr int HS_BINS = 4096, HS_CAP = 256, HS_PASSES = 6, HS_UNROLL = 4;
+struct HselState {
+    unsigned long long prefix;     // digits selected so far (low bits zero)
+    unsigned long long rank;       // wanted rank among the keys that match the prefix
+    unsigned long long m;          // number of valid keys (pass 0)
+    unsigned long long nxt;        // finish: smallest key above the prefix interval
+    int fixed;                     // number of leading bits the prefix fixes
+    int done;                      // the prefix interval holds <= HS_CAP keys, or every bit is fixed
+    unsigned cnt;                  // keys inside the prefix interval
+    unsigned ncand;                // finish: candidates appended
+    unsigned ticket;
+    unsigned pad;
+    unsigned hist[HS_BINS];
+    unsigned long long cand[HS_CAP];
+};
 
 __device__ __forceinline__ bool last_block_arrives(unsigned *ticket, int *is_last_lds)
 {
@@ -586,131 +729,268 @@ __device__ __forceinline__ bool last_block_arrives(unsigned *ticket, int *is_las
     return *is_last_lds != 0;
 }
 
-__global__ __launch_bounds__(256) void k_rsel_pass(const unsigned long long *__restrict__ keys, long Q, int pass,
-                                                   RselState *__restrict__ S, const unsigned long long *__restrict__ count,
-                                                   const IcpDev *__restrict__ st)
+// the same for a block whose only publications are device-scope ATOMICS (histogram bins, candidate appends, minima):
+// they are performed at the coherence point already, no write-back of plain stores to order before the ticket
+__device__ __forceinline__ bool last_block_arrives_atomics(unsigned *ticket, int *is_last_lds)
 {
-    __shared__ unsigned hist[RSEL_BINS];
-    if (st && st->stop) return;
-    __shared__ unsigned scan[4];               // wave totals of the last block's prefix scan
-    __shared__ int is_last;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int shift = pass < 5 ? 53 - 11 * pass : 0, bits = pass < 5 ? 11 : 9;
-    const unsigned mask = (1u << bits) - 1u;
-    const unsigned long long prefix = S->st[0];
-    for (int i = tid; i < RSEL_BINS; i += 256) hist[i] = 0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    const long stride = (long)gridDim.x * 256;
-    for (long base = (long)blockIdx.x * 256; base < Q; base += stride) {        // wave-uniform trip count
-        const long i = base + tid;
-        const unsigned long long k = i < Q ? keys[i] : ~0ull;
-        bool act = k != ~0ull && (pass == 0 || (k >> (shift + bits)) == (prefix >> (shift + bits)));
-        const unsigned bin = (unsigned)(k >> shift) & mask;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const unsigned long long am = __ballot(act);
-            if (am == 0) break;
-            const int leader = __ffsll((long long)am) - 1;
-            const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
-            const unsigned long long same = __ballot(act && bin == b0);
-            if (lane == leader) atomicAdd(&hist[b0], (unsigned)__popcll(same));
-            act = act && bin != b0;
-        }
-        if (act) atomicAdd(&hist[bin], 1u);
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *is_last_lds = (t == gridDim.x - 1) ? 1 : 0;
+        if (*is_last_lds) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    for (int i = tid; i < RSEL_BINS; i += 256) if (hist[i]) atomicAdd(&S->hist[i], hist[i]);
-    if (!last_block_arrives(&S->ticket, &is_last)) return;
-    // thread t owns bins 8t..8t+7 of the complete histogram
-    unsigned h[8], mine = 0;
+    return *is_last_lds != 0;
+}
+
+// key of correspondence i for the statistic at hand: the distance itself (median) or |d - median| (MAD); ~0 = not a candidate
+template <bool ABS>
+__device__ __forceinline__ unsigned long long hs_key(double d, uint8_t f, double ctr)
+{
+    return f ? okey(ABS ? fabs(d - ctr) : d) : ~0ull;
+}
+
+template <bool ABS>
+__global__ __launch_bounds__(256) void k_hsel_pass(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q, int pass,
+                                                   HselState *__restrict__ S, const double *__restrict__ center,
+                                                   const IcpDev *__restrict__ st)
+{
+    __shared__ unsigned hist[HS_BINS];
+    __shared__ unsigned scan[4];
+    __shared__ int is_last;
+    if (st && st->stop) return;
+    if (S->done) return;                                        // (written by an earlier launch: uniform)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bits = pass < 5 ? 12 : 4, shift = pass < 5 ? 52 - 12 * pass : 0;
+    const unsigned mask = (1u << bits) - 1u;
+    const unsigned long long prefix = S->prefix;
+    const double ctr = ABS ? center[0] : 0.0;
+    for (int i = tid; i < HS_BINS; i += 256) hist[i] = 0;
+    __syncthreads();
+    const long stride = (long)gridDim.x * (256 * HS_UNROLL);
+    for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {      // block-uniform trip count
+        double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { h[j] = S->hist[8 * tid + j]; mine += h[j]; S->hist[8 * tid + j] = 0; }
-    // exclusive prefix of the 256 per-thread counts: DPP scan inside each wave + the three wave totals before it
+        for (int u = 0; u < HS_UNROLL; ++u) {                   // all loads first
+            const long i = base + u * 256 + tid;
+            f[u] = i < Q ? flag[i] : (uint8_t)0;
+            d[u] = i < Q ? dist[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < HS_UNROLL; ++u) {
+            const unsigned long long k = hs_key<ABS>(d[u], f[u], ctr);
+            bool act = f[u] && (pass == 0 || (k >> (shift + bits)) == (prefix >> (shift + bits)));
+            const unsigned bin = (unsigned)(k >> shift) & mask;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned long long am = __ballot(act);
+                if (am == 0) break;
+                const int leader = __ffsll((long long)am) - 1;
+                const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+                const unsigned long long same = __ballot(act && bin == b0);
+                if (lane == leader) atomicAdd(&hist[b0], (unsigned)__popcll(same));
+                act = act && bin != b0;
+            }
+            if (act) atomicAdd(&hist[bin], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < HS_BINS; i += 256) if (hist[i]) atomicAdd(&S->hist[i], hist[i]);
+    if (!last_block_arrives_atomics(&S->ticket, &is_last)) return;
+    // thread t owns bins 16t .. 16t+15 of the complete histogram
+    unsigned h[16], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { h[j] = S->hist[16 * tid + j]; mine += h[j]; S->hist[16 * tid + j] = 0; }
     const unsigned incl = wscan_u32(mine);
     if (lane == 63) scan[tid >> 6] = incl;
-    if (tid == 0) S->ticket = 0;
-    const long m = (long)count[0];
-    const unsigned long long rank = pass == 0 ? (unsigned long long)((m - 1) / 2) : S->st[1];   // (read by all BEFORE the
-    __syncthreads();                                                                            //  owner of the bin rewrites it)
+    const unsigned long long rank_in = S->rank;                 // (read by all before the owner of the bin rewrites it)
+    __syncthreads();
     unsigned before = 0;
     for (int w = 0; w < (tid >> 6); ++w) before += scan[w];
-    const unsigned excl = before + incl - mine;
-    unsigned long long acc = excl;
+    const unsigned long long total = (unsigned long long)scan[0] + scan[1] + scan[2] + scan[3];
+    const unsigned long long m = pass == 0 ? total : S->m;
+    const unsigned long long rank = pass == 0 ? (m ? (m - 1) / 2 : 0) : rank_in;
+    if (tid == 0) {
+        S->ticket = 0;
+        if (pass == 0) { S->m = m; if (m == 0) { S->done = 1; S->cnt = 0; S->fixed = 0; } }
+    }
+    unsigned long long acc = before + incl - mine;
     if (m > 0 && rank >= acc && rank < acc + mine) {
         int j = 0;
         while (rank >= acc + h[j]) { acc += h[j]; ++j; }
-        S->st[0] = prefix | ((unsigned long long)(8 * tid + j) << shift);
-        S->st[1] = rank - acc;
-        if (pass == 5) { S->st[2] = 0; S->st[3] = ~0ull; }
+        S->prefix = prefix | ((unsigned long long)(16 * tid + j) << shift);
+        S->rank = rank - acc;
+        S->cnt = h[j];
+        S->fixed = 64 - shift;
+        S->done = (h[j] <= (unsigned)HS_CAP || pass == HS_PASSES - 1) ? 1 : 0;
     }
 }
 
-// second middle value + their mean: dst[0] = np.median of the keys' values (NaN when there are none)
-__global__ __launch_bounds__(256) void k_rsel_finish(const unsigned long long *__restrict__ keys, long Q,
-                                                     RselState *__restrict__ S, const unsigned long long *__restrict__ count,
-                                                     double *__restrict__ dst, const IcpDev *__restrict__ st)
+// collects the survivors of the prefix interval, finds the smallest key above it, and (last block) ranks the survivors:
+// dst[0] = mean of the two middle values = np.median (NaN without candidates).  Resets the state for the next statistic.
+template <bool ABS>
+__global__ __launch_bounds__(256) void k_hsel_finish(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
+                                                     HselState *__restrict__ S, const double *__restrict__ center,
+                                                     double *__restrict__ dst, unsigned long long *__restrict__ m_out,
+                                                     const IcpDev *__restrict__ st)
 {
+    __shared__ unsigned long long sc[HS_CAP];
+    __shared__ unsigned long long pnx[4], pick[2];
     __shared__ int is_last;
     if (st && st->stop) return;
     const int tid = threadIdx.x, lane = tid & 63;
-    const unsigned long long ka = S->st[0];
-    unsigned long long le = 0, nxt = ~0ull;
-    for (long i = (long)blockIdx.x * 256 + tid; i < Q; i += (long)gridDim.x * 256) {
-        const unsigned long long k = keys[i];
-        if (k <= ka) le += 1; else nxt = k < nxt ? k : nxt;
+    const unsigned long long prefix = S->prefix, m = S->m;
+    const int fixed = S->fixed;
+    const unsigned cnt = S->cnt;
+    const bool collect = cnt <= (unsigned)HS_CAP;               // otherwise every bit is fixed: the interval is ONE value
+    const unsigned long long hi = fixed >= 64 ? prefix : (prefix | (~0ull >> fixed));
+    const double ctr = ABS ? center[0] : 0.0;
+    unsigned long long nxt = ~0ull;
+    if (m > 0) {
+        const long stride = (long)gridDim.x * (256 * HS_UNROLL);
+        for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {
+            double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < HS_UNROLL; ++u) {
+                const long i = base + u * 256 + tid;
+                f[u] = i < Q ? flag[i] : (uint8_t)0;
+                d[u] = i < Q ? dist[i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < HS_UNROLL; ++u) {
+                if (!f[u]) continue;
+                const unsigned long long k = hs_key<ABS>(d[u], f[u], ctr);
+                if (k > hi) nxt = k < nxt ? k : nxt;
+                else if (collect && k >= prefix) { const unsigned pos = atomicAdd(&S->ncand, 1u); if (pos < (unsigned)HS_CAP) __hip_atomic_store(&S->cand[pos], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            }
+        }
     }
-    le = wsum_u64(le);
     { unsigned long long o;
       o = lane_xor64<32>(nxt); nxt = o < nxt ? o : nxt;  o = lane_xor64<16>(nxt); nxt = o < nxt ? o : nxt;
       o = lane_xor64<8>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<4>(nxt);  nxt = o < nxt ? o : nxt;
       o = lane_xor64<2>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<1>(nxt);  nxt = o < nxt ? o : nxt; }
-    __shared__ unsigned long long ple[4], pnx[4];
-    if (lane == 0) { ple[tid >> 6] = le; pnx[tid >> 6] = nxt; }
+    if (lane == 0) pnx[tid >> 6] = nxt;
     __syncthreads();
     if (tid == 0) {
-        const unsigned long long tl = (ple[0] + ple[1]) + (ple[2] + ple[3]);
         unsigned long long tn = pnx[0];
         for (int w = 1; w < 4; ++w) tn = pnx[w] < tn ? pnx[w] : tn;
-        if (tl) atomicAdd(&S->st[2], tl);
-        if (tn != ~0ull) atomicMin(&S->st[3], tn);
+        if (tn != ~0ull) atomicMin(&S->nxt, tn);
     }
     if (!last_block_arrives(&S->ticket, &is_last)) return;
+    const unsigned long long rank = S->rank, above = S->nxt;
+    if (tid < 2) pick[tid] = prefix;                            // (single-value interval: both middles are that value unless ...)
+    if (collect) {
+        if (tid < (int)cnt) sc[tid] = S->cand[tid];
+        __syncthreads();
+        if (tid < (int)cnt) {
+            const unsigned long long k = sc[tid];
+            unsigned r = 0;
+            for (unsigned j = 0; j < cnt; ++j) { const unsigned long long o = sc[j]; r += (o < k || (o == k && j < (unsigned)tid)) ? 1u : 0u; }
+            if (r == rank) pick[0] = k;
+            if (r == rank + 1) pick[1] = k;
+        }
+    }
+    __syncthreads();
     if (tid == 0) {
-        const long m = (long)count[0];
-        const long r = (m - 1) / 2;
-        const unsigned long long kb = ((m & 1) || (long)S->st[2] >= r + 2) ? ka : S->st[3];
+        const unsigned long long ka = pick[0];
+        unsigned long long kb = ka;
+        if (!(m & 1)) kb = (rank + 1 < cnt) ? pick[1] : above;    // even count: the next value up, inside the interval or just above it
         dst[0] = m > 0 ? (oval64(ka) + oval64(kb)) / 2.0 : __builtin_nan("");
-        S->st[0] = 0; S->st[1] = 0; S->ticket = 0;
+        if (m_out) *m_out = m;
+        S->prefix = 0; S->rank = 0; S->m = 0; S->nxt = ~0ull; S->fixed = 0; S->done = 0; S->cnt = 0; S->ncand = 0; S->ticket = 0;
     }
 }
 
-size_t reject_select_scratch_bytes() { return sizeof(RselState); }
-
-// scratch: keys (Q u64), state (reject_select_scratch_bytes), small (4 u64/doubles: m, kept, med, mad)
-hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
-                            unsigned long long *keys, void *state, unsigned long long *small, const IcpDev *st)
+// keep mask of the rejection (corrpts.py:182-188: |d - median| <= 3 * MAD among the flagged) and, in the same pass, count /
+// mean / std of the kept distances -- sums taken relative to the median, so one pass loses nothing to cancellation.
+// Block partials are folded by the last block to arrive in a fixed order.  out4 = (m, median, mad, n_kept), out3 = (n, mean, std).
+__global__ __launch_bounds__(256) void k_keep_stats(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
+                                                    const double *__restrict__ med_mad, const unsigned long long *__restrict__ m_in,
+                                                    uint8_t *__restrict__ keep, double *__restrict__ partial /*[3][NE_MAX_GRID]*/,
+                                                    unsigned *__restrict__ ticket, double *__restrict__ out4, double *__restrict__ out3,
+                                                    double *__restrict__ host_out, double seq, const IcpDev *__restrict__ st)
 {
-    unsigned long long *counts = small;            // [0] m, [1] kept
-    double *med_mad = (double *)(small + 2);       // [0] median, [1] mad
-    RselState *S = (RselState *)state;
-    // (a chained launch that finds the run over skips every kernel below: the zeroed scratch is never read)
-    hipError_t e = hipMemsetAsync(small, 0, 4 * sizeof(unsigned long long), s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(state, 0, sizeof(RselState), s);
-    if (e != hipSuccess) return e;
-    const unsigned g = (unsigned)std::min<long>(2048, (Q + 255) / 256);
-    const unsigned gs = (unsigned)std::min<long>(512, (Q + 1023) / 1024);
-    for (int stat = 0; stat < 2; ++stat) {
-        hipLaunchKernelGGL(k_reject_keys, dim3(g), dim3(256), 0, s, dist, flag, Q, stat ? (const double *)med_mad : nullptr, keys,
-                           stat ? (unsigned long long *)nullptr : counts, st);
-        for (int pass = 0; pass < 6; ++pass)
-            hipLaunchKernelGGL(k_rsel_pass, dim3(gs), dim3(256), 0, s, (const unsigned long long *)keys, Q, pass, S,
-                               (const unsigned long long *)counts, st);
-        hipLaunchKernelGGL(k_rsel_finish, dim3(gs), dim3(256), 0, s, (const unsigned long long *)keys, Q, S,
-                           (const unsigned long long *)counts, med_mad + stat, st);
+    __shared__ double red[4][3];
+    __shared__ int is_last;
+    if (st && st->stop) return;
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const double med = med_mad[0], bound = 3 * med_mad[1];
+    double n = 0, s1 = 0, s2 = 0;
+    const long stride = (long)gridDim.x * (256 * HS_UNROLL);
+    for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {
+        double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < HS_UNROLL; ++u) {
+            const long i = base + u * 256 + tid;
+            f[u] = i < Q ? flag[i] : (uint8_t)0;
+            d[u] = i < Q ? dist[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < HS_UNROLL; ++u) {
+            const long i = base + u * 256 + tid;
+            const double e = d[u] - med;
+            const bool k = f[u] && fabs(e) <= bound;
+            if (i < Q) keep[i] = k ? 1 : 0;
+            if (k) { n += 1.0; s1 += e; s2 += e * e; }
+        }
     }
-    hipLaunchKernelGGL(k_reject_keep, dim3(g), dim3(256), 0, s, dist, flag, Q, (const double *)med_mad, keep, counts + 1, st);
-    hipLaunchKernelGGL(k_reject_finish, dim3(1), dim3(1), 0, s, counts, (const double *)med_mad, out4, st);
+    n = wsum(n); s1 = wsum(s1); s2 = wsum(s2);
+    if (lane == 0) { red[wid][0] = n; red[wid][1] = s1; red[wid][2] = s2; }
+    __syncthreads();
+    if (tid < 3) partial[(long)tid * NE_MAX_GRID + blockIdx.x] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (!last_block_arrives(ticket, &is_last)) return;
+    if (wid < 3) {
+        double t = 0;
+        for (unsigned blk = lane; blk < gridDim.x; blk += 64) t += partial[(long)wid * NE_MAX_GRID + blk];
+        t = wsum(t);
+        if (lane == 0) red[0][wid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        *ticket = 0;
+        const double cnt = red[0][0], mu = red[0][1] / cnt;
+        const double var = red[0][2] / cnt - mu * mu;
+        const double mean = med + mu, sd = sqrt(var > 0.0 ? var : 0.0);
+        out4[0] = (double)m_in[0]; out4[1] = med; out4[2] = med_mad[1]; out4[3] = cnt;
+        out3[0] = cnt; out3[1] = mean; out3[2] = sd;
+        if (host_out) {
+            host_out[0] = out4[0]; host_out[1] = med; host_out[2] = med_mad[1]; host_out[3] = cnt;
+            host_out[4] = cnt; host_out[5] = mean; host_out[6] = sd;
+            __threadfence_system();
+            __hip_atomic_store(host_out + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+size_t reject_select_scratch_bytes() { return sizeof(HselState); }
+
+// state: reject_select_scratch_bytes() of device scratch; small: 4 x 8 bytes ([0] m, [2] median, [3] mad);
+// partial / ticket: the solver's block-partial scratch (3 * NE_MAX_GRID doubles) and its ticket word
+hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, double *out3,
+                            void *state, unsigned long long *small, double *partial, unsigned *ticket, double *host_out, double seq,
+                            const IcpDev *st)
+{
+    double *med_mad = (double *)(small + 2);       // [0] median, [1] mad
+    HselState *S = (HselState *)state;
+    // (a chained launch that finds the run over skips every kernel below: the scratch is never read)
+    hipError_t e = hipMemsetAsync(state, 0, sizeof(HselState), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(&S->nxt, 0xff, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    // every block ends with ONE same-address ticket atomic, and those serialise at ~20 ns apiece across the 8 XCDs (measured:
+    // 1024 blocks 28 us, 256 blocks 12 us for the same 9 MB) -- so few, fat blocks: one per CU
+    static const long cap = [] { const char *e = std::getenv("SICP_HS_GRID"); const long v = e ? std::atol(e) : 0; return v > 0 && v <= NE_MAX_GRID ? v : 256L; }();
+    const unsigned g = (unsigned)std::min<long>(cap, (Q + 256 * HS_UNROLL - 1) / (256 * HS_UNROLL));
+    for (int pass = 0; pass < HS_PASSES; ++pass)
+        hipLaunchKernelGGL((k_hsel_pass<false>), dim3(g), dim3(256), 0, s, dist, flag, Q, pass, S, (const double *)nullptr, st);
+    hipLaunchKernelGGL((k_hsel_finish<false>), dim3(g), dim3(256), 0, s, dist, flag, Q, S, (const double *)nullptr, med_mad, small, st);
+    for (int pass = 0; pass < HS_PASSES; ++pass)
+        hipLaunchKernelGGL((k_hsel_pass<true>), dim3(g), dim3(256), 0, s, dist, flag, Q, pass, S, (const double *)med_mad, st);
+    hipLaunchKernelGGL((k_hsel_finish<true>), dim3(g), dim3(256), 0, s, dist, flag, Q, S, (const double *)med_mad, med_mad + 1,
+                       (unsigned long long *)nullptr, st);
+    hipLaunchKernelGGL(k_keep_stats, dim3(g), dim3(256), 0, s, dist, flag, Q, (const double *)med_mad, (const unsigned long long *)small,
+                       keep, partial, ticket, out4, out3, host_out, seq, st);
     return hipGetLastError();
 }
 
@@ -765,22 +1045,49 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
 {
     const dim3 grid(cdiv(Q, 4)), block(256);
     Xf id = {};
+    if (Q >= GRID_NN16_MIN_Q) {
+        const dim3 g16(cdiv(Q, 16));
+        if (H)
+            hipLaunchKernelGGL((k_grid_nn16<true, false>), g16, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec,
+                               *H, *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work,
+                               (const uint32_t *)nullptr);
+        else
+            hipLaunchKernelGGL((k_grid_nn16<false, false>), g16, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec,
+                               id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work,
+                               (const uint32_t *)nullptr);
+        return;
+    }
     if (H)
         hipLaunchKernelGGL((k_grid_nn<true, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec, *H,
-                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work);
+                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work, (const uint32_t *)nullptr);
     else
         hipLaunchKernelGGL((k_grid_nn<false, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec, id,
-                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work);
+                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work, (const uint32_t *)nullptr);
 }
 
 // the match of a chained iteration: transform taken from the loop state on the device
 void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                             const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
-                            int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work)
+                            int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
+                            const uint32_t *order)
 {
     Xf id = {};
-    hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(cdiv(Q, 4)), dim3(256), 0, s, qx, qy, qz, Q, prev_p2, G, cell_start,
-                       (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work);
+    if (Q >= GRID_NN16_MIN_Q) {
+        unsigned g16 = cdiv(Q, 16);
+        if (order) g16 = (g16 + 7u) & ~7u;
+        hipLaunchKernelGGL((k_grid_nn16<true, true>), dim3(g16), dim3(256), 0, s, qx, qy, qz, Q, prev_p2, G, cell_start,
+                           (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work, order);
+        return;
+    }
+    unsigned g = cdiv(Q, 4);
+    if (order) g = (g + 7u) & ~7u;
+    hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(g), dim3(256), 0, s, qx, qy, qz, Q, prev_p2, G, cell_start,
+                       (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work, order);
+}
+
+void launch_scatter_order(hipStream_t s, const uint32_t *ids, long n, uint32_t *cursor, uint32_t *order)
+{
+    hipLaunchKernelGGL(k_scatter_order, dim3(cdiv(n, 256)), dim3(256), 0, s, ids, n, cursor, order);
 }
 
 void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int k, const GridGeom &G,

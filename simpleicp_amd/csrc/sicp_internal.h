@@ -96,15 +96,18 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
                     double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work);
 void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                             const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
-                            int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work);
+                            int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
+                            const uint32_t *order);
+void launch_scatter_order(hipStream_t s, const uint32_t *ids, long n, uint32_t *cursor, uint32_t *order);
 void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int k, const GridGeom &G,
                      const uint32_t *cell_start, const void *rec, double rmax, int64_t idx_base, double *d2_out, int64_t *idx_out);
 
 void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec);
 void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, double *d2, int64_t *idx, double *p2);
 size_t reject_select_scratch_bytes();
-hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
-                            unsigned long long *keys, void *state, unsigned long long *small, const IcpDev *st = nullptr);
+hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, double *out3,
+                            void *state, unsigned long long *small, double *partial, unsigned *ticket, double *host_out = nullptr,
+                            double seq = 0.0, const IcpDev *st = nullptr);
 void launch_aos_to_soa(hipStream_t s, const double *aos, long n, long npad, double *x, double *y, double *z);
 void launch_found_mask(hipStream_t s, const int64_t *idx, long Q, uint8_t *out);
 void launch_pad_fill(hipStream_t s, double *x, double *y, double *z, long n, long npad);

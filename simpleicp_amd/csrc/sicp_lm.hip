@@ -15,6 +15,7 @@
 // Residuals are accumulated relative to a shift (the kept distances' mean) so that their variance comes out of the
 // same pass without cancellation: no separate statistics launches.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "sicp_internal.h"
@@ -221,16 +222,23 @@ __global__ __launch_bounds__(LB) void k_lm_eval(
     }
     __syncthreads();
     if (!S.is_last) return;
-    // fold the block partials: lane t sums entry t over the blocks, four independent chains (fixed order for a given grid)
-    if (tid < 64) {
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        unsigned b = 0;
-        for (; b + 4 <= gridDim.x; b += 4) {
-            s0 += partial[(long)b * 64 + tid]; s1 += partial[(long)(b + 1) * 64 + tid];
-            s2 += partial[(long)(b + 2) * 64 + tid]; s3 += partial[(long)(b + 3) * 64 + tid];
+    // fold the block partials (fixed order for a given grid): the block's four waves take eight partials each per step --
+    // 32 rows of 512 B in flight -- lane t sums entry t; a one-wave fold of 1024 partials cost more than the evaluation
+    {
+        const int wid = tid >> 6, lane = tid & 63;
+        double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (unsigned b0 = 0; b0 < gridDim.x; b0 += 32) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned b = b0 + (unsigned)(wid * 8 + k);
+                if (b < gridDim.x) s8[k] += partial[(long)b * 64 + lane];
+            }
         }
-        for (; b < gridDim.x; ++b) s0 += partial[(long)b * 64 + tid];
-        S.gb[tid] = (s0 + s1) + (s2 + s3);
+        S.gp[wid][0][lane] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    }
+    __syncthreads();
+    if (tid < 64) {
+        S.gb[tid] = (S.gp[0][0][tid] + S.gp[1][0][tid]) + (S.gp[2][0][tid] + S.gp[3][0][tid]);
         if (tid == 0) *ticket = 0;                          // re-arm for the next launch on this stream
         lm_advance(S, L, A, stats, shift);
     }
@@ -350,9 +358,11 @@ __global__ __launch_bounds__(LB) void k_lm_finish(
 
 int lm_eval_grid(long Q)
 {
+    // (one block per CU: the per-block ticket atomics serialise, see reject_by_select in sicp_grid.hip)
+    static const long cap = [] { const char *e = std::getenv("SICP_LM_GRID"); const long v = e ? std::atol(e) : 0; return v > 0 && v <= NE_MAX_GRID ? v : 256L; }();
     long g = (Q + LB - 1) / LB;
     if (g < 1) g = 1;
-    if (g > NE_MAX_GRID) g = NE_MAX_GRID;
+    if (g > cap) g = cap;
     return (int)g;
 }
 

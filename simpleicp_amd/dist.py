@@ -128,10 +128,29 @@ def attach(ctx, gn_shard=False, partition=None, group=None):
     if partition is not None:
         ctx.set_partition(partition)
     if os.environ.get("SICP_XCHG", "rccl") != "callback":
-        box = [ctx.comm_unique_id() if rank == 0 else None]
+        err = None
+        try:
+            box = [ctx.comm_unique_id() if rank == 0 else None]
+        except Exception as exc:  # noqa: BLE001  (librccl missing on rank 0: everybody must learn of it)
+            box, err = [None], exc
         td.broadcast_object_list(box, src=td.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ctx.comm_init(box[0], rank, world, gn_shard=gn_shard)
-        return "rccl"
+        if box[0] is None:
+            err = err or RuntimeError("rank 0 could not create an RCCL id")
+        else:
+            try:
+                ctx.comm_init(box[0], rank, world, gn_shard=gn_shard)
+            except Exception as exc:  # noqa: BLE001
+                err = exc
+        # all ranks take the same road: one failed communicator sends the whole job to the callback exchange
+        verdicts = [None] * world
+        td.all_gather_object(verdicts, None if err is None else f"rank {rank}: {err}", group=group)
+        failed = [v for v in verdicts if v is not None]
+        if not failed:
+            return "rccl"
+        ctx.comm_destroy()
+        if rank == 0:
+            print("simpleicp_amd: library-owned RCCL communicator unavailable (" + "; ".join(failed)
+                  + "); using the torch.distributed callback exchange", file=sys.stderr, flush=True)
     ctx.set_exchange(make_exchange(ctx, group), rank, world, gn_shard=gn_shard)
     return "callback"
 
