@@ -263,7 +263,7 @@ def run(args):
     match_kernel = ctx.last_match_kernel()
     # ... and one more with the grid search tallying the candidates / rows it touches (the bytes its roofline is priced on)
     work = None
-    if match_kernel == "k_grid_nn":
+    if match_kernel in ("k_grid_nn", "k_grid_nn16"):
         ctx.timing_enable(True, count_work=True)
         ctx.timing_reset()
         cold()
@@ -291,7 +291,7 @@ def run(args):
     fused = nq <= 2048
     evals_per_it = ne_evals / args.steps
     bytes_bruteforce = n_local * 24 + nq * (24 + 16)        # read the searched cloud once + queries + (idx, d2)
-    bytes_solve = int(last.n_kept) * 72 * (evals_per_it if fused else 1.0) + (nq * 8 * 3 if fused else 0)
+    bytes_solve = int(last.n_kept) * 72 * evals_per_it + (nq * 8 * 3 if fused else 0)
     pmc, pmc_src = {}, None
     pmc_file = ROOT / "profiles" / "latest_pmc.json"
     if pmc_file.exists():
@@ -307,7 +307,7 @@ def run(args):
             d.update(extra)
         return d
 
-    if match_kernel == "k_grid_nn":
+    if match_kernel in ("k_grid_nn", "k_grid_nn16"):
         # the pruned search's OWN bytes: every candidate it evaluates is one packed 32-B record (x, y, z, index),
         # every non-empty grid row two 4-B offsets, every query its coordinates, the previous match (bound) and the
         # 48-B result -- tallied by the kernel itself in a separate pass
@@ -316,23 +316,26 @@ def run(args):
             bytes_match = per["candidates"] * 32 + per["rows"] * 8 + nq * (24 + 24 + 48)
             extra = {"candidates_per_query": per["candidates"] / nq, "grid_rows_per_query": per["rows"] / nq}
         else:
-            bytes_match = pmc.get("k_grid_nn") or bytes_bruteforce
+            bytes_match = pmc.get(match_kernel) or bytes_bruteforce
             extra = {"bytes_alg_source": "PMC traffic (no in-kernel work counters in this build)"}
         extra["pruning_ratio"] = bytes_bruteforce / max(1.0, bytes_match)
         extra["bytes_bruteforce_per_launch"] = int(bytes_bruteforce)
         r_match = roof(match_kernel, match_ms, bytes_match,
-                       "exact 1-NN on a static uniform grid, one wave per query: reads only the cells inside the bound ball "
-                       "(pruning_ratio = brute-force algorithmic bytes / these); ~4 dependent memory round trips per "
-                       "query, i.e. latency-bound, not bandwidth-bound", extra)
+                       ("exact 1-NN on a static uniform grid, one wave per query: reads only the cells the bound ball touches "
+                        "(pruning_ratio = brute-force algorithmic bytes / these); ~4 dependent memory round trips per "
+                        "query, i.e. latency-bound, not bandwidth-bound") if match_kernel == "k_grid_nn" else
+                       ("exact 1-NN on a static uniform grid, four cell-ordered queries per wave: reads only the cells the bound "
+                        "ball touches (pruning_ratio = brute-force algorithmic bytes / these); VALU-issue- and latency-bound"), extra)
     else:
         r_match = roof(match_kernel, match_ms, bytes_bruteforce,
                        "brute-force Q x N scan: VALU-bound by construction (SURVEY 8d), cloud read once")
-    tail_kernel = "k_icp_tail" if fused else "k_normal_eq"
+    tail_kernel = "k_icp_tail" if fused else "k_lm_eval"
     r_solve = roof(tail_kernel, solve_ms, bytes_solve,
                    "everything after the match in ONE single-workgroup launch (distances, MAD rejection, LM with "
                    "device-side 6x6 solves): ~1000 correspondences = latency-bound on one CU by design, not bandwidth"
-                   if fused else "fused residual + 6x6 normal-equation reduction, 72 B/correspondence/evaluation")
-    solve_total = solve_ms * (1 if fused else evals_per_it)
+                   if fused else "the iteration's solver launches together (enqueued evaluations + finish): residual + Jacobian rows + 8x8 "
+                   "Gram on the FP64 matrix pipe, 72 B/correspondence/evaluation; the last block of an evaluation advances the solver")
+    solve_total = solve_ms
     dominant = r_solve if solve_total >= match_ms else r_match
 
     out = {

@@ -22,7 +22,7 @@ XCHG_ALLGATHER_F64, XCHG_SUM_F64 = 1, 2
 PART_CLOUD, PART_QUERIES = 0, 1
 K_KNN1, K_KNNK, K_NORMALEQ, K_SELECT = 0, 1, 2, 3
 KERNEL_NAMES = {K_KNN1: "match", K_KNNK: "knnk_scan", K_NORMALEQ: "solve", K_SELECT: "reject_select"}
-MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1_frec", 4: "k_knn1_fmfma"}
+MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1_frec", 4: "k_knn1_fmfma", 5: "k_grid_nn16"}
 
 EXPORTS = [
     "sicp_abi_version", "sicp_last_error", "sicp_device_count", "sicp_ctx_create", "sicp_ctx_destroy",

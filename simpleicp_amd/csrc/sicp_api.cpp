@@ -247,7 +247,8 @@ struct sicp_ctx {
     DevBuf<uint32_t> q_order;      // large query sets: the queries [q_order_lo, +q_order_cnt) in cell order (search locality)
     long q_order_lo = -1, q_order_cnt = 0;
     long order_min_q = 32768;      // SICP_ORDER_MIN_Q: from this many queries per launch on (0: never)
-    int last_match_kernel = 0;     // 0 exact scan, 1 filtered scan (inline), 2 grid, 3 filtered scan (record + fix-up)
+    long nn16_min_q = 32768;       // SICP_NN16_MIN_Q: from this many queries per launch on the grid search runs four queries per wave
+    int last_match_kernel = 0;     // 0 exact scan, 1 filtered scan (inline), 2 grid, 3 filtered scan (record + fix-up), 4 matrix-pipe filter, 5 grid, four queries per wave
     // ICP state (selected fixed points and per-iteration products)
     int64_t Q = 0, qpad = 0;
     DevBuf<double> q;              // qx|qy|qz [qpad]
@@ -699,12 +700,12 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
     if (rigid && (c->knn1_mode == 3 || (c->knn1_mode == 0 && big))) {
         CHK(grid_build(c, slot));
         Grid &gr = cl.grid;
-        c->last_match_kernel = 2;
+        c->last_match_kernel = Q >= c->nn16_min_q ? 5 : 2;
         {
             Timed t(c, SICP_K_KNN1);
             launch_grid_nn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, prev_p2, gr.g, gr.cell_start.p, gr.rec.p, H,
                            H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out, p2_out,
-                           c->count_work ? c->match_work.p : nullptr);
+                           c->count_work ? c->match_work.p : nullptr, Q >= c->nn16_min_q);
         }
         HIPCHK(hipGetLastError());
         return SICP_OK;
@@ -940,6 +941,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
     if (const char *e = std::getenv("SICP_LM_EVALS")) { const int d = std::atoi(e); if (d >= 0 && d <= 32) c->lm_evals = d; }
     if (const char *e = std::getenv("SICP_ORDER_MIN_Q")) c->order_min_q = std::atol(e);
+    if (const char *e = std::getenv("SICP_NN16_MIN_Q")) c->nn16_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
     if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : !std::strcmp(e, "mfma") ? 2 : 0;
     if (const char *e = std::getenv("SICP_FSCAN_CAP")) c->fscan_cap = std::atol(e);
@@ -1348,7 +1350,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 // their place in the full arrays)
                 long lo = 0, cnt = Q;
                 if (qshard) cnt = query_slice(c, Q, &lo);
-                c->last_match_kernel = 2;
+                c->last_match_kernel = cnt >= c->nn16_min_q ? 5 : 2;
                 const bool ordered = c->order_min_q > 0 && cnt >= c->order_min_q;
                 if (ordered) CHK(query_order_build(c, lo, cnt, cl.grid.g.h));
                 Timed t(c, SICP_K_KNN1);
@@ -1356,7 +1358,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                     launch_grid_nn_chained(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt,
                                            prev ? prev + 3 * lo : nullptr, cl.grid.g, cl.grid.cell_start.p, cl.grid.rec.p,
                                            c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo, c->m_p2.p + 3 * lo,
-                                           c->count_work ? c->match_work.p : nullptr, ordered ? c->q_order.p : nullptr);
+                                           c->count_work ? c->match_work.p : nullptr, ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q);
             } else if (qshard) {
                 return fail(SICP_ERR_INVALID, "query shards need the grid search (SICP_KNN1 forces another kernel)");
             } else {

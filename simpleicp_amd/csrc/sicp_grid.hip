@@ -28,8 +28,6 @@
 namespace sicp {
 
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
-// from this many queries per launch on the search runs four queries per wave (k_grid_nn16); SICP_NN16_MIN_Q overrides (A/B runs)
-static const long GRID_NN16_MIN_Q = [] { const char *e = std::getenv("SICP_NN16_MIN_Q"); return e ? std::atol(e) : 32768L; }();
 
 __device__ __forceinline__ unsigned long long okey(double v)
 {
@@ -340,17 +338,93 @@ __global__ __launch_bounds__(256) void k_grid_nn(
         best = __builtin_inf(); bidx = 0xffffffffu;
         const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
         const long nrows = (long)ny * nz;
+        // candidates of up to four rows: ranges are wave-uniform, lane l takes record l (+ 64, ...) of each row
+        auto scan_rows = [&](const uint32_t (&rbv)[4], const uint32_t (&rlv)[4]) {
+            uint32_t longest = rlv[0] > rlv[1] ? rlv[0] : rlv[1];
+            { const uint32_t t2 = rlv[2] > rlv[3] ? rlv[2] : rlv[3]; longest = longest > t2 ? longest : t2; }
+            for (uint32_t o = 0; o < longest; o += 64) {              // (rows longer than a wave: dense cells, duplicates)
+                double4 P[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ok[u] = o + (uint32_t)lane < rlv[u];
+                    P[u] = rec[ok[u] ? rbv[u] + o + (uint32_t)lane : 0u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!ok[u]) continue;
+                    double X = P[u].x, Y = P[u].y, Z = P[u].z;
+                    if (XFORM) { double a2, b2, c2; xf(H, X, Y, Z, a2, b2, c2); X = a2; Y = b2; Z = c2; }
+                    const double dx = X - ax, dy = Y - ay, dz = Z - az;
+                    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                    const uint32_t oi = (uint32_t)__double_as_longlong(P[u].w);
+                    if (d2 < best || (d2 == best && oi < bidx)) { best = d2; bidx = oi; bx = P[u].x; by = P[u].y; bz = P[u].z; }
+                }
+                if (work) { for (int u = 0; u < 4; ++u) n_cand += ok[u] ? 1 : 0; }
+            }
+        };
+        // The ball, not its bounding cube: a row (cy, cz) is needed only if its (y, z) rectangle comes within r of the query,
+        // and then only the cells within sqrt(r^2 - lb^2) of it along x.  (`all`: the cube covers the whole grid and the pass
+        // ends the search whatever it finds -- then every row is taken in full.)
+        const double r2 = r * r, etol = 1e-6 * G.h;
+        double cull2 = __builtin_inf();                           // rows farther than this cannot hold the answer (set by hits)
         for (long rb = 0; rb < nrows; rb += 64) {
             uint32_t b = 0, len = 0;
+            double lb2 = __builtin_inf();
             if (rb + lane < nrows) {
                 const long rr = rb + lane;
                 const int cy = lo[1] + (int)(rr % ny), cz = lo[2] + (int)(rr / ny);
                 const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
-                b = cell_start[row + lo[0]];
-                len = cell_start[row + hi[0] + 1] - b;
+                int xl = lo[0], xh = hi[0];
+                lb2 = 0.0;
+                if (!all) {
+                    const double yl = G.mn[1] + (double)cy * G.h, zl = G.mn[2] + (double)cz * G.h;
+                    const double dy = fmax(fmax(yl - etol - cyq, cyq - (yl + G.h + etol)), 0.0);
+                    const double dz = fmax(fmax(zl - etol - czq, czq - (zl + G.h + etol)), 0.0);
+                    lb2 = fma(dy, dy, dz * dz);
+                    const double rem = r2 - lb2;
+                    if (rem >= 0.0) {
+                        // half-width along x, rounded up (float sqrt + margin; the cell tolerance covers the rest)
+                        const double hw = (rem < 1e-30 ? 1e-15 : (double)(sqrtf((float)rem) * 1.000001f)) + etol;
+                        const double fl = floor((cxq - hw - G.mn[0]) * G.inv_h - 1e-6);
+                        const double fh = floor((cxq + hw - G.mn[0]) * G.inv_h + 1e-6);
+                        const int tl = fl < 0.0 ? 0 : (fl > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fl);
+                        const int th = fh < 0.0 ? 0 : (fh > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fh);
+                        xl = tl > xl ? tl : xl; xh = th < xh ? th : xh;
+                    } else {
+                        xh = xl - 1;                                  // outside the ball
+                    }
+                }
+                if (xh >= xl && lb2 <= cull2) {
+                    b = cell_start[row + xl];
+                    len = cell_start[row + xh + 1] - b;
+                }
             }
             unsigned long long todo = __ballot(len > 0);          // rows of this batch that hold points
             if (work && len > 0) n_rows += 1;                     // (per-lane tallies, summed once at the end)
+            if (__popcll((long long)todo) > 4) {
+                // many rows (a wide ball: cold start, far query): nearest row first, then drop the rows its hit rules out
+                unsigned long long key = len > 0 ? (unsigned long long)__double_as_longlong(lb2) : ~0ull, mk = key;
+                { unsigned long long o;
+                  o = lane_xor64<32>(mk); mk = o < mk ? o : mk;  o = lane_xor64<16>(mk); mk = o < mk ? o : mk;
+                  o = lane_xor64<8>(mk);  mk = o < mk ? o : mk;  o = lane_xor64<4>(mk);  mk = o < mk ? o : mk;
+                  o = lane_xor64<2>(mk);  mk = o < mk ? o : mk;  o = lane_xor64<1>(mk);  mk = o < mk ? o : mk; }
+                const int j = __ffsll((long long)__ballot(len > 0 && key == mk)) - 1;
+                const uint32_t rbv[4] = {(uint32_t)__builtin_amdgcn_readlane((int)b, j), 0u, 0u, 0u};
+                const uint32_t rlv[4] = {(uint32_t)__builtin_amdgcn_readlane((int)len, j), 0u, 0u, 0u};
+                todo &= ~(1ull << j);
+                scan_rows(rbv, rlv);
+                double wb = best;
+                { double o;
+                  o = lane_xor_f64<32>(wb); wb = o < wb ? o : wb;  o = lane_xor_f64<16>(wb); wb = o < wb ? o : wb;
+                  o = lane_xor_f64<8>(wb);  wb = o < wb ? o : wb;  o = lane_xor_f64<4>(wb);  wb = o < wb ? o : wb;
+                  o = lane_xor_f64<2>(wb);  wb = o < wb ? o : wb;  o = lane_xor_f64<1>(wb);  wb = o < wb ? o : wb; }
+                if (wb < __builtin_inf()) {
+                    const double rbnd = sqrt(wb) * (1.0 + 1e-12) + slack;
+                    cull2 = rbnd * rbnd;
+                    todo &= __ballot(lb2 <= cull2);
+                }
+            }
             while (todo) {
                 // up to four rows per step: ranges by register broadcast, one record per lane and row
                 uint32_t rbv[4], rlv[4];
@@ -364,28 +438,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
                         rlv[u] = (uint32_t)__builtin_amdgcn_readlane((int)len, j);
                     }
                 }
-                uint32_t longest = rlv[0] > rlv[1] ? rlv[0] : rlv[1];
-                { const uint32_t t2 = rlv[2] > rlv[3] ? rlv[2] : rlv[3]; longest = longest > t2 ? longest : t2; }
-                for (uint32_t o = 0; o < longest; o += 64) {              // (rows longer than a wave: dense cells, duplicates)
-                    double4 P[4];
-                    bool ok[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        ok[u] = o + (uint32_t)lane < rlv[u];
-                        P[u] = rec[ok[u] ? rbv[u] + o + (uint32_t)lane : 0u];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (!ok[u]) continue;
-                        double X = P[u].x, Y = P[u].y, Z = P[u].z;
-                        if (XFORM) { double a2, b2, c2; xf(H, X, Y, Z, a2, b2, c2); X = a2; Y = b2; Z = c2; }
-                        const double dx = X - ax, dy = Y - ay, dz = Z - az;
-                        const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
-                        const uint32_t oi = (uint32_t)__double_as_longlong(P[u].w);
-                        if (d2 < best || (d2 == best && oi < bidx)) { best = d2; bidx = oi; bx = P[u].x; by = P[u].y; bz = P[u].z; }
-                    }
-                    if (work) { for (int u = 0; u < 4; ++u) n_cand += ok[u] ? 1 : 0; }
-                }
+                scan_rows(rbv, rlv);
             }
         }
         // wave-wide lexicographic (d2, original index) minimum: DPP butterfly, every lane ends up with it;
@@ -499,17 +552,90 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
         uint32_t bidx = 0xffffffffu, bpos = 0;         // (record position: the group's winner re-reads its coordinates at the end)
         const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
         const long nrows = done ? 0 : (long)ny * nz;
+        // candidates of up to two rows per group: lane gl of a group takes record gl (+ 16, ...) of each of its rows
+        auto scan_rows = [&](const uint32_t (&rbv)[2], const uint32_t (&rlv)[2]) {
+            const uint32_t longest = rlv[0] > rlv[1] ? rlv[0] : rlv[1];
+            for (uint32_t o = 0; __any(o < longest); o += 16) {
+                double4 P[2];
+                bool ok[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    ok[u] = o + (uint32_t)gl < rlv[u];
+                    P[u] = rec[ok[u] ? rbv[u] + o + (uint32_t)gl : 0u];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (!ok[u]) continue;
+                    double X = P[u].x, Y = P[u].y, Z = P[u].z;
+                    if (XFORM) { double a2, b2, c2; xf(H, X, Y, Z, a2, b2, c2); X = a2; Y = b2; Z = c2; }
+                    const double dx = X - ax, dy = Y - ay, dz = Z - az;
+                    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                    const uint32_t oi = (uint32_t)__double_as_longlong(P[u].w);
+                    if (d2 < best || (d2 == best && oi < bidx)) { best = d2; bidx = oi; bpos = rbv[u] + o + (uint32_t)gl; }
+                }
+                if (work) { for (int u = 0; u < 2; ++u) n_cand += ok[u] ? 1 : 0; }
+            }
+        };
+        // the ball, not its bounding cube (see k_grid_nn)
+        const double r2 = r * r, etol = 1e-6 * G.h;
+        double cull2 = __builtin_inf();
         for (long rb = 0; __any(rb < nrows); rb += 16) {
             uint32_t b = 0, len = 0;
+            double lb2 = __builtin_inf();
             if (rb + gl < nrows) {
                 const long rr = rb + gl;
                 const int cy = lo[1] + (int)(rr % ny), cz = lo[2] + (int)(rr / ny);
                 const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
-                b = cell_start[row + lo[0]];
-                len = cell_start[row + hi[0] + 1] - b;
+                int xl = lo[0], xh = hi[0];
+                lb2 = 0.0;
+                if (!all) {
+                    const double yl = G.mn[1] + (double)cy * G.h, zl = G.mn[2] + (double)cz * G.h;
+                    const double dy = fmax(fmax(yl - etol - cyq, cyq - (yl + G.h + etol)), 0.0);
+                    const double dz = fmax(fmax(zl - etol - czq, czq - (zl + G.h + etol)), 0.0);
+                    lb2 = fma(dy, dy, dz * dz);
+                    const double rem = r2 - lb2;
+                    if (rem >= 0.0) {
+                        const double hw = (rem < 1e-30 ? 1e-15 : (double)(sqrtf((float)rem) * 1.000001f)) + etol;
+                        const double fl = floor((cxq - hw - G.mn[0]) * G.inv_h - 1e-6);
+                        const double fh = floor((cxq + hw - G.mn[0]) * G.inv_h + 1e-6);
+                        const int tl = fl < 0.0 ? 0 : (fl > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fl);
+                        const int th = fh < 0.0 ? 0 : (fh > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fh);
+                        xl = tl > xl ? tl : xl; xh = th < xh ? th : xh;
+                    } else {
+                        xh = xl - 1;
+                    }
+                }
+                if (xh >= xl && lb2 <= cull2) {
+                    b = cell_start[row + xl];
+                    len = cell_start[row + xh + 1] - b;
+                }
             }
             unsigned todo = (unsigned)(__ballot(len > 0) >> gbase) & 0xffffu;      // this group's rows that hold points
             if (work && len > 0) n_rows += 1;
+            const bool many = __popc(todo) > 4;
+            if (__any(many)) {
+                // groups with many rows: nearest row first, then drop the rows its hit rules out
+                unsigned long long key = len > 0 ? (unsigned long long)__double_as_longlong(lb2) : ~0ull, mk = key;
+                { unsigned long long o;
+                  o = lane_xor64<8>(mk);  mk = o < mk ? o : mk;  o = lane_xor64<4>(mk);  mk = o < mk ? o : mk;
+                  o = lane_xor64<2>(mk);  mk = o < mk ? o : mk;  o = lane_xor64<1>(mk);  mk = o < mk ? o : mk; }
+                const unsigned geq = (unsigned)(__ballot(len > 0 && key == mk) >> gbase) & 0xffffu;
+                const int j = (many && geq) ? __ffs((int)geq) - 1 : 0;
+                const uint32_t vb = (uint32_t)__shfl((int)b, gbase + j), vl = (uint32_t)__shfl((int)len, gbase + j);
+                const uint32_t rbv[2] = {many ? vb : 0u, 0u};
+                const uint32_t rlv[2] = {many ? vl : 0u, 0u};
+                if (many) todo &= ~(1u << j);
+                scan_rows(rbv, rlv);
+                double gb = best;
+                { double o;
+                  o = lane_xor_f64<8>(gb);  gb = o < gb ? o : gb;  o = lane_xor_f64<4>(gb);  gb = o < gb ? o : gb;
+                  o = lane_xor_f64<2>(gb);  gb = o < gb ? o : gb;  o = lane_xor_f64<1>(gb);  gb = o < gb ? o : gb; }
+                if (many && gb < __builtin_inf()) {
+                    const double rbnd = sqrt(gb) * (1.0 + 1e-12) + slack;
+                    cull2 = rbnd * rbnd;
+                }
+                todo &= (unsigned)(__ballot(lb2 <= cull2) >> gbase) & 0xffffu;
+            }
             while (__any(todo != 0u)) {
                 uint32_t rbv[2], rlv[2];
 #pragma unroll
@@ -520,27 +646,7 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
                     const uint32_t vb = (uint32_t)__shfl((int)b, gbase + j), vl = (uint32_t)__shfl((int)len, gbase + j);
                     rbv[u] = has ? vb : 0u; rlv[u] = has ? vl : 0u;
                 }
-                const uint32_t longest = rlv[0] > rlv[1] ? rlv[0] : rlv[1];
-                for (uint32_t o = 0; __any(o < longest); o += 16) {
-                    double4 P[2];
-                    bool ok[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        ok[u] = o + (uint32_t)gl < rlv[u];
-                        P[u] = rec[ok[u] ? rbv[u] + o + (uint32_t)gl : 0u];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        if (!ok[u]) continue;
-                        double X = P[u].x, Y = P[u].y, Z = P[u].z;
-                        if (XFORM) { double a2, b2, c2; xf(H, X, Y, Z, a2, b2, c2); X = a2; Y = b2; Z = c2; }
-                        const double dx = X - ax, dy = Y - ay, dz = Z - az;
-                        const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
-                        const uint32_t oi = (uint32_t)__double_as_longlong(P[u].w);
-                        if (d2 < best || (d2 == best && oi < bidx)) { best = d2; bidx = oi; bpos = rbv[u] + o + (uint32_t)gl; }
-                    }
-                    if (work) { for (int u = 0; u < 2; ++u) n_cand += ok[u] ? 1 : 0; }
-                }
+                scan_rows(rbv, rlv);
             }
         }
         // lexicographic (d2, original index) minimum over the group's 16 lanes (one DPP row)
@@ -1041,11 +1147,12 @@ void launch_scatter(hipStream_t s, const double *x, const double *y, const doubl
 
 void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                     const GridGeom &G, const uint32_t *cell_start, const void *rec, const Xf *H, const Xf *Hinv, double rmax,
-                    double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work)
+                    double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
+                    bool four_per_wave)
 {
     const dim3 grid(cdiv(Q, 4)), block(256);
     Xf id = {};
-    if (Q >= GRID_NN16_MIN_Q) {
+    if (four_per_wave) {
         const dim3 g16(cdiv(Q, 16));
         if (H)
             hipLaunchKernelGGL((k_grid_nn16<true, false>), g16, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec,
@@ -1069,10 +1176,10 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
 void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                             const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
                             int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
-                            const uint32_t *order)
+                            const uint32_t *order, bool four_per_wave)
 {
     Xf id = {};
-    if (Q >= GRID_NN16_MIN_Q) {
+    if (four_per_wave) {
         unsigned g16 = cdiv(Q, 16);
         if (order) g16 = (g16 + 7u) & ~7u;
         hipLaunchKernelGGL((k_grid_nn16<true, true>), dim3(g16), dim3(256), 0, s, qx, qy, qz, Q, prev_p2, G, cell_start,

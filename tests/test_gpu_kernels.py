@@ -265,16 +265,22 @@ def test_too_few_correspondences(ctx):
 
 
 # ---- filtered scan (FP32 conservative filter + exact FP64 verification) == plain brute force ----
-@pytest.fixture(scope="module", params=["filter", "grid"])
+@pytest.fixture(scope="module", params=["filter", "grid", "grid16"])
 def ctx_filter(request):
-    """Contexts that FORCE the filtered brute-force scan / the grid search even for small clouds."""
+    """Contexts that FORCE the filtered brute-force scan / the grid search (one query per wave, or four: the flavour large
+    query sets get) even for small clouds."""
     import os
     from simpleicp_amd import _lib
-    os.environ["SICP_KNN1"] = request.param
+    env = {"SICP_KNN1": "grid" if request.param == "grid16" else request.param}
+    if request.param == "grid16":
+        env["SICP_NN16_MIN_Q"] = "1"
+        env["SICP_ORDER_MIN_Q"] = "1"        # ... and the iteration's queries in cell order, one eighth per XCD
+    os.environ.update(env)
     try:
         c = _lib.Context(0)
     finally:
-        del os.environ["SICP_KNN1"]
+        for k in env:
+            del os.environ[k]
     c.mode = request.param
     yield c
     c.close()
