@@ -27,11 +27,13 @@ namespace sicp {
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int LB = 256;                     // lanes per block, one correspondence per lane and chunk
+constexpr int LB = 512;                     // lanes per block, one correspondence per lane and chunk
+constexpr int LCH = 2;                      // chunks staged per round
+constexpr int LW = LB / 64;                 // waves per block
 
 struct LmShared {
-    double ja[LB][8];                       // this chunk's rows
-    double gp[4][2][64];                    // per-wave Gram blocks
+    double ja[LCH * LB][8];                 // this round's rows
+    double gp[LW][2][64];                   // per-wave Gram blocks
     double gb[64];                          // this block's Gram (shifted residual column)
     double G[2][64];                        // last block / finish: accepted and trial Gram, unshifted
     double sc[16];                          // broadcast scalars
@@ -51,40 +53,56 @@ __device__ void block_gram(LmShared &S, const double *__restrict__ qx, const dou
     const double s1 = sc[0], c1 = sc[1], s2 = sc[2], c2 = sc[3];
     const double w3y = -s1 * c2, w3z = c1 * c2;
     v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-    for (long ch = first; ch < nchunks; ch += step) {
-        const long i = ch * LB + tid;
-        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        double r = 0.0;
-        if (i < Q && keep[i]) {
-            const double px = p2[3 * i], py = p2[3 * i + 1], pz = p2[3 * i + 2];
-            const float fx = normals[3 * i], fy = normals[3 * i + 1], fz = normals[3 * i + 2];
-            double X, Y, Z;
-            xfm(H, px, py, pz, X, Y, Z);
-            r = pdist(X - qx[i], Y - qy[i], Z - qz[i], fx, fy, fz);
-            const double nx = fx, ny = fy, nz = fz;
-            const double ux = X - x[3], uy = Y - x[4], uz = Z - x[5];          // R p
-            const double cx = uy * nz - uz * ny, cy = uz * nx - ux * nz, cz = ux * ny - uy * nx;   // (R p) x n
-            a[0] = cx;
-            a[1] = c1 * cy + s1 * cz;
-            a[2] = s2 * cx + w3y * cy + w3z * cz;
-            a[3] = nx; a[4] = ny; a[5] = nz;
-            a[6] = r - shift;
-            a[7] = 1.0;
-        }
-        if (i < Q) resid_t[i] = r;
-        __syncthreads();                                  // the previous chunk's rows have been consumed
-        double2 *row = reinterpret_cast<double2 *>(&S.ja[tid][0]);
-        row[0] = make_double2(a[0], a[1]); row[1] = make_double2(a[2], a[3]);
-        row[2] = make_double2(a[4], a[5]); row[3] = make_double2(a[6], a[7]);
-        __syncthreads();
-        // Gram product on the FP64 matrix pipe (layout: see sicp_tail.hip::eval_ne)
-        const double *src = &S.ja[wid * 64 + 4 * ((lane >> 3) & 1) + (lane >> 4)][lane & 7];
+    // LCH chunks of LB correspondences per round: their loads are in flight together (a block is alone on its CU -- one
+    // block per CU keeps the ticket cheap -- so memory latency has to be covered inside the block), one barrier pair per round
+    for (long ch0 = first * LCH; ch0 < nchunks; ch0 += step * LCH) {
+        double a[LCH][8], r[LCH];
+        bool in[LCH];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double v = src[0], u = src[64];
-            src += 128;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(u, u, acc2, 0, 0, 0);
+        for (int c = 0; c < LCH; ++c) {
+            const long i = (ch0 + c) * LB + tid;
+            in[c] = i < Q;
+            r[c] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[c][k] = 0.0;
+            if (in[c] && keep[i]) {
+                const double px = p2[3 * i], py = p2[3 * i + 1], pz = p2[3 * i + 2];
+                const float fx = normals[3 * i], fy = normals[3 * i + 1], fz = normals[3 * i + 2];
+                double X, Y, Z;
+                xfm(H, px, py, pz, X, Y, Z);
+                r[c] = pdist(X - qx[i], Y - qy[i], Z - qz[i], fx, fy, fz);
+                const double nx = fx, ny = fy, nz = fz;
+                const double ux = X - x[3], uy = Y - x[4], uz = Z - x[5];          // R p
+                const double cx = uy * nz - uz * ny, cy = uz * nx - ux * nz, cz = ux * ny - uy * nx;   // (R p) x n
+                a[c][0] = cx;
+                a[c][1] = c1 * cy + s1 * cz;
+                a[c][2] = s2 * cx + w3y * cy + w3z * cz;
+                a[c][3] = nx; a[c][4] = ny; a[c][5] = nz;
+                a[c][6] = r[c] - shift;
+                a[c][7] = 1.0;
+            }
+        }
+        __syncthreads();                                  // the previous round's rows have been consumed
+#pragma unroll
+        for (int c = 0; c < LCH; ++c) {
+            const long i = (ch0 + c) * LB + tid;
+            if (in[c]) resid_t[i] = r[c];
+            double2 *row = reinterpret_cast<double2 *>(&S.ja[c * LB + tid][0]);
+            row[0] = make_double2(a[c][0], a[c][1]); row[1] = make_double2(a[c][2], a[c][3]);
+            row[2] = make_double2(a[c][4], a[c][5]); row[3] = make_double2(a[c][6], a[c][7]);
+        }
+        __syncthreads();
+        // Gram product on the FP64 matrix pipe (layout: see sicp_tail.hip::eval_ne); chunks beyond the end hold zero rows
+#pragma unroll
+        for (int c = 0; c < LCH; ++c) {
+            const double *src = &S.ja[c * LB + wid * 64 + 4 * ((lane >> 3) & 1) + (lane >> 4)][lane & 7];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double v = src[0], u = src[64];
+                src += 128;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(u, u, acc2, 0, 0, 0);
+            }
         }
     }
     acc += acc2;
@@ -100,7 +118,7 @@ __device__ void block_gram(LmShared &S, const double *__restrict__ qx, const dou
     if (tid < 64) {
         double g = 0.0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) g += S.gp[w][0][tid] + S.gp[w][1][tid];
+        for (int w = 0; w < LW; ++w) g += S.gp[w][0][tid] + S.gp[w][1][tid];
         S.gb[tid] = g;
     }
     __syncthreads();
@@ -222,12 +240,12 @@ __global__ __launch_bounds__(LB) void k_lm_eval(
     }
     __syncthreads();
     if (!S.is_last) return;
-    // fold the block partials (fixed order for a given grid): the block's four waves take eight partials each per step --
-    // 32 rows of 512 B in flight -- lane t sums entry t; a one-wave fold of 1024 partials cost more than the evaluation
+    // fold the block partials (fixed order for a given grid): the block's waves take eight partials each per step --
+    // 8 * LW rows of 512 B in flight -- lane t sums entry t; a one-wave fold of 1024 partials cost more than the evaluation
     {
         const int wid = tid >> 6, lane = tid & 63;
         double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (unsigned b0 = 0; b0 < gridDim.x; b0 += 32) {
+        for (unsigned b0 = 0; b0 < gridDim.x; b0 += 8 * LW) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const unsigned b = b0 + (unsigned)(wid * 8 + k);
@@ -238,7 +256,10 @@ __global__ __launch_bounds__(LB) void k_lm_eval(
     }
     __syncthreads();
     if (tid < 64) {
-        S.gb[tid] = (S.gp[0][0][tid] + S.gp[1][0][tid]) + (S.gp[2][0][tid] + S.gp[3][0][tid]);
+        double g = 0.0;
+#pragma unroll
+        for (int w = 0; w < LW; ++w) g += S.gp[w][0][tid];
+        S.gb[tid] = g;
         if (tid == 0) *ticket = 0;                          // re-arm for the next launch on this stream
         lm_advance(S, L, A, stats, shift);
     }
@@ -360,7 +381,7 @@ int lm_eval_grid(long Q)
 {
     // (one block per CU: the per-block ticket atomics serialise, see reject_by_select in sicp_grid.hip)
     static const long cap = [] { const char *e = std::getenv("SICP_LM_GRID"); const long v = e ? std::atol(e) : 0; return v > 0 && v <= NE_MAX_GRID ? v : 256L; }();
-    long g = (Q + LB - 1) / LB;
+    long g = ((Q + LB - 1) / LB + LCH - 1) / LCH;     // one round of LCH chunks per block, up to the cap
     if (g < 1) g = 1;
     if (g > cap) g = cap;
     return (int)g;
