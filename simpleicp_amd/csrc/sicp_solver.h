@@ -99,8 +99,11 @@ __device__ __forceinline__ bool lm_step(const double *G, double w, const double 
         if (observed(A.ow[i])) g += A.ow[i] * A.ow[i] * (x[i] - A.obs[i]);
         b[i] = fi ? 0.0 : -g;
     }
-    // M = L D L^T: afterwards M[i][j] (j < i) = L[i][j], M[j][j] = D[j]
+    // M = L D L^T: afterwards M[i][j] (j < i) = L[i][j], M[j][j] = D[j].  The pivots' reciprocals are formed ONCE (hardware
+    // estimate + two Newton steps: full precision, a third of the latency of the IEEE division sequence, and this chain is
+    // on every lane's critical path) and reused by the back-substitution.
     bool ok = true;
+    double inv[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = M[j][j];
@@ -108,13 +111,16 @@ __device__ __forceinline__ bool lm_step(const double *G, double w, const double 
         for (int k = 0; k < j; ++k) d -= M[j][k] * M[j][k] * M[k][k];
         ok = ok && (d > 0.0) && (d < __builtin_inf());
         M[j][j] = d;
-        const double inv = 1.0 / d;
+        double y = __builtin_amdgcn_rcp(d);
+        y = fma(fma(-d, y, 1.0), y, y);
+        y = fma(fma(-d, y, 1.0), y, y);
+        inv[j] = y;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double t = M[i][j];
 #pragma unroll
             for (int k = 0; k < j; ++k) t -= M[i][k] * M[j][k] * M[k][k];
-            M[i][j] = t * inv;
+            M[i][j] = t * y;
         }
     }
 #pragma unroll
@@ -124,7 +130,7 @@ __device__ __forceinline__ bool lm_step(const double *G, double w, const double 
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
-        double t = b[i] / M[i][i];
+        double t = b[i] * inv[i];
 #pragma unroll
         for (int k = i + 1; k < 6; ++k) t -= M[k][i] * dx[k];
         dx[i] = t;
