@@ -146,3 +146,67 @@ def test_allgather_exchange_world2(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_worker_allgather, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert all((tmp_path / f"ag{r}").exists() for r in range(2))
+
+
+class _FakeCtx:
+    """Stands in for _lib.Context in dist.attach: records what attach did; `fail_on` makes that rank's communicator fail."""
+
+    def __init__(self, rank, fail_on):
+        self.rank, self.fail_on, self.calls = rank, fail_on, []
+
+    def set_partition(self, mode):
+        self.calls.append(("partition", mode))
+
+    def comm_unique_id(self):
+        if self.fail_on == "id":
+            raise RuntimeError("librccl could not be loaded")
+        return b"\x01" * 128
+
+    def comm_init(self, uid, rank, world, gn_shard=False):
+        assert uid == b"\x01" * 128
+        if self.fail_on == rank:
+            raise RuntimeError("ncclCommInitRank failed")
+        self.calls.append(("comm_init", rank, world))
+
+    def comm_destroy(self):
+        self.calls.append(("comm_destroy",))
+
+    def set_exchange(self, fn, rank, world, gn_shard=False):
+        self.calls.append(("callback", rank, world))
+
+
+def _worker_attach(rank, world, port, tmp):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("SICP_XCHG", None)
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simpleicp_amd import dist
+        dist.make_exchange = lambda ctx, group=None: (lambda *a: 0)          # (the real one wraps device pointers)
+        # every rank's communicator comes up -> the library-owned RCCL path on every rank
+        c = _FakeCtx(rank, fail_on=None)
+        assert dist.attach(c, partition=1) == "rccl" and ("comm_init", rank, world) in c.calls and ("callback", rank, world) not in c.calls
+        # ONE rank fails -> ALL ranks drop their communicator and register the callback exchange
+        c = _FakeCtx(rank, fail_on=1)
+        assert dist.attach(c) == "callback" and ("comm_destroy",) in c.calls and c.calls[-1] == ("callback", rank, world)
+        # rank 0 cannot even create an id (librccl missing)
+        c = _FakeCtx(rank, fail_on="id" if rank == 0 else None)
+        assert dist.attach(c) == "callback" and c.calls[-1] == ("callback", rank, world)
+        os.environ["SICP_XCHG"] = "callback"
+        c = _FakeCtx(rank, fail_on=None)
+        assert dist.attach(c) == "callback" and not any(x[0] == "comm_init" for x in c.calls)
+        Path(tmp, f"at{rank}").write_text("ok")
+    finally:
+        os.environ.pop("SICP_XCHG", None)
+        td.destroy_process_group()
+
+
+def test_attach_falls_back_to_the_callback_on_every_rank_together(tmp_path):
+    """dist.attach: the library's own RCCL communicator by default; if it fails on ANY rank (or rank 0 cannot load
+    librccl) every rank agrees to use the torch.distributed callback exchange -- no rank is left waiting in a collective
+    the others never enter."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_attach, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"at{r}").exists() for r in range(2))

@@ -434,13 +434,14 @@ def test_filtered_scan_variants_and_overflow_fallback(variant, cap):
     c.close()
 
 
-@pytest.mark.parametrize("Q", [1, 6, 63, 512, 513, 1024, 1025, 1500, 2048, 2049, 5000, 10_000, 16_384, 16_385])
+@pytest.mark.parametrize("Q", [1, 6, 63, 512, 513, 1024, 1025, 1500, 2048, 2049, 5000, 10_000, 16_384, 16_385, 40_000])
 @pytest.mark.parametrize("quantised", [False, True])
 def test_iteration_q_sweep_every_tail_path(ctx, Q, quantised):
     """Every instantiation of the iteration's tail against the oracle with bit-level assertions: the fused
     single-launch tail with 1 / 2 / 4 correspondences per lane (Q <= 512 / 1024 / 2048), the single-workgroup
-    LDS radix selection (2048 < Q <= 16384) and the multi-workgroup selection above, including both hand-over
-    points and even / odd survivor counts; a quantised cloud supplies duplicate distances.  Also
+    LDS selection (2048 < Q <= 16384) and the multi-workgroup digit selection above (40 000: with the four-queries-per-wave
+    search over cell-ordered queries that large sets get by default), including both hand-over points and even / odd
+    survivor counts; a quantised cloud supplies duplicate distances.  Also
     sicp_icp_uncertainties on each path (optimization.py:126-170)."""
     from simpleicp_amd import _lib
     rng = np.random.default_rng(Q)
