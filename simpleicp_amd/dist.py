@@ -127,7 +127,7 @@ def attach(ctx, gn_shard=False, partition=None, group=None):
     rank, world = td.get_rank(group), td.get_world_size(group)
     if partition is not None:
         ctx.set_partition(partition)
-    if os.environ.get("SICP_XCHG", "rccl") != "callback":
+    if os.environ.get("SICP_XCHG", "rccl") != "callback" and td.get_backend(group) != "gloo":
         err = None
         try:
             box = [ctx.comm_unique_id() if rank == 0 else None]
@@ -193,7 +193,8 @@ def make_exchange(ctx, group=None, synchronous=None):
     itself; the host side only issues the collective.  By default the collective is enqueued IN
     ORDER ON THE LIBRARY'S OWN STREAM (torch.cuda.ExternalStream), so nothing blocks the host
     between the pack kernel, the all-gather and the reduce kernel; SICP_XCHG_SYNC=1 (or
-    synchronous=True) restores the blocking variant."""
+    synchronous=True) restores the blocking variant.  A gloo group (no GPU collectives; also what lets several ranks share
+    ONE GPU in tests/test_gpu_exchange.py) is served by staging through host memory."""
     import os
     import torch
     import torch.distributed as td
@@ -215,7 +216,27 @@ def make_exchange(ctx, group=None, synchronous=None):
             t = views[key] = _wrap(ptr, (count,), "<f8", dev)
         return t
 
+    host_staged = td.get_backend(group) == "gloo"      # a group without GPU collectives: stage through host memory, blocking
+
+    def fn_host(what, a, b, c, count):
+        with torch.cuda.device(dev):
+            lib_stream.synchronize()
+            send = view(a, count).cpu()
+            if what == _lib.XCHG_ALLGATHER_F64:
+                recv = torch.empty(count * world, dtype=torch.float64)
+                allgather_into(recv, send, group)
+                view(b, count * world).copy_(recv)
+            elif what == _lib.XCHG_SUM_F64:
+                allreduce_sum(send, group)
+                view(a, count).copy_(send)
+            else:
+                return 1
+            torch.cuda.synchronize(dev)
+        return 0
+
     def fn(what, a, b, c, count):
+        if host_staged:
+            return fn_host(what, a, b, c, count)
         with torch.cuda.device(dev), torch.cuda.stream(lib_stream):
             if synchronous:
                 lib_stream.synchronize()

@@ -122,9 +122,11 @@ class SimpleICP:
             pc2._upload(ctx, _lib.MOV, lo, hi, index_base=lo, rows=rows)
 
         upload_movable()
+        self._job = {"ranks": world, "partition": None, "exchange": None}
         if sharded:
-            dist.attach(ctx, gn_shard=(not qshard) and (correspondences >= 262144 or os.environ.get("SICP_GN_SHARD") == "1"),
-                        partition=_lib.PART_QUERIES if qshard else _lib.PART_CLOUD)
+            how = dist.attach(ctx, gn_shard=(not qshard) and (correspondences >= 262144 or os.environ.get("SICP_GN_SHARD") == "1"),
+                              partition=_lib.PART_QUERIES if qshard else _lib.PART_CLOUD)
+            self._job.update(partition="queries" if qshard else "cloud", exchange=how)
         else:
             dist.detach(ctx)
         try:
@@ -254,7 +256,7 @@ class SimpleICP:
         if debug_dirpath:
             pc2.write_xyz(Path(debug_dirpath).joinpath(f"iteration{it:03d}_postoptim_pcmov.xyz"))
 
-        self.last_run_info = {"iterations": it + 1, "stats": stats, "seconds": time.time() - t_start}
+        self.last_run_info = {"iterations": it + 1, "stats": stats, "seconds": time.time() - t_start, **getattr(self, "_job", {})}
         _log.info(f"Finished in {time.time() - t_start:.3f} seconds!")
         return H, X_new, rbp, residuals
 

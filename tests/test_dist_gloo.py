@@ -185,6 +185,7 @@ def _worker_attach(rank, world, port, tmp):
     try:
         from simpleicp_amd import dist
         dist.make_exchange = lambda ctx, group=None: (lambda *a: 0)          # (the real one wraps device pointers)
+        td.get_backend = lambda group=None: "nccl"                           # (a gloo group goes straight to the callback)
         # every rank's communicator comes up -> the library-owned RCCL path on every rank
         c = _FakeCtx(rank, fail_on=None)
         assert dist.attach(c, partition=1) == "rccl" and ("comm_init", rank, world) in c.calls and ("callback", rank, world) not in c.calls

@@ -88,3 +88,74 @@ def test_exchange_plumbing_with_one_rank_process_group():
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": str(ROOT), "port": port}], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "EXCHANGE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+WORKER2 = r'''
+import os, sys, numpy as np
+rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+sys.path.insert(0, "%(root)s"); sys.path.insert(0, "%(root)s/tests")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SIMPLEICP_DEVICE="0")
+import torch, torch.distributed as td
+from conftest import load_golden, load_cloud
+from simpleicp_amd import PointCloud, SimpleICP, backend
+td.init_process_group("gloo", rank=rank, world_size=world)
+def run(name="bunny", **extra):
+    g, files, kw = load_golden(name)
+    pf = PointCloud(load_cloud(files[0]), columns=["x", "y", "z"]); pm = PointCloud(load_cloud(files[1]), columns=["x", "y", "z"])
+    icp = SimpleICP(verbose=False); icp.add_point_clouds(pf, pm)
+    H, X, rbp, res = icp.run(**{**kw, **extra})
+    info = icp.last_run_info
+    assert info["ranks"] == world == 2 and info["exchange"] == "callback" and info["partition"] == os.environ.get("SICP_PARTITION", "cloud"), info
+    return H, X, res, info["iterations"]
+res = {}
+res["cloud"] = run()                                    # the movable cloud in index shards, one all-gather + lexmin per iteration
+os.environ["SICP_PARTITION"] = "queries"
+res["queries"] = run()                                  # every rank the whole cloud, its slice of the queries
+del os.environ["SICP_PARTITION"]
+os.environ["SICP_GN_SHARD"] = "1"
+res["gn"] = run()                                       # + the 6x6 reduction sharded (SUM all-reduce per solver step)
+del os.environ["SICP_GN_SHARD"]
+res["dragon_q5000"] = run("dragon_q5000")               # Q > 2048: the large-Q chain between the exchanges
+td.barrier()
+td.destroy_process_group()
+np.savez(out, **{k + "_" + n: v for k, t in res.items() for n, v in zip(("H", "X", "r", "it"), t)})
+print("RANK_OK", rank)
+'''
+
+
+def test_two_ranks_sharing_one_gpu_agree_with_one_rank(tmp_path):
+    """The multi-rank flow with REAL shards on hardware: two processes share cuda:0 (a gloo group, collectives staged through
+    host memory -- RCCL refuses two ranks on one device), each uploads its index shard of the movable cloud (or matches its
+    slice of the queries) and the per-iteration exchange merges them.  Cloud shards and query shards must reproduce the
+    single-process run bit for bit; with the sharded 6x6 reduction the sums are grouped differently (1e-9)."""
+    import socket
+    sys.path.insert(0, str(ROOT / "tests"))
+    from conftest import load_golden, load_cloud
+    from simpleicp_amd import PointCloud, SimpleICP
+
+    def run(name):
+        g, files, kw = load_golden(name)
+        pf = PointCloud(load_cloud(files[0]), columns=["x", "y", "z"]); pm = PointCloud(load_cloud(files[1]), columns=["x", "y", "z"])
+        icp = SimpleICP(verbose=False); icp.add_point_clouds(pf, pm)
+        H, X, rbp, res = icp.run(**kw)
+        return H, X, res, icp.last_run_info["iterations"]
+
+    ref = {"bunny": run("bunny"), "dragon_q5000": run("dragon_q5000")}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker2.py"
+    script.write_text(WORKER2 % {"root": str(ROOT)})
+    env = {k: v for k, v in os.environ.items() if k not in ("SICP_XCHG", "SICP_PARTITION", "SICP_GN_SHARD", "SICP_FORCE_EXCHANGE")}
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(port), str(tmp_path / f"rank{r}.npz")], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs) and all("RANK_OK" in o for o in outs), "\n".join(o[-3000:] for o in outs)
+    for r in range(2):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        for key, name in (("cloud", "bunny"), ("queries", "bunny"), ("dragon_q5000", "dragon_q5000")):
+            H, X, res, it = ref[name]
+            assert int(z[key + "_it"]) == it and np.array_equal(z[key + "_H"], H) and np.array_equal(z[key + "_X"], X) \
+                and np.array_equal(z[key + "_r"], res), (key, r, np.abs(z[key + "_H"] - H).max())
+        H, X, res, it = ref["bunny"]
+        assert int(z["gn_it"]) == it and np.abs(z["gn_H"] - H).max() < 1e-9
