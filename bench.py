@@ -171,6 +171,11 @@ def run(args):
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU path)", file=sys.stderr)
         sys.exit(2)
+    # SICP_BENCH_SHARE_GPU=1 (tests only): every rank on cuda:0, a gloo group with host-staged collectives -- the multi-rank
+    # flow of this file on a one-GPU box (RCCL refuses two ranks on one device); never a measurement
+    share_gpu = os.environ.get("SICP_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         print(f"bench.py: rank {rank} has no GPU (only {torch.cuda.device_count()} visible)", file=sys.stderr)
         sys.exit(2)
@@ -179,7 +184,10 @@ def run(args):
     if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            td.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from simpleicp_amd import _lib, dist
 
@@ -241,7 +249,7 @@ def run(args):
             td.barrier()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
             td.all_reduce(t, op=td.ReduceOp.MAX)
             el = float(t.item())
         return el, x, ne_evals, last

@@ -159,3 +159,21 @@ def test_two_ranks_sharing_one_gpu_agree_with_one_rank(tmp_path):
                 and np.array_equal(z[key + "_r"], res), (key, r, np.abs(z[key + "_H"] - H).max())
         H, X, res, it = ref["bunny"]
         assert int(z["gn_it"]) == it and np.abs(z["gn_H"] - H).max() < 1e-9
+
+
+@pytest.mark.parametrize("partition", ["cloud", "queries"])
+def test_bench_two_ranks_self_launched(partition):
+    """`python bench.py --gpus 2` from a plain interpreter: the file spawns its own ranks, shards the movable cloud (or the
+    queries), times with barrier + MAX over ranks, and rank 0 prints ONE JSON line whose parity leg (every rank in the
+    exchange, rank 0 against the oracle) is green.  SICP_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 over gloo."""
+    import json
+    env = dict(os.environ, SICP_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--repeats", "2",
+                        "--points", "300000", "--partition", partition, "--no-cpu-baseline", "--no-end-to-end",
+                        "--no-bruteforce-leg"], env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["parity"]["ok"] is True, d["parity"]
+    assert "callback" in d["config"]["parallelism"] and ("query" in d["config"]["parallelism"]) == (partition == "queries")
