@@ -1447,8 +1447,8 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
         c->resid_slot = small_q ? 0 : (int)o[REC_RESID_SLOT];
         if (c->solve_trace && small_q)
             std::fprintf(stderr, "[tail] cycles: load+dist %.0f select %.0f (median %.0f in %.0f rounds, MAD %.0f in %.0f) keep %.0f lm %.0f "
-                                 "(%lld evals, %lld steps) final %.0f\n",
-                         o[50], o[51], o[55], o[56], o[57], o[58], o[52], o[53], (long long)R.ne_evals, (long long)R.lm_steps, o[54]);
+                                 "(%lld evals %.0f, %lld steps, solves %.0f, accept %.0f) final %.0f\n",
+                         o[50], o[51], o[55], o[56], o[57], o[58], o[52], o[53], (long long)R.ne_evals, o[59], (long long)R.lm_steps, o[60], o[49], o[54]);
         if (o[REC_CONVERGED] != 0.0) over = true;
     }
     return rc;

@@ -462,9 +462,19 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
     int steps = 0, evals = 0, cur = 1, tries = 0;
     bool first = true;
     double cost = 0.0, lambda = 0.0, dxmax = 0.0;
+    // finer split of the solver loop (-DSICP_TAIL_FINE_TRACE: each reading drains the LDS queue, ~100 cycles -- off by default;
+    // measured at C4: evaluation 5.35 k cycles, acceptance 1.05 k, 6x6 solve 2.3 k, trial angles + loop 2.2 k per round)
+#ifdef SICP_TAIL_FINE_TRACE
+#define SICP_FT(x) x
+#else
+#define SICP_FT(x)
+#endif
+    long long t_eval = 0, t_step = 0, t_acc = 0;
 #pragma unroll 1
     for (;;) {
+        SICP_FT(const long long te0 = clock64();)
         eval_ne<EPT>(S, xn, scn, C, rrn, cur ^ 1); ++evals;      // (its first barrier orders it after the last one's LDS reads)
+        SICP_FT(const long long te1 = clock64(); t_eval += te1 - te0;)
         const double costn = objective(S.gf[wid][cur ^ 1], w, xn, A);
         if (first && !need_w && tid == 0) {
             // r = d at the start estimate: sum r, sum r^2, n of this evaluation ARE the kept distances' statistics
@@ -496,6 +506,7 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         // next trial from (x, lambda)
         bool ok = false;
         double dstep[6];
+        SICP_FT(const long long ts0 = clock64(); t_acc += ts0 - te1;)
 #pragma unroll 1
         for (; tries < 40; ++tries) {
             ok = lm_step(S.gf[wid][cur], w, x, lambda, A, dstep);
@@ -506,6 +517,7 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
             if (ok) break;
             lambda = lambda > 0 ? lambda * 10 : 1e-6;
         }
+        SICP_FT(t_step += clock64() - ts0;)
         if (!ok) break;
         double xm = 0.0;
 #pragma unroll
@@ -559,6 +571,7 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         S.out[REC_CONVERGED] = conv ? 1.0 : 0.0;
         tk[5] = clock64();
         for (int k = 0; k < 5; ++k) S.out[50 + k] = (double)(tk[k + 1] - tk[k]);
+        S.out[59] = (double)t_eval; S.out[60] = (double)t_step; S.out[49] = (double)t_acc;
         S.out[55] = (double)(tsel - tk[1]); S.out[56] = rounds[0]; S.out[57] = (double)(tk[2] - tsel); S.out[58] = rounds[1];
 
     }
