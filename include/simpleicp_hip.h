@@ -72,6 +72,9 @@ int sicp_cloud_size(sicp_ctx *ctx, int slot, int64_t *n_out);
 int sicp_cloud_transform(sicp_ctx *ctx, int slot, const double H[16]);
 /* PointCloud.X (pointcloud.py:81-84): (n,3) row-major copy out. */
 int sicp_cloud_download(sicp_ctx *ctx, int slot, double *xyz_out);
+/* The same as three contiguous columns -- what `self[["x", "y", "z"]] = ...` leaves in the DataFrame after
+ * transform_by_H (pointcloud.py:215-217): straight out of the column-wise device layout, no transpose on either side. */
+int sicp_cloud_download_columns(sicp_ctx *ctx, int slot, double *x_out, double *y_out, double *z_out);
 /* The `planarity` column of a cloud that has one (CorrPts.reject_wrt_planarity also tests the MOVABLE cloud's
  * planarity of every matched point when pc2 carries that column, corrpts.py:158-163; NaN fails the test).
  * Only consulted for SICP_MOV by the iteration.  The column is indexed by GLOBAL point index and has n_global

@@ -27,7 +27,7 @@ MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1
 EXPORTS = [
     "sicp_abi_version", "sicp_last_error", "sicp_device_count", "sicp_ctx_create", "sicp_ctx_destroy",
     "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_upload_columns", "sicp_cloud_size", "sicp_cloud_transform",
-    "sicp_cloud_download", "sicp_cloud_set_planarity", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
+    "sicp_cloud_download", "sicp_cloud_download_columns", "sicp_cloud_set_planarity", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
     "sicp_set_exchange", "sicp_comm_unique_id", "sicp_comm_init", "sicp_comm_destroy", "sicp_set_partition", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_last_match_kernel",
     "sicp_xyz_count", "sicp_xyz_read", "sicp_xyz_write",
@@ -88,6 +88,7 @@ def load():
     L.sicp_cloud_size.argtypes = [vp, cint, C.POINTER(i64)]
     L.sicp_cloud_transform.argtypes = [vp, cint, vp]
     L.sicp_cloud_download.argtypes = [vp, cint, vp]
+    L.sicp_cloud_download_columns.argtypes = [vp, cint, vp, vp, vp]
     L.sicp_cloud_set_planarity.argtypes = [vp, cint, vp, vp, i64, i64]
     L.sicp_knn.argtypes = [vp, cint, vp, i64, cint, vp, dbl, vp, vp]
     L.sicp_select_in_range.argtypes = [vp, cint, cint, vp, i64, vp, dbl, vp]
@@ -219,6 +220,13 @@ class Context:
         out = np.empty((self.size(slot), 3))
         self._chk(self._L.sicp_cloud_download(self._h, slot, _ptr(out)))
         return out
+
+    def download_columns(self, slot):
+        """The cloud as three contiguous float64 vectors (x, y, z)."""
+        n = self.size(slot)
+        cols = [np.empty(n) for _ in range(3)]
+        self._chk(self._L.sicp_cloud_download_columns(self._h, slot, _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2])))
+        return cols
 
     def set_planarity(self, slot, planarity=None, rows=None, n_global=None):
         """The cloud's `planarity` column (corrpts.py:158-163 tests the movable cloud's too): a dense float32 vector

@@ -1124,6 +1124,18 @@ SICP_EXPORT int sicp_cloud_download(sicp_ctx *c, int slot, double *xyz_out)
     return sync(c);
 }
 
+SICP_EXPORT int sicp_cloud_download_columns(sicp_ctx *c, int slot, double *x_out, double *y_out, double *z_out)
+{
+    CHK(check_slot(c, slot, true));
+    if (!x_out || !y_out || !z_out) return fail(SICP_ERR_INVALID, "x_out / y_out / z_out is null");
+    HIPCHK(hipSetDevice(c->device));
+    Cloud &cl = c->cloud[slot];
+    HIPCHK(hipMemcpyAsync(x_out, cl.x(), (size_t)cl.n * sizeof(double), hipMemcpyDefault, c->stream));
+    HIPCHK(hipMemcpyAsync(y_out, cl.y(), (size_t)cl.n * sizeof(double), hipMemcpyDefault, c->stream));
+    HIPCHK(hipMemcpyAsync(z_out, cl.z(), (size_t)cl.n * sizeof(double), hipMemcpyDefault, c->stream));
+    return sync(c);
+}
+
 // ------------------------------------------------------------------------------------------
 SICP_EXPORT int sicp_knn(sicp_ctx *c, int slot, const double *q_xyz, int64_t Q, int k, const double *H, double max_dist,
                          int64_t *idx_out, double *d2_out)
@@ -1448,7 +1460,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
         if (c->solve_trace && small_q)
             std::fprintf(stderr, "[tail] cycles: load+dist %.0f select %.0f (median %.0f in %.0f rounds, MAD %.0f in %.0f) keep %.0f lm %.0f "
                                  "(%lld evals %.0f, %lld steps, solves %.0f, accept %.0f) final %.0f\n",
-                         o[50], o[51], o[55], o[56], o[57], o[58], o[52], o[53], (long long)R.ne_evals, o[59], (long long)R.lm_steps, o[60], o[49], o[54]);
+                         o[50], o[51], o[55], o[56], o[57], o[58], o[52], o[53], (long long)R.ne_evals, o[59], (long long)R.lm_steps, o[60], o[62], o[54]);
         if (o[REC_CONVERGED] != 0.0) over = true;
     }
     return rc;

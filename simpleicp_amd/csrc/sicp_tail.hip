@@ -571,7 +571,7 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         S.out[REC_CONVERGED] = conv ? 1.0 : 0.0;
         tk[5] = clock64();
         for (int k = 0; k < 5; ++k) S.out[50 + k] = (double)(tk[k + 1] - tk[k]);
-        S.out[59] = (double)t_eval; S.out[60] = (double)t_step; S.out[49] = (double)t_acc;
+        S.out[59] = (double)t_eval; S.out[60] = (double)t_step; S.out[62] = (double)t_acc;
         S.out[55] = (double)(tsel - tk[1]); S.out[56] = rounds[0]; S.out[57] = (double)(tk[2] - tsel); S.out[58] = rounds[1];
 
     }

@@ -25,7 +25,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _lib, backend, dist
-from .pointcloud import PointCloud
+from .pointcloud import _ALL, PointCloud
 from .rbp import H_from_params, RigidBodyParameters
 
 _log = logging.getLogger(__name__)
@@ -144,15 +144,13 @@ class SimpleICP:
         if debug_dirpath:
             X_fix, X_mov = pc1.X, pc2.X
 
-        sel = pc1.idx_selected            # carried along: every flatnonzero over the mask is a pass over N_f
+        sel = pc1._selection()            # carried along (_ALL or indices): every pass over the mask is a pass over N_f
         if np.isfinite(max_overlap_distance):
             _log.info("Consider partial overlap of point clouds ...")
-            if len(sel):
+            if sel is _ALL or len(sel):
                 # both clouds are resident already: only the verdicts cross the host link
-                near = ctx.select_in_range(_lib.FIX, _lib.MOV, None if len(sel) == pc1.num_points else sel, H,
-                                           float(max_overlap_distance))
-                sel = sel[near]
-                pc1.idx_selected = sel
+                near = ctx.select_in_range(_lib.FIX, _lib.MOV, None if sel is _ALL else sel, H, float(max_overlap_distance))
+                sel = pc1._keep_selected(sel, near)
             if not len(sel) > 0:
                 raise SimpleICPException(
                     "Point clouds do not overlap within max_overlap_distance = "

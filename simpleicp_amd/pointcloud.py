@@ -20,6 +20,7 @@ import pandas as pd
 from . import _lib, backend
 
 _XYZ = ["x", "y", "z"]
+_ALL = object()          # selection sentinel: "every point" (no index vector materialised)
 _ATTRS = ("nx", "ny", "nz", "planarity")
 
 try:                                       # O(selected) construction of the sparse attribute columns
@@ -182,13 +183,39 @@ class PointCloud(pd.DataFrame):
     def select_n_points(self, n: int, _cur=None):
         """Equidistant sub-sampling of the current selection (np.round = half-to-even;
         duplicates collapse, so fewer than n points may remain) -- pointcloud.py:132-147.
-        (Internal callers pass the selection they already hold and get the new one back.)"""
+        (Internal callers pass the selection they already hold -- ``_ALL`` for "every point", which spares a pass over
+        the mask and an index vector of N entries -- and get the new one back.)"""
+        if _cur is _ALL:
+            if self._num_points > n:
+                cur = np.unique(np.round(np.linspace(0, self._num_points - 1, n)).astype(np.int64))
+                self.idx_selected = cur
+                return cur
+            return np.arange(self._num_points, dtype=np.int64)
         cur = self.idx_selected if _cur is None else _cur
         if len(cur) > n:
             pos = np.round(np.linspace(0, len(cur) - 1, n)).astype(int)
             cur = np.unique(cur[pos])
             self.idx_selected = cur
         return cur if _cur is not None else None
+
+    def _selection(self):
+        """``_ALL`` when every point is selected (one vectorised count over the mask), else the selected indices."""
+        mask = self["selected"].to_numpy()
+        if int(np.count_nonzero(mask)) == self._num_points:
+            return _ALL
+        return np.flatnonzero(mask)
+
+    def _keep_selected(self, cur, near):
+        """Narrows the selection ``cur`` (``_ALL`` or sorted indices) to the entries flagged in ``near`` (one 0/1 byte
+        per entry of ``cur``); writes the `selected` column and returns the new index vector."""
+        near = np.asarray(near).view(bool) if np.asarray(near).dtype.itemsize == 1 else np.asarray(near, dtype=bool)
+        if cur is _ALL:
+            idx = np.flatnonzero(near)
+            self["selected"] = near                      # the verdicts ARE the new mask
+            return idx
+        idx = cur[near]
+        self.idx_selected = idx
+        return idx
 
     def select_in_range(self, X: np.ndarray, max_range: float, _ctx=None, _slot=None) -> None:
         """Keeps selected points whose nearest neighbour in X is closer than max_range
@@ -246,8 +273,22 @@ class PointCloud(pd.DataFrame):
             self._upload(ctx, slot)
         ctx.transform(slot, np.asarray(H, dtype=np.float64))
         Xt = ctx.download(slot)
-        self["x"], self["y"], self["z"] = Xt[:, 0], Xt[:, 1], Xt[:, 2]
+        # the frame wants three contiguous columns: they come straight out of the device's column-wise layout (a second
+        # copy over the link costs a third of what three strided host copies of Xt[:, j] do) and are handed to the frame
+        # WITHOUT pandas' defensive copy of freshly made arrays nobody else holds
+        cols = ctx.download_columns(slot)
+        for name, col in zip(_XYZ, cols):
+            self._adopt_column(name, col)
         return Xt
+
+    def _adopt_column(self, name, values):
+        """``self[name] = values`` for an array this object just created: same result, no copy."""
+        try:
+            if name not in self.columns or len(values) != len(self.index) or values.dtype != np.float64:
+                raise TypeError
+            self._set_item_mgr(name, values)              # (pandas-internal: what __setitem__ calls after sanitising)
+        except Exception:                                 # noqa: BLE001  -- any other pandas: the public road
+            self[name] = values
 
     # ---- I/O (pointcloud.py:219-226) ------------------------------------------------------
     def write_xyz(self, file: Path):
