@@ -26,7 +26,7 @@ def timed(name):
     setattr(_lib.Context, name, wrap)
 
 
-for m in ("upload", "download", "transform", "knn", "select_in_range", "estimate_normals", "icp_setup", "icp_run", "icp_iterate",
+for m in ("upload", "upload_columns", "download", "download_columns", "transform", "knn", "select_in_range", "estimate_normals", "icp_setup", "icp_run", "icp_iterate",
           "icp_state", "icp_uncertainties"):
     timed(m)
 
@@ -49,4 +49,4 @@ for rep in range(2):                      # second pass = warm (context, allocat
     for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
         print(f"    ctx.{k:20s} {v * 1e3:10.2f} ms")
     print(f"    {'host (pandas/numpy)':24s} {(t_run - sum(acc.values())) * 1e3:10.2f} ms")
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)

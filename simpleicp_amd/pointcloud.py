@@ -157,6 +157,11 @@ class PointCloud(pd.DataFrame):
 
     @idx_selected.setter
     def idx_selected(self, idx_selected: List[int]) -> None:
+        self._set_idx_selected(idx_selected)
+
+    def _set_idx_selected(self, idx_selected) -> None:
+        """(Internal callers use this instead of ``self.idx_selected = ...``: pandas' __setattr__ evaluates the property's
+        GETTER first -- a flatnonzero over all N points -- before it reaches the setter.)"""
         mask = np.zeros(self._num_points, dtype=bool)
         mask[np.asarray(idx_selected, dtype=np.int64)] = True
         self["selected"] = mask
@@ -178,7 +183,7 @@ class PointCloud(pd.DataFrame):
 
     def select_by_indices(self, indices: List[int]) -> None:
         """Keeps the currently selected points whose index is in ``indices``."""
-        self.idx_selected = np.intersect1d(self.idx_selected, indices)
+        self._set_idx_selected(np.intersect1d(self.idx_selected, indices))
 
     def select_n_points(self, n: int, _cur=None):
         """Equidistant sub-sampling of the current selection (np.round = half-to-even;
@@ -188,14 +193,14 @@ class PointCloud(pd.DataFrame):
         if _cur is _ALL:
             if self._num_points > n:
                 cur = np.unique(np.round(np.linspace(0, self._num_points - 1, n)).astype(np.int64))
-                self.idx_selected = cur
+                self._set_idx_selected(cur)
                 return cur
             return np.arange(self._num_points, dtype=np.int64)
         cur = self.idx_selected if _cur is None else _cur
         if len(cur) > n:
             pos = np.round(np.linspace(0, len(cur) - 1, n)).astype(int)
             cur = np.unique(cur[pos])
-            self.idx_selected = cur
+            self._set_idx_selected(cur)
         return cur if _cur is not None else None
 
     def _selection(self):
@@ -214,7 +219,7 @@ class PointCloud(pd.DataFrame):
             self["selected"] = near                      # the verdicts ARE the new mask
             return idx
         idx = cur[near]
-        self.idx_selected = idx
+        self._set_idx_selected(idx)
         return idx
 
     def select_in_range(self, X: np.ndarray, max_range: float, _ctx=None, _slot=None) -> None:
@@ -231,7 +236,7 @@ class PointCloud(pd.DataFrame):
         self._upload(ctx, _lib.FIX)
         near = ctx.select_in_range(_lib.FIX, _lib.MOV, None if len(cur) == self._num_points else cur,
                                    max_range=float(max_range))
-        self.idx_selected = cur[near]
+        self._set_idx_selected(cur[near])
 
     # ---- attributes (pointcloud.py:173-203) ---------------------------------------------
     def estimate_normals(self, neighbors: int, _ctx=None, _uploaded=False, _sel=None) -> None:
