@@ -576,45 +576,47 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
                 if (work) { for (int u = 0; u < 2; ++u) n_cand += ok[u] ? 1 : 0; }
             }
         };
-        // the ball, not its bounding cube (see k_grid_nn)
+        // the ball, not its bounding cube (see k_grid_nn); once a hit bounds the answer the ball is the hit's, not the pass's
         const double r2 = r * r, etol = 1e-6 * G.h;
         double cull2 = __builtin_inf();
+        auto row_range = [&](long rr, uint32_t &b, uint32_t &len, double &lb2) {
+            b = 0; len = 0;
+            const int cy = lo[1] + (int)(rr % ny), cz = lo[2] + (int)(rr / ny);
+            const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
+            int xl = lo[0], xh = hi[0];
+            lb2 = 0.0;
+            if (!all) {
+                const double yl = G.mn[1] + (double)cy * G.h, zl = G.mn[2] + (double)cz * G.h;
+                const double dy = fmax(fmax(yl - etol - cyq, cyq - (yl + G.h + etol)), 0.0);
+                const double dz = fmax(fmax(zl - etol - czq, czq - (zl + G.h + etol)), 0.0);
+                lb2 = fma(dy, dy, dz * dz);
+                const double rem = fmin(r2, cull2) - lb2;
+                if (rem >= 0.0) {
+                    const double hw = (rem < 1e-30 ? 1e-15 : (double)(sqrtf((float)rem) * 1.000001f)) + etol;
+                    const double fl = floor((cxq - hw - G.mn[0]) * G.inv_h - 1e-6);
+                    const double fh = floor((cxq + hw - G.mn[0]) * G.inv_h + 1e-6);
+                    const int tl = fl < 0.0 ? 0 : (fl > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fl);
+                    const int th = fh < 0.0 ? 0 : (fh > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fh);
+                    xl = tl > xl ? tl : xl; xh = th < xh ? th : xh;
+                } else {
+                    xh = xl - 1;
+                }
+            }
+            if (xh >= xl) {
+                b = cell_start[row + xl];
+                len = cell_start[row + xh + 1] - b;
+            }
+        };
         for (long rb = 0; __any(rb < nrows); rb += 16) {
             uint32_t b = 0, len = 0;
             double lb2 = __builtin_inf();
-            if (rb + gl < nrows) {
-                const long rr = rb + gl;
-                const int cy = lo[1] + (int)(rr % ny), cz = lo[2] + (int)(rr / ny);
-                const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
-                int xl = lo[0], xh = hi[0];
-                lb2 = 0.0;
-                if (!all) {
-                    const double yl = G.mn[1] + (double)cy * G.h, zl = G.mn[2] + (double)cz * G.h;
-                    const double dy = fmax(fmax(yl - etol - cyq, cyq - (yl + G.h + etol)), 0.0);
-                    const double dz = fmax(fmax(zl - etol - czq, czq - (zl + G.h + etol)), 0.0);
-                    lb2 = fma(dy, dy, dz * dz);
-                    const double rem = r2 - lb2;
-                    if (rem >= 0.0) {
-                        const double hw = (rem < 1e-30 ? 1e-15 : (double)(sqrtf((float)rem) * 1.000001f)) + etol;
-                        const double fl = floor((cxq - hw - G.mn[0]) * G.inv_h - 1e-6);
-                        const double fh = floor((cxq + hw - G.mn[0]) * G.inv_h + 1e-6);
-                        const int tl = fl < 0.0 ? 0 : (fl > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fl);
-                        const int th = fh < 0.0 ? 0 : (fh > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fh);
-                        xl = tl > xl ? tl : xl; xh = th < xh ? th : xh;
-                    } else {
-                        xh = xl - 1;
-                    }
-                }
-                if (xh >= xl && lb2 <= cull2) {
-                    b = cell_start[row + xl];
-                    len = cell_start[row + xh + 1] - b;
-                }
-            }
+            if (rb + gl < nrows) row_range(rb + gl, b, len, lb2);
             unsigned todo = (unsigned)(__ballot(len > 0) >> gbase) & 0xffffu;      // this group's rows that hold points
             if (work && len > 0) n_rows += 1;
             const bool many = __popc(todo) > 4;
             if (__any(many)) {
-                // groups with many rows: nearest row first, then drop the rows its hit rules out
+                // groups with many rows: nearest row first, then drop the rows its hit rules out and shrink the others'
+                // x ranges to the hit's ball (one more look at the cell offsets, a fraction of the candidates)
                 unsigned long long key = len > 0 ? (unsigned long long)__double_as_longlong(lb2) : ~0ull, mk = key;
                 { unsigned long long o;
                   o = lane_xor64<8>(mk);  mk = o < mk ? o : mk;  o = lane_xor64<4>(mk);  mk = o < mk ? o : mk;
@@ -632,9 +634,13 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
                   o = lane_xor_f64<2>(gb);  gb = o < gb ? o : gb;  o = lane_xor_f64<1>(gb);  gb = o < gb ? o : gb; }
                 if (many && gb < __builtin_inf()) {
                     const double rbnd = sqrt(gb) * (1.0 + 1e-12) + slack;
-                    cull2 = rbnd * rbnd;
+                    const double c2 = rbnd * rbnd;
+                    if (c2 < cull2) {
+                        cull2 = c2;
+                        if (((todo >> gl) & 1u) && rb + gl < nrows) row_range(rb + gl, b, len, lb2);
+                    }
                 }
-                todo &= (unsigned)(__ballot(lb2 <= cull2) >> gbase) & 0xffffu;
+                todo &= (unsigned)(__ballot(len > 0 && lb2 <= cull2) >> gbase) & 0xffffu;
             }
             while (__any(todo != 0u)) {
                 uint32_t rbv[2], rlv[2];
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
                 }
                 done = true;
             } else {
-                r = found ? sqrt(best) * (1.0 + 1e-12) + slack : 2.0 * r;
+                r = found ? sqrt(best) * (1.0 + 1e-12) + slack : 1.4142135623730951 * r;
                 last = found;
                 if (r > r_lim) r = r_lim;
             }
