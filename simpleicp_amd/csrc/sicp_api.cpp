@@ -102,6 +102,10 @@ struct Cloud {
     DevBuf<float> pl;     // `planarity` column by GLOBAL index (pl_n entries; 0 = the cloud has no such column)
     int64_t pl_n = 0;
     DevBuf<double> xyz;   // x[npad] | y[npad] | z[npad]
+    // every 64th point with a grid of its own (built on demand for a cold chained search): the nearest SUBSAMPLE point is a cloud
+    // point, so its distance bounds the answer -- one cheap search hands the real one a radius instead of a doubling ladder
+    DevBuf<double> sub_xyz; int64_t sub_n = 0, sub_npad = 0;
+    Grid sub_grid;
     const double *x() const { return xyz.p; }
     const double *y() const { return xyz.p + npad; }
     const double *z() const { return xyz.p + 2 * npad; }
@@ -247,6 +251,10 @@ struct sicp_ctx {
     DevBuf<uint32_t> q_order;      // large query sets: the queries [q_order_lo, +q_order_cnt) in cell order (search locality)
     long q_order_lo = -1, q_order_cnt = 0;
     long order_min_q = 32768;      // SICP_ORDER_MIN_Q: from this many queries per launch on (0: never)
+    DevBuf<double> bound_p2, bound_d2;   // cold search: nearest subsample point per query (coordinates = the bound) + scratch
+    DevBuf<int64_t> bound_idx;
+    int coarse_iters = 1;          // SICP_COARSE_ITERS: chained iterations (from a cold start) whose search is bounded by the subsample's
+    long coarse_min_n = 262144;    // ... for clouds of at least this many points
     long nn16_min_q = 32768;       // SICP_NN16_MIN_Q: from this many queries per launch on the grid search runs four queries per wave
     int last_match_kernel = 0;     // 0 exact scan, 1 filtered scan (inline), 2 grid, 3 filtered scan (record + fix-up), 4 matrix-pipe filter, 5 grid, four queries per wave
     // ICP state (selected fixed points and per-iteration products)
@@ -478,12 +486,32 @@ double key_to_double(unsigned long long k)
 }
 
 // bins the cloud of `slot` once (own frame); see sicp_grid.hip
+int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const double *Y, const double *Z, long n, Grid &gr);
+
 int grid_build(sicp_ctx *c, int slot)
 {
     Cloud &cl = c->cloud[slot];
-    Grid &gr = cl.grid;
+    return grid_build_arrays(c, cl, cl.x(), cl.y(), cl.z(), cl.n, cl.grid);
+}
+
+// the cloud's subsample (every SUB_STRIDE-th point) and its grid
+constexpr long SUB_STRIDE = 64;
+int subsample_build(sicp_ctx *c, int slot)
+{
+    Cloud &cl = c->cloud[slot];
+    if (cl.sub_grid.valid) return SICP_OK;
+    cl.sub_n = (cl.n + SUB_STRIDE - 1) / SUB_STRIDE;
+    cl.sub_npad = round_up(cl.sub_n, 1024);
+    CHK(cl.sub_xyz.reserve((size_t)3 * cl.sub_npad));
+    launch_stride_sample(c->stream, cl.x(), cl.y(), cl.z(), cl.n, SUB_STRIDE, cl.sub_n, cl.sub_npad, cl.sub_xyz.p);
+    HIPCHK(hipGetLastError());
+    return grid_build_arrays(c, cl, cl.sub_xyz.p, cl.sub_xyz.p + cl.sub_npad, cl.sub_xyz.p + 2 * cl.sub_npad, cl.sub_n, cl.sub_grid);
+}
+
+// bins n points (columns X, Y, Z, inside cl's bounding box) once; see sicp_grid.hip
+int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const double *Y, const double *Z, long n, Grid &gr)
+{
     if (gr.valid) return SICP_OK;
-    const long n = cl.n;
     double mn[3], ex[3], vol = 1.0; int deff = 0;
     for (int a = 0; a < 3; ++a) {
         mn[a] = cl.bb_lo[a];
@@ -522,7 +550,7 @@ int grid_build(sicp_ctx *c, int slot)
             CHK(c->g_counts.reserve((size_t)wc + 1));
             HIPCHK(hipMemsetAsync(c->g_counts.p, 0, ((size_t)wc + 1) * sizeof(uint32_t), c->stream));
             HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), c->stream));
-            launch_window_probe(c->stream, cl.x(), cl.y(), cl.z(), n, every, W, whi, c->g_counts.p, d_cnt);
+            launch_window_probe(c->stream, X, Y, Z, n, every, W, whi, c->g_counts.p, d_cnt);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(c->h_small + 54, d_cnt, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             CHK(sync(c));
@@ -563,7 +591,7 @@ int grid_build(sicp_ctx *c, int slot)
         CHK(c->g_counts.reserve((size_t)ncells + 1));
         HIPCHK(hipMemsetAsync(c->g_counts.p, 0, ((size_t)ncells + 1) * sizeof(uint32_t), c->stream));
         HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), c->stream));
-        launch_cell_ids(c->stream, cl.x(), cl.y(), cl.z(), n, G, c->g_ids.p, c->g_counts.p, probed ? nullptr : d_cnt);
+        launch_cell_ids(c->stream, X, Y, Z, n, G, c->g_ids.p, c->g_counts.p, probed ? nullptr : d_cnt);
         HIPCHK(hipGetLastError());
         if (probed) { gr.avg_per_cell = target; break; }
         HIPCHK(hipMemcpyAsync(c->h_small + 54, d_cnt, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -582,7 +610,7 @@ int grid_build(sicp_ctx *c, int slot)
     CHK(c->g_blk.reserve((size_t)grid_scan_blocks(ncells) + 1));
     CHK(gr.rec.reserve((size_t)4 * n));
     launch_grid_scan(c->stream, c->g_counts.p, ncells, c->g_blk.p, gr.cell_start.p, c->g_cursor.p);
-    launch_scatter(c->stream, cl.x(), cl.y(), cl.z(), c->g_ids.p, n, c->g_cursor.p, gr.rec.p);
+    launch_scatter(c->stream, X, Y, Z, c->g_ids.p, n, c->g_cursor.p, gr.rec.p);
     HIPCHK(hipGetLastError());
     CHK(sync(c));
     gr.valid = true;
@@ -942,6 +970,8 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_LM_EVALS")) { const int d = std::atoi(e); if (d >= 0 && d <= 32) c->lm_evals = d; }
     if (const char *e = std::getenv("SICP_ORDER_MIN_Q")) c->order_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_NN16_MIN_Q")) c->nn16_min_q = std::atol(e);
+    if (const char *e = std::getenv("SICP_COARSE_ITERS")) c->coarse_iters = std::atoi(e);
+    if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
     if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
     if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : !std::strcmp(e, "mfma") ? 2 : 0;
     if (const char *e = std::getenv("SICP_FSCAN_CAP")) c->fscan_cap = std::atol(e);
@@ -963,8 +993,9 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     if (c->comm) { (void)rccl()->CommDestroy(c->comm); c->comm = nullptr; }
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    for (auto &cl : c->cloud) { cl.xyz.release(); cl.pl.release(); cl.grid.cell_start.release(); cl.grid.rec.release(); }
-    c->q_order.release(); c->g_ids.release(); c->g_counts.release(); c->g_cursor.release(); c->g_blk.release(); c->match_work.release(); c->rj_keys.release();
+    for (auto &cl : c->cloud) { cl.xyz.release(); cl.pl.release(); cl.grid.cell_start.release(); cl.grid.rec.release();
+                                 cl.sub_xyz.release(); cl.sub_grid.cell_start.release(); cl.sub_grid.rec.release(); }
+    c->bound_p2.release(); c->bound_d2.release(); c->bound_idx.release(); c->q_order.release(); c->g_ids.release(); c->g_counts.release(); c->g_cursor.release(); c->g_blk.release(); c->match_work.release(); c->rj_keys.release();
     c->stage.release(); c->part_d2.release(); c->part_idx.release(); c->kq.release(); c->k_d2.release();
     c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->hit_cnt.release(); c->hit_list.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
@@ -997,7 +1028,7 @@ int upload_begin(sicp_ctx *c, int slot, int64_t n, int64_t index_base)
     HIPCHK(hipSetDevice(c->device));
     Cloud &cl = c->cloud[slot];
     cl.n = n; cl.npad = round_up(n, TILE_PTS); cl.idx_base = index_base;
-    cl.grid.valid = false;
+    cl.grid.valid = false; cl.sub_grid.valid = false;
     cl.pl_n = 0;                                       // a new cloud has no planarity column until one is set
     CHK(cl.xyz.reserve((size_t)3 * cl.npad));
     return SICP_OK;
@@ -1073,7 +1104,7 @@ SICP_EXPORT int sicp_cloud_transform(sicp_ctx *c, int slot, const double H[16])
     Cloud &cl = c->cloud[slot];
     launch_transform(c->stream, cl.x(), cl.y(), cl.z(), cl.n, X);
     HIPCHK(hipGetLastError());
-    cl.grid.valid = false;
+    cl.grid.valid = false; cl.sub_grid.valid = false;
     return cloud_stats(c, slot);                          // new bounding box / largest norm (also the synchronisation point)
 }
 
@@ -1349,6 +1380,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
     double seqs[REC_RING];
     double xcur[6]; std::memcpy(xcur, P0->x, sizeof xcur);
     int64_t launched = 0, completed = 0;
+    const bool cold_start = !c->have_prev_match;      // no earlier match of these queries to bound the first searches
     bool over = false;
     int rc = SICP_OK;
     const bool htrace = c->host_trace;
@@ -1365,12 +1397,26 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 c->last_match_kernel = cnt >= c->nn16_min_q ? 5 : 2;
                 const bool ordered = c->order_min_q > 0 && cnt >= c->order_min_q;
                 if (ordered) CHK(query_order_build(c, lo, cnt, cl.grid.g.h));
+                // A search without a useful bound (the run's first iterations: no previous match, or one made under an estimate
+                // that was metres off) first asks the cloud's SUBSAMPLE for its nearest point: a cloud point, so a bound, and
+                // close enough to the answer that the real search goes straight to that radius instead of doubling its way out.
+                const bool coarse = cold_start && launched < c->coarse_iters && cl.n >= c->coarse_min_n && cnt > 0;
+                if (coarse) {
+                    CHK(subsample_build(c, SICP_MOV));
+                    CHK(c->bound_p2.reserve((size_t)3 * Q)); CHK(c->bound_d2.reserve(Q)); CHK(c->bound_idx.reserve(Q));
+                }
                 Timed t(c, SICP_K_KNN1);
+                if (coarse)
+                    launch_grid_nn_chained(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt, nullptr,
+                                           cl.sub_grid.g, cl.sub_grid.cell_start.p, cl.sub_grid.rec.p, c->icp_dev.p, cl.rmax, 0,
+                                           c->bound_d2.p + lo, c->bound_idx.p + lo, c->bound_p2.p + 3 * lo, nullptr,
+                                           ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q);
                 if (cnt > 0)
                     launch_grid_nn_chained(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt,
-                                           prev ? prev + 3 * lo : nullptr, cl.grid.g, cl.grid.cell_start.p, cl.grid.rec.p,
-                                           c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo, c->m_p2.p + 3 * lo,
-                                           c->count_work ? c->match_work.p : nullptr, ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q);
+                                           coarse ? c->bound_p2.p + 3 * lo : (prev ? prev + 3 * lo : nullptr), cl.grid.g,
+                                           cl.grid.cell_start.p, cl.grid.rec.p, c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p + lo,
+                                           c->m_idx.p + lo, c->m_p2.p + 3 * lo, c->count_work ? c->match_work.p : nullptr,
+                                           ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q, coarse);
             } else if (qshard) {
                 return fail(SICP_ERR_INVALID, "query shards need the grid search (SICP_KNN1 forces another kernel)");
             } else {

@@ -237,6 +237,18 @@ __global__ __launch_bounds__(256) void k_scatter(const double *__restrict__ x, c
     rec[pos] = make_double4(x[i], y[i], z[i], __longlong_as_double((long long)i));
 }
 
+// every `stride`-th point of a cloud (column layout in, column layout out): the subsample whose nearest point bounds a cold search
+__global__ __launch_bounds__(256) void k_stride_sample(const double *__restrict__ x, const double *__restrict__ y,
+                                                       const double *__restrict__ z, long n, long stride, long m, long mpad,
+                                                       double *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= mpad) return;
+    const bool in = i < m;
+    const long j = in ? i * stride : 0;
+    out[i] = in ? x[j] : 1e300; out[mpad + i] = in ? y[j] : 1e300; out[2 * mpad + i] = in ? z[j] : 1e300;
+}
+
 // the same counting sort for QUERIES, keeping only the permutation: order[slot] = query (large query sets are searched
 // in cell order so that waves running side by side read the same rows of the cloud's grid)
 __global__ __launch_bounds__(256) void k_scatter_order(const uint32_t *__restrict__ ids, long n, uint32_t *__restrict__ cursor,
@@ -275,7 +287,8 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     Xf H, Xf Hinv, double rmax, double max_d2, int64_t idx_base,
     double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
     const IcpDev *__restrict__ st, unsigned long long *__restrict__ work /* nullable: [0] candidates, [1] rows, [2] launches */,
-    const uint32_t *__restrict__ order /* nullable: queries in cell order (grid size is a multiple of 8 then) */)
+    const uint32_t *__restrict__ order /* nullable: queries in cell order (grid size is a multiple of 8 then) */,
+    int tight /* prev_p2 is a bound to search in one go (the nearest point of a subsample), not an old match */)
 {
     const int lane = threadIdx.x & 63;
     long q = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     // a bound that spans many cells (first iterations: the estimate still moves by metres) is not searched in one
     // go: start small and let the first hit shrink the ball
     double r = 0.75 * G.h;
-    if (r > r_lim) r = r_lim;
+    if (r > r_lim || (tight && r_lim < __builtin_inf())) r = r_lim;
 
     double best = __builtin_inf(), bx = 0, by = 0, bz = 0;
     uint32_t bidx = 0xffffffffu;
@@ -500,7 +513,7 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
     const double *__restrict__ prev_p2, GridGeom G, const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
     Xf H, Xf Hinv, double rmax, double max_d2, int64_t idx_base,
     double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
-    const IcpDev *__restrict__ st, unsigned long long *__restrict__ work, const uint32_t *__restrict__ order)
+    const IcpDev *__restrict__ st, unsigned long long *__restrict__ work, const uint32_t *__restrict__ order, int tight)
 {
     const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48;
     long blk = blockIdx.x;
@@ -532,7 +545,7 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
         }
     }
     double r = 0.75 * G.h;
-    if (r > r_lim) r = r_lim;
+    if (r > r_lim || (tight && r_lim < __builtin_inf())) r = r_lim;
 
     bool done = !active, last = false;
     unsigned long long n_cand = 0, n_rows = 0;
@@ -1163,39 +1176,45 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
         if (H)
             hipLaunchKernelGGL((k_grid_nn16<true, false>), g16, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec,
                                *H, *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work,
-                               (const uint32_t *)nullptr);
+                               (const uint32_t *)nullptr, 0);
         else
             hipLaunchKernelGGL((k_grid_nn16<false, false>), g16, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec,
                                id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work,
-                               (const uint32_t *)nullptr);
+                               (const uint32_t *)nullptr, 0);
         return;
     }
     if (H)
         hipLaunchKernelGGL((k_grid_nn<true, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec, *H,
-                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work, (const uint32_t *)nullptr);
+                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work, (const uint32_t *)nullptr, 0);
     else
         hipLaunchKernelGGL((k_grid_nn<false, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec, id,
-                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work, (const uint32_t *)nullptr);
+                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work, (const uint32_t *)nullptr, 0);
 }
 
 // the match of a chained iteration: transform taken from the loop state on the device
 void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                             const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
                             int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
-                            const uint32_t *order, bool four_per_wave)
+                            const uint32_t *order, bool four_per_wave, bool tight)
 {
     Xf id = {};
     if (four_per_wave) {
         unsigned g16 = cdiv(Q, 16);
         if (order) g16 = (g16 + 7u) & ~7u;
         hipLaunchKernelGGL((k_grid_nn16<true, true>), dim3(g16), dim3(256), 0, s, qx, qy, qz, Q, prev_p2, G, cell_start,
-                           (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work, order);
+                           (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work, order, tight ? 1 : 0);
         return;
     }
     unsigned g = cdiv(Q, 4);
     if (order) g = (g + 7u) & ~7u;
     hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(g), dim3(256), 0, s, qx, qy, qz, Q, prev_p2, G, cell_start,
-                       (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work, order);
+                       (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work, order, tight ? 1 : 0);
+}
+
+void launch_stride_sample(hipStream_t s, const double *x, const double *y, const double *z, long n, long stride, long m, long mpad,
+                          double *out)
+{
+    hipLaunchKernelGGL(k_stride_sample, dim3(cdiv(mpad, 256)), dim3(256), 0, s, x, y, z, n, stride, m, mpad, out);
 }
 
 void launch_scatter_order(hipStream_t s, const uint32_t *ids, long n, uint32_t *cursor, uint32_t *order)
