@@ -253,6 +253,7 @@ struct sicp_ctx {
     long order_min_q = 32768;      // SICP_ORDER_MIN_Q: from this many queries per launch on (0: never)
     DevBuf<double> bound_p2, bound_d2;   // cold search: nearest subsample point per query (coordinates = the bound) + scratch
     DevBuf<int64_t> bound_idx;
+    bool reject_split = true;      // SICP_REJECT_SPLIT=0: mid-Q distances inside the single-workgroup rejection kernel
     int coarse_iters = 1;          // SICP_COARSE_ITERS: chained iterations (from a cold start) whose search is bounded by the subsample's
     long coarse_min_n = 262144;    // ... for clouds of at least this many points
     long nn16_min_q = 32768;       // SICP_NN16_MIN_Q: from this many queries per launch on the grid search runs four queries per wave
@@ -970,6 +971,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_LM_EVALS")) { const int d = std::atoi(e); if (d >= 0 && d <= 32) c->lm_evals = d; }
     if (const char *e = std::getenv("SICP_ORDER_MIN_Q")) c->order_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_NN16_MIN_Q")) c->nn16_min_q = std::atol(e);
+    if (const char *e = std::getenv("SICP_REJECT_SPLIT")) c->reject_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_COARSE_ITERS")) c->coarse_iters = std::atoi(e);
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
     if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
@@ -1442,9 +1444,18 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 // distances + rejections (corrpts.py:139-211), kept-distance statistics, then the solver chain
                 if (Q <= REJECT_MAX_Q) {
                     Timed t(c, SICP_K_SELECT);
-                    launch_dist_reject_stats(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q,
-                                             A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->keep.p, c->small.p,
-                                             c->small.p + 4, c->icp_dev.p);
+                    if (c->reject_split) {
+                        // distances + flags by the whole machine, then selection + keep mask + statistics by one workgroup on
+                        // the 9 bytes per correspondence it still has to read
+                        Xf unused = {};
+                        launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
+                                         A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
+                        launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->icp_dev.p, c->small.p + 4);
+                    } else {
+                        launch_dist_reject_stats(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q,
+                                                 A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->keep.p, c->small.p,
+                                                 c->small.p + 4, c->icp_dev.p);
+                    }
                 } else {
                     Xf unused = {};
                     launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,

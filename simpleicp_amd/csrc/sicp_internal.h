@@ -154,7 +154,8 @@ void launch_postmatch(hipStream_t s, const double *qx, const double *qy, const d
                       const float *planarity, const double *p2, const int64_t *idx, long Q, const Xf &H,
                       float min_planarity, const float *pl2, long pl2_n, double *dist, uint8_t *flag, const IcpDev *st = nullptr);
 // st (nullable): loop state of a chained run -- H comes from it (postmatch) and every kernel exits at once when the run is over
-void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, const IcpDev *st = nullptr);
+void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
+                   const IcpDev *st = nullptr, double *out3 = nullptr);
 void launch_dist_reject_stats(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
                               const float *planarity, const double *p2, const int64_t *idx, long Q, float min_planarity,
                               const float *pl2, long pl2_n, double *dist, uint8_t *flag, uint8_t *keep, double *out4, double *out3,

@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(RJ_BLOCK) void k_reject(
         for (int i = tid; i < n; i += RJ_BLOCK) keep[i] = 0;
         if (tid == 0) {
             out4[0] = 0; out4[1] = __builtin_nan(""); out4[2] = __builtin_nan(""); out4[3] = 0;
-            if (FUSED) { out3[0] = 0; out3[1] = __builtin_nan(""); out3[2] = __builtin_nan(""); }
+            if (out3) { out3[0] = 0; out3[1] = __builtin_nan(""); out3[2] = __builtin_nan(""); }
         }
         return;
     }
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(RJ_BLOCK) void k_reject(
         keep[i] = kq;
         if (kq) {
             v3[0] += 1.0;
-            if (FUSED) { const double dev = dist[i] - med; v3[1] += dev; v3[2] = fma(dev, dev, v3[2]); }
+            if (out3) { const double dev = dist[i] - med; v3[1] += dev; v3[2] = fma(dev, dev, v3[2]); }
         }
     }
 #pragma unroll
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(RJ_BLOCK) void k_reject(
         double t[3] = {0.0, 0.0, 0.0};
         for (int w = 0; w < RJ_WAVES; ++w) for (int j = 0; j < 3; ++j) t[j] += S.red[1][w][j];
         out4[0] = (double)m; out4[1] = med; out4[2] = mad; out4[3] = t[0];
-        if (FUSED) {
+        if (out3) {
             const double var = (t[2] - t[1] * t[1] / t[0]) / t[0];
             out3[0] = t[0]; out3[1] = med + t[1] / t[0]; out3[2] = sqrt(var > 0.0 ? var : 0.0);
         }
@@ -1580,10 +1580,11 @@ void launch_scatter_f32(hipStream_t s, float *dst, const int64_t *rows, const fl
     if (m > 0) hipLaunchKernelGGL(k_scatter_f32, dim3(cdiv(m, 256)), dim3(256), 0, s, dst, rows, vals, m);
 }
 
-void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, const IcpDev *st)
+void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, const IcpDev *st,
+                   double *out3)
 {
     hipLaunchKernelGGL(k_reject<false>, dim3(1), dim3(RJ_BLOCK), 0, s, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
-                       nullptr, 0L, (double *)dist, (uint8_t *)flag, Q, keep, out4, nullptr, st);
+                       nullptr, 0L, (double *)dist, (uint8_t *)flag, Q, keep, out4, out3, st);
 }
 
 // chained runs, 2048 < Q <= REJECT_MAX_Q: distances + flags + rejection + kept-distance statistics in one launch
