@@ -111,6 +111,7 @@ res = {}
 res["cloud"] = run()                                    # the movable cloud in index shards, one all-gather + lexmin per iteration
 os.environ["SICP_PARTITION"] = "queries"
 res["queries"] = run()                                  # every rank the whole cloud, its slice of the queries
+res["queries_odd"] = run(correspondences=999)           # ... of unequal length (the last rank's slice is one short)
 del os.environ["SICP_PARTITION"]
 os.environ["SICP_GN_SHARD"] = "1"
 res["gn"] = run()                                       # + the 6x6 reduction sharded (SUM all-reduce per solver step)
@@ -133,14 +134,14 @@ def test_two_ranks_sharing_one_gpu_agree_with_one_rank(tmp_path):
     from conftest import load_golden, load_cloud
     from simpleicp_amd import PointCloud, SimpleICP
 
-    def run(name):
+    def run(name, **extra):
         g, files, kw = load_golden(name)
         pf = PointCloud(load_cloud(files[0]), columns=["x", "y", "z"]); pm = PointCloud(load_cloud(files[1]), columns=["x", "y", "z"])
         icp = SimpleICP(verbose=False); icp.add_point_clouds(pf, pm)
-        H, X, rbp, res = icp.run(**kw)
+        H, X, rbp, res = icp.run(**{**kw, **extra})
         return H, X, res, icp.last_run_info["iterations"]
 
-    ref = {"bunny": run("bunny"), "dragon_q5000": run("dragon_q5000")}
+    ref = {"bunny": run("bunny"), "dragon_q5000": run("dragon_q5000"), "bunny_999": run("bunny", correspondences=999)}
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -153,7 +154,7 @@ def test_two_ranks_sharing_one_gpu_agree_with_one_rank(tmp_path):
     assert all(p.returncode == 0 for p in procs) and all("RANK_OK" in o for o in outs), "\n".join(o[-3000:] for o in outs)
     for r in range(2):
         z = np.load(tmp_path / f"rank{r}.npz")
-        for key, name in (("cloud", "bunny"), ("queries", "bunny"), ("dragon_q5000", "dragon_q5000")):
+        for key, name in (("cloud", "bunny"), ("queries", "bunny"), ("queries_odd", "bunny_999"), ("dragon_q5000", "dragon_q5000")):
             H, X, res, it = ref[name]
             assert int(z[key + "_it"]) == it and np.array_equal(z[key + "_H"], H) and np.array_equal(z[key + "_X"], X) \
                 and np.array_equal(z[key + "_r"], res), (key, r, np.abs(z[key + "_H"] - H).max())
