@@ -529,3 +529,35 @@ def test_iteration_with_movable_selection_and_planarity(ctx, name, clouds):
         ctx.icp_setup(np.array([0, len(Xf)]), np.zeros((2, 3), np.float32), np.zeros(2, np.float32))
     with pytest.raises(_lib.BackendError):
         ctx.estimate_normals(_lib.FIX, np.array([-1, 3]), 5)
+
+
+@pytest.mark.parametrize("Q", [1500, 9000, 20_000])
+@pytest.mark.parametrize("layers", [1, 2, 3])
+def test_rejection_with_massive_duplicate_distances(ctx, Q, layers):
+    """Thousands of EXACTLY equal distances (planes at exact offsets, exact normals): every selection flavour must walk its
+    digits / bins down to a single key value and still get rank, second middle value and count right -- the fused tail
+    (Q <= 2048), the one-workgroup LDS selection, and the multi-workgroup digit selection whose survivors no longer fit its
+    candidate list (> 256 equal keys).  All parameters fixed (infinite weights): the iteration is match + rejection only."""
+    from simpleicp_amd import _lib
+    g = np.arange(300) * 0.1
+    P = np.column_stack([a.ravel() for a in np.meshgrid(g, g)] + [np.zeros(90_000)])          # lattice plane z = 0
+    off = np.array([0.5, 0.25, 1.0])[:layers]
+    z = off[np.minimum((P[:, 0] / 30.0 * layers).astype(int), layers - 1)]                      # 1, 2 or 3 exact offsets, by strip
+    Xm = P + np.column_stack((np.full(len(P), 0.003), np.full(len(P), 0.002), z))
+    rng = np.random.default_rng(Q + layers)
+    sel = np.sort(rng.choice(len(P), Q, replace=False))
+    nv = np.tile(np.array([[0, 0, 1]], dtype=np.float32), (Q, 1))
+    pl = np.ones(Q, dtype=np.float32)
+    pl[::7] = 0.1                                                                               # some rows fail the planarity test
+    ctx.upload(_lib.FIX, P)
+    ctx.upload(_lib.MOV, Xm)
+    ctx.icp_setup(sel, nv, pl)
+    z6, fixed = np.zeros(6), np.full(6, np.inf)
+    o = orc.icp_iteration(Xm, P[sel], nv, pl, z6, z6, 1.0, z6, fixed, 0.3)
+    R = ctx.icp_iterate(z6, z6, fixed, 0.3, 1.0)
+    idx, dist, keep, _ = ctx.icp_state()
+    assert np.array_equal(idx, o["nn"]) and np.array_equal(dist, o["dist"])
+    assert len(np.unique(dist)) == layers                                                       # the duplicates are real
+    assert R.median == o["median"] and R.mad == o["mad"] and R.n_kept == o["n"]
+    assert np.array_equal(keep, o["keep"])
+    assert np.array_equal(np.array(R.x[:]), z6)
