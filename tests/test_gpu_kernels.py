@@ -275,6 +275,7 @@ def ctx_filter(request):
     if request.param == "grid16":
         env["SICP_NN16_MIN_Q"] = "1"
         env["SICP_ORDER_MIN_Q"] = "1"        # ... and the iteration's queries in cell order, one eighth per XCD
+        env["SICP_COARSE_MIN_N"] = "1"       # ... and a cold iteration bounded by the subsample's nearest point whatever the cloud size
     os.environ.update(env)
     try:
         c = _lib.Context(0)
