@@ -201,3 +201,39 @@ def test_sparse_attribute_columns_equal_dense_construction():
         assert np.array_equal(pl, pc["planarity"].to_numpy().astype(np.float32)[idx], equal_nan=True)
     pc["nx"] = np.arange(n, dtype=np.float64)                            # a caller-assigned dense column
     assert np.array_equal(pc._attributes_of(sel)[0][:, 0], np.arange(n, dtype=np.float32)[sel])
+
+
+def _build_c_demo(tmp_path):
+    import subprocess
+    from simpleicp_amd import build
+    build.build()
+    exe = tmp_path / "c_abi_demo"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O2", f"-I{ROOT / 'include'}",
+                        str(ROOT / "examples" / "c_abi_demo.c"), f"-L{ROOT / 'simpleicp_amd'}", "-lsimpleicp_hip", "-lm",
+                        f"-Wl,-rpath,{ROOT / 'simpleicp_amd'}", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_host_links(tmp_path):
+    """include/simpleicp_hip.h is C99 (-pedantic -Werror) and a C program links against the library; without a device
+    it fails LOUDLY with SICP_ERR_NO_DEVICE (exit code 3 of the demo), it does not compute on the host."""
+    import subprocess
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c",
+                        str(ROOT / "include" / "simpleicp_hip.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = _build_c_demo(tmp_path)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is visible: the GPU flavour of this test runs the demo to the end")
+    r = subprocess.run([str(exe), "20000", "500"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "ABI version 1" in r.stdout and "no HIP device" in r.stderr, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_c_host_runs_an_icp(tmp_path):
+    """examples/c_abi_demo.c: uploads, normals, the whole iteration loop and the result through the C ABI from plain C."""
+    import subprocess
+    exe = _build_c_demo(tmp_path)
+    r = subprocess.run([str(exe), "200000", "1000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "max |x - x_true|" in r.stdout, (r.returncode, r.stdout, r.stderr)
