@@ -179,6 +179,39 @@ int sicp_icp_uncertainties(sicp_ctx *ctx, double sigma_out[6]);
  * out[28] sum r^2, out[29] n. */
 int sicp_icp_normal_equations(sicp_ctx *ctx, const double x[6], double out[30]);
 
+/* ---- the iteration's operators one by one ------------------------------------------------ */
+/* sicp_icp_iterate is the reference's loop body in one call.  A caller that drives the reference's classes itself
+ * -- CorrPts(pc1, pc2).match() / .reject_wrt_planarity() / .reject_wrt_point_to_plane_distances(), then
+ * SimpleICPOptimization(...).estimate_parameters() (simpleicp.py:190-227) -- binds these instead; they share the
+ * iteration's kernels and its state (sicp_icp_setup declares pc1's selected points and normals; the movable cloud is
+ * pc2.X_selected).  A correspondence is "alive" until a rejection drops it (the reference drops the row from its
+ * DataFrame, corrpts.py:156,163,188); sicp_icp_get_state returns the alive mask as `keep`.
+ *
+ * CorrPts.match (corrpts.py:124-137) + __compute_point_to_plane_distances (corrpts.py:195-211): nearest movable
+ * point of every selected fixed point under H (NULL = identity: the caller has transformed pc2 itself, as
+ * simpleicp.py:188 does) and the signed point-to-plane distance to it; every correspondence is alive afterwards.
+ *   pc2_idx_out (Q) int64 (global index), dist_out (Q) float64; either may be NULL. */
+int sicp_corr_match(sicp_ctx *ctx, const double *H, int64_t *pc2_idx_out, double *dist_out);
+/* CorrPts.reject_wrt_planarity (corrpts.py:139-163): alive &= planarity >= min_planarity (float32 compare, NaN
+ * fails) for the correspondence's point in pc1 and in pc2.  The columns are handed over PER CORRESPONDENCE, (Q)
+ * float32 in query order -- the reference's `pc.iloc[idx]["planarity"]`; NULL = that cloud has no such column and
+ * is not tested (corrpts.py:151,158). */
+int sicp_corr_reject_planarity(sicp_ctx *ctx, double min_planarity, const float *pc1_planarity,
+                               const float *pc2_planarity, int64_t *n_alive_out);
+/* CorrPts.reject_wrt_point_to_plane_distances (corrpts.py:165-188) over the alive correspondences: median (mean of
+ * the two middle values), raw MAD (scale 1.0), alive &= |d - median| <= 3 MAD.  median / mad are NaN when nothing
+ * was alive. */
+int sicp_corr_reject_distances(sicp_ctx *ctx, double *median_out, double *mad_out, int64_t *n_alive_out);
+/* SimpleICPOptimization.estimate_parameters (optimization.py:65-124) over the alive correspondences: minimises the
+ * reference's objective from params->x (min_planarity is ignored here) and leaves the unweighted residuals for
+ * sicp_icp_get_state, the estimate for sicp_icp_uncertainties.
+ *   pc2_xyz : optional (Q,3) coordinates of the matched movable points as they are NOW (host-or-device) -- the
+ *             reference reads pc2's coordinates when it optimises, after it has undone the match's transform
+ *             (simpleicp.py:202); NULL = the coordinates the match saw.
+ * SICP_ERR_TOO_FEW below 6 alive correspondences (simpleicp.py:209-214). */
+int sicp_estimate_parameters(sicp_ctx *ctx, const sicp_iter_params *params, const double *pc2_xyz,
+                             sicp_iter_result *result);
+
 /* mathutils.py:39-68,81-93: parameters -> 4x4 row-major H (host only). */
 int sicp_params_to_H(const double x[6], double H_out[16]);
 

@@ -3,6 +3,10 @@
 Drop-in for ``from simpleicp import SimpleICP, PointCloud, RigidBodyParameters``
 (/root/reference/python/simpleicp/__init__.py:12-14); the hot path runs in hand-written HIP
 kernels (simpleicp_amd/csrc) loaded through a C ABI (include/simpleicp_hip.h).
+
+The reference's other modules keep their names for callers that drive the loop themselves:
+``simpleicp_amd.corrpts.CorrPts``, ``simpleicp_amd.optimization.SimpleICPOptimization``,
+``simpleicp_amd.mathutils``, ``simpleicp_amd.simpleicp`` (operator by operator on the same kernels).
 """
 import logging as _logging
 

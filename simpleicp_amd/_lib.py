@@ -29,6 +29,7 @@ EXPORTS = [
     "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_upload_columns", "sicp_cloud_size", "sicp_cloud_transform",
     "sicp_cloud_download", "sicp_cloud_download_columns", "sicp_cloud_set_planarity", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
+    "sicp_corr_match", "sicp_corr_reject_planarity", "sicp_corr_reject_distances", "sicp_estimate_parameters",
     "sicp_set_exchange", "sicp_comm_unique_id", "sicp_comm_init", "sicp_comm_destroy", "sicp_set_partition", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_last_match_kernel",
     "sicp_xyz_count", "sicp_xyz_read", "sicp_xyz_write",
 ]
@@ -100,6 +101,10 @@ def load():
     L.sicp_icp_uncertainties.argtypes = [vp, vp]
     L.sicp_icp_normal_equations.argtypes = [vp, vp, vp]
     L.sicp_params_to_H.argtypes = [vp, vp]
+    L.sicp_corr_match.argtypes = [vp, vp, vp, vp]
+    L.sicp_corr_reject_planarity.argtypes = [vp, dbl, vp, vp, C.POINTER(i64)]
+    L.sicp_corr_reject_distances.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(i64)]
+    L.sicp_estimate_parameters.argtypes = [vp, C.POINTER(IterParams), vp, C.POINTER(IterResult)]
     L.sicp_set_exchange.argtypes = [vp, EXCHANGE_FN, vp, cint, cint, cint]
     L.sicp_comm_unique_id.argtypes = [vp]
     L.sicp_comm_init.argtypes = [vp, vp, cint, cint, cint]
@@ -331,6 +336,55 @@ class Context:
         out = np.empty(30)
         self._chk(self._L.sicp_icp_normal_equations(self._h, _ptr(_f64(x)), _ptr(out)))
         return out
+
+    # -- the iteration's operators one by one (CorrPts / SimpleICPOptimization, corrpts.py / optimization.py) --
+    def corr_match(self, H=None):
+        """CorrPts.match: (pc2_idx (Q) int64, point-to-plane distances (Q)) of the points declared by icp_setup in the
+        movable slot under H (None = identity); every correspondence is alive afterwards."""
+        Q = self._Q
+        idx, dist = np.empty(Q, np.int64), np.empty(Q, np.float64)
+        Hc = None if H is None else _f64(H).reshape(16)
+        self._chk(self._L.sicp_corr_match(self._h, _ptr(Hc), _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def corr_reject_planarity(self, min_planarity, pc1_planarity=None, pc2_planarity=None):
+        """CorrPts.reject_wrt_planarity; the columns per correspondence ((Q) float32, None = the cloud has none).
+        Returns the number of correspondences still alive."""
+        def col(v):
+            if v is None:
+                return None
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            if v.shape != (self._Q,):
+                raise ValueError("planarity columns must have one value per correspondence")
+            return v
+        p1, p2 = col(pc1_planarity), col(pc2_planarity)
+        n = C.c_int64()
+        self._chk(self._L.sicp_corr_reject_planarity(self._h, float(min_planarity), _ptr(p1), _ptr(p2), C.byref(n)))
+        return n.value
+
+    def corr_reject_distances(self):
+        """CorrPts.reject_wrt_point_to_plane_distances over the alive correspondences: (median, mad, n_alive)."""
+        med, mad, n = C.c_double(), C.c_double(), C.c_int64()
+        self._chk(self._L.sicp_corr_reject_distances(self._h, C.byref(med), C.byref(mad), C.byref(n)))
+        return med.value, mad.value, n.value
+
+    def estimate_parameters(self, x, obs, obs_weight, distance_weight=1.0, pc2_xyz=None, max_lm_steps=0):
+        """SimpleICPOptimization.estimate_parameters over the alive correspondences, from x; pc2_xyz: (Q,3) current
+        coordinates of the matched movable points (None = as matched).  Returns IterResult."""
+        P = IterParams((C.c_double * 6)(*x), (C.c_double * 6)(*obs), (C.c_double * 6)(*obs_weight),
+                       0.0, -1.0 if distance_weight is None else distance_weight, int(max_lm_steps))
+        R = IterResult()
+        p2 = None
+        if pc2_xyz is not None:
+            p2 = _f64(pc2_xyz)
+            if p2.shape != (self._Q, 3):
+                raise ValueError("pc2_xyz must be (Q, 3)")
+        rc = self._L.sicp_estimate_parameters(self._h, C.byref(P), _ptr(p2), C.byref(R))
+        if rc != OK:
+            err = BackendError(self._L.sicp_last_error().decode(), rc)
+            err.result = R
+            raise err
+        return R
 
     def stream_ptr(self):
         """Raw hipStream_t of the context (for torch.cuda.ExternalStream)."""

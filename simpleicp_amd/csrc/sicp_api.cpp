@@ -270,6 +270,8 @@ struct sicp_ctx {
     DevBuf<unsigned> ticket;
     double *h_small = nullptr;     // pinned mirror of `small`
     bool have_iter = false;
+    bool have_corr = false;        // sicp_corr_match has run: m_idx / m_p2 / dist hold its correspondences, `keep` the alive mask
+    DevBuf<float> corr_pl;         // per-correspondence planarity columns handed to sicp_corr_reject_planarity: pc1 [Q] | pc2 [Q]
     double last_x[6] = {0}, last_w = 1.0, last_obs[6] = {0}, last_ow[6] = {0};
     double last_ne[30] = {0};      // normal equations at last_x (fused path caches them)
     bool have_last_ne = false;
@@ -1003,6 +1005,7 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
     c->resid.release(); c->flag.release(); c->keep.release(); c->small.release(); c->ne_partial.release();
     c->ticket.release(); c->icp_dev.release(); c->lm_dev.release(); c->resid2.release();
+    c->corr_pl.release();
     if (c->h_lm) (void)hipHostFree(c->h_lm);
     if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
@@ -1302,6 +1305,7 @@ SICP_EXPORT int sicp_icp_setup(sicp_ctx *c, const int64_t *sel_idx, int64_t Q, c
     HIPCHK(hipMemcpyAsync(c->normals.p, normals, (size_t)3 * Q * sizeof(float), hipMemcpyDefault, c->stream));
     HIPCHK(hipMemcpyAsync(c->planarity.p, planarity, (size_t)Q * sizeof(float), hipMemcpyDefault, c->stream));
     c->have_iter = false;
+    c->have_corr = false;
     c->have_prev_match = false;
     c->q_order_lo = -1; c->q_order_cnt = 0;
     return sync(c);
@@ -1343,6 +1347,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
     Cloud &cl = c->cloud[SICP_MOV];
     *done_out = 0;
     if (max_it <= 0) return SICP_OK;
+    c->have_corr = false;
     // the pruned exact search on the static grid serves every rigid H, i.e. every H(x) of the loop
     const bool grid = (c->knn1_mode == 0 || c->knn1_mode == 3) && cl.n < (1LL << 31);
     if (grid) CHK(grid_build(c, SICP_MOV));
@@ -1523,63 +1528,19 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
     return rc;
 }
 
-// ---- larger Q (or a sharded 6x6 reduction): multi-kernel tail, LM loop on the host ---------------------------
-int iterate_host_lm(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
+// ---- optimisation: optimization.py:65-124 as LM on fused 6x6 reductions over the rows of `keep`, from P->x ----
+// Expects R->dist_std (kept distances, for the automatic weight); fills the solver's part of R, the residuals at the
+// optimum (c->resid) and the state sicp_icp_uncertainties reads.
+int host_lm_solve(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
 {
-    std::memset(R, 0, sizeof *R);
     const long Q = c->Q;
-    c->resid_slot = 0;
     int nfree = 0, freeidx[6];
     for (int j = 0; j < 6; ++j)
         if (std::isfinite(P->obs_weight[j])) freeidx[nfree++] = j;
-    // ---- match: simpleicp.py:188-202, corrpts.py:124-137 (transform fused into the scan) ----
-    double H12[12];
-    params_to_H12(P->x, H12);
-    Xf X; for (int i = 0; i < 12; ++i) X.m[i] = H12[i];
-    CHK(knn1_device(c, SICP_MOV, c->q.p, Q, c->qpad, &X, std::numeric_limits<double>::infinity(),
-                    c->have_prev_match ? c->m_p2.p : nullptr, c->m_d2.p, c->m_idx.p, c->m_p2.p));
-    c->have_prev_match = true;              // (after an exchange: the job-wide winner's coordinates -- still a valid bound)
-    CHK(exchange_best(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
-    c->have_last_ne = false;
-    // ---- distances + rejections: corrpts.py:139-211 ----
-    launch_postmatch(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, c->m_p2.p,
-                     c->m_idx.p, Q, X, (float)P->min_planarity, c->cloud[SICP_MOV].pl_n > 0 ? c->cloud[SICP_MOV].pl.p : nullptr,
-                     c->cloud[SICP_MOV].pl_n, c->dist.p, c->flag.p);
-    double *h_st = c->h_small + 160;                      // pinned: [0..3] rejection, [4..6] n / mean / std, [15] ticket
-    double seq = (double)(++c->solve_seq);
-    {
-        Timed t(c, SICP_K_SELECT);
-        if (Q > REJECT_MAX_Q) {
-            // one workgroup cannot chew a million distances: exact order statistics by multi-workgroup digit selection,
-            // keep mask and kept-distance statistics in its last pass
-            CHK(c->rj_keys.reserve((reject_select_scratch_bytes() + 7) / 8));
-            CHK(c->ne_partial.reserve((size_t)NE_MAX_GRID * 64));
-            if (reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
-                                 (unsigned long long *)(c->small.p + 56), c->ne_partial.p, c->ticket.p, h_st, seq) != hipSuccess)
-                return fail(SICP_ERR_HIP, "rejection by digit selection failed");
-        } else {
-            launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p);
-            launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4, c->small.p, h_st, seq, c->ne_partial.p, c->ticket.p);
-        }
-    }
-    HIPCHK(hipGetLastError());
-    CHK(wait_ticket(c, h_st + 15, seq));
-    R->n_queries = Q;
-    R->n_planar = (int64_t)h_st[0];
-    R->median = h_st[1]; R->mad = h_st[2];
-    R->n_kept = (int64_t)h_st[3];
-    R->dist_mean = h_st[5]; R->dist_std = h_st[6];
-    c->have_iter = true;
-    std::memcpy(c->last_x, P->x, sizeof c->last_x);
-    if (R->n_kept < 6) {
-        std::memcpy(R->x, P->x, sizeof R->x);
-        return too_few((long long)R->n_kept);
-    }
+    double *h_st = c->h_small + 160;                      // pinned: [4..6] n / mean / std, [15] ticket
     double w = P->distance_weight;
     if (!(w > 0)) w = 1.0 / (R->dist_std * R->dist_std);   // simpleicp.py:233-234
     R->weight_used = w;
-
-    // ---- optimisation: optimization.py:65-124 as LM on fused 6x6 reductions ----
     const double *obs = P->obs, *ow = P->obs_weight;
     double x[6]; std::memcpy(x, P->x, sizeof x);
     double ne[30];
@@ -1630,7 +1591,7 @@ int iterate_host_lm(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
     // ---- residuals at the optimum (optimization.py:117-124) + their mean/std (simpleicp.py:356-379) ----
     CHK(normal_eq_host(c, x, true, false, ne)); R->ne_evals++;
     cost = objective(ne, w, x, obs, ow);
-    seq = (double)(++c->solve_seq);
+    const double seq = (double)(++c->solve_seq);
     launch_stats(c->stream, c->resid.p, c->keep.p, Q, c->small.p + 4, nullptr, h_st, seq, c->ne_partial.p, c->ticket.p);
     HIPCHK(hipGetLastError());
     CHK(wait_ticket(c, h_st + 15, seq));
@@ -1644,6 +1605,59 @@ int iterate_host_lm(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
     std::memcpy(c->last_obs, obs, sizeof c->last_obs);
     std::memcpy(c->last_ow, ow, sizeof c->last_ow);
     return SICP_OK;
+}
+
+// ---- larger Q (or a sharded 6x6 reduction): multi-kernel tail, LM loop on the host ---------------------------
+int iterate_host_lm(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
+{
+    std::memset(R, 0, sizeof *R);
+    const long Q = c->Q;
+    c->resid_slot = 0;
+    c->have_corr = false;
+    // ---- match: simpleicp.py:188-202, corrpts.py:124-137 (transform fused into the scan) ----
+    double H12[12];
+    params_to_H12(P->x, H12);
+    Xf X; for (int i = 0; i < 12; ++i) X.m[i] = H12[i];
+    CHK(knn1_device(c, SICP_MOV, c->q.p, Q, c->qpad, &X, std::numeric_limits<double>::infinity(),
+                    c->have_prev_match ? c->m_p2.p : nullptr, c->m_d2.p, c->m_idx.p, c->m_p2.p));
+    c->have_prev_match = true;              // (after an exchange: the job-wide winner's coordinates -- still a valid bound)
+    CHK(exchange_best(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
+    c->have_last_ne = false;
+    // ---- distances + rejections: corrpts.py:139-211 ----
+    launch_postmatch(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, c->m_p2.p,
+                     c->m_idx.p, Q, X, (float)P->min_planarity, c->cloud[SICP_MOV].pl_n > 0 ? c->cloud[SICP_MOV].pl.p : nullptr,
+                     c->cloud[SICP_MOV].pl_n, c->dist.p, c->flag.p);
+    double *h_st = c->h_small + 160;                      // pinned: [0..3] rejection, [4..6] n / mean / std, [15] ticket
+    double seq = (double)(++c->solve_seq);
+    {
+        Timed t(c, SICP_K_SELECT);
+        if (Q > REJECT_MAX_Q) {
+            // one workgroup cannot chew a million distances: exact order statistics by multi-workgroup digit selection,
+            // keep mask and kept-distance statistics in its last pass
+            CHK(c->rj_keys.reserve((reject_select_scratch_bytes() + 7) / 8));
+            CHK(c->ne_partial.reserve((size_t)NE_MAX_GRID * 64));
+            if (reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
+                                 (unsigned long long *)(c->small.p + 56), c->ne_partial.p, c->ticket.p, h_st, seq) != hipSuccess)
+                return fail(SICP_ERR_HIP, "rejection by digit selection failed");
+        } else {
+            launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p);
+            launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4, c->small.p, h_st, seq, c->ne_partial.p, c->ticket.p);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    CHK(wait_ticket(c, h_st + 15, seq));
+    R->n_queries = Q;
+    R->n_planar = (int64_t)h_st[0];
+    R->median = h_st[1]; R->mad = h_st[2];
+    R->n_kept = (int64_t)h_st[3];
+    R->dist_mean = h_st[5]; R->dist_std = h_st[6];
+    c->have_iter = true;
+    std::memcpy(c->last_x, P->x, sizeof c->last_x);
+    if (R->n_kept < 6) {
+        std::memcpy(R->x, P->x, sizeof R->x);
+        return too_few((long long)R->n_kept);
+    }
+    return host_lm_solve(c, P, R);
 }
 
 }  // namespace
@@ -1694,7 +1708,7 @@ SICP_EXPORT int sicp_icp_run(sicp_ctx *c, const sicp_iter_params *P0, int64_t ma
 SICP_EXPORT int sicp_icp_get_state(sicp_ctx *c, int64_t *pc2_idx, double *dist, uint8_t *keep, double *residual)
 {
     if (!c) return fail(SICP_ERR_INVALID, "null ctx");
-    if (!c->have_iter) return fail(SICP_ERR_INVALID, "no iteration has run yet");
+    if (!c->have_iter && !c->have_corr) return fail(SICP_ERR_INVALID, "no iteration has run yet");
     HIPCHK(hipSetDevice(c->device));
     const size_t Q = (size_t)c->Q;
     if (pc2_idx) HIPCHK(hipMemcpyAsync(pc2_idx, c->m_idx.p, Q * sizeof(int64_t), hipMemcpyDefault, c->stream));
@@ -1736,6 +1750,140 @@ SICP_EXPORT int sicp_icp_uncertainties(sicp_ctx *c, double sigma_out[6])
         if (!spd_solve(m, A, b)) return fail(SICP_ERR_NUMERIC, "normal matrix is not positive definite");
         sigma_out[freeidx[u]] = std::sqrt(s02 * b[u]);
     }
+    return SICP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// The iteration's operators one by one (CorrPts / SimpleICPOptimization as the reference's callers drive them,
+// simpleicp.py:190-227): the kernels of the multi-kernel iteration behind separate entry points.  The alive mask of
+// the correspondences lives in `keep`.
+namespace {
+
+int check_corr(sicp_ctx *c)
+{
+    if (!c) return fail(SICP_ERR_INVALID, "null ctx");
+    if (!c->have_corr) return fail(SICP_ERR_INVALID, "call sicp_corr_match first");
+    return SICP_OK;
+}
+
+// count / mean / std of the alive correspondences' distances -> pinned h_st[4..6] (and the rejection's out4 -> h_st[0..3])
+int corr_alive_stats(sicp_ctx *c, const double *also4, double **h_st_out)
+{
+    double *h_st = c->h_small + 160;
+    const double seq = (double)(++c->solve_seq);
+    launch_stats(c->stream, c->dist.p, c->keep.p, c->Q, c->small.p + 4, also4, h_st, seq, c->ne_partial.p, c->ticket.p);
+    HIPCHK(hipGetLastError());
+    CHK(wait_ticket(c, h_st + 15, seq));
+    *h_st_out = h_st;
+    return SICP_OK;
+}
+
+}  // namespace
+
+SICP_EXPORT int sicp_corr_match(sicp_ctx *c, const double *H, int64_t *pc2_idx_out, double *dist_out)
+{
+    if (!c) return fail(SICP_ERR_INVALID, "null ctx");
+    if (c->Q <= 0) return fail(SICP_ERR_INVALID, "call sicp_icp_setup first");
+    CHK(check_slot(c, SICP_MOV, true));
+    HIPCHK(hipSetDevice(c->device));
+    const long Q = c->Q;
+    Xf X = {{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}};           // identity: contract (T) then returns the coordinates unchanged
+    if (H) H16_to_Xf(H, &X);
+    c->have_corr = false;
+    CHK(knn1_device(c, SICP_MOV, c->q.p, Q, c->qpad, &X, std::numeric_limits<double>::infinity(),
+                    c->have_prev_match ? c->m_p2.p : nullptr, c->m_d2.p, c->m_idx.p, c->m_p2.p));
+    c->have_prev_match = true;
+    CHK(exchange_best(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
+    c->have_last_ne = false;
+    c->have_iter = false;                                     // no estimate belongs to these correspondences yet
+    c->resid_slot = 0;
+    // distances (contract (P)); the flags of this launch are not used: nothing is rejected yet
+    launch_postmatch(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, c->m_p2.p,
+                     c->m_idx.p, Q, X, -std::numeric_limits<float>::infinity(), nullptr, 0, c->dist.p, c->flag.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(c->keep.p, 1, (size_t)Q, c->stream));
+    HIPCHK(hipMemsetAsync(c->resid.p, 0, (size_t)Q * sizeof(double), c->stream));
+    if (pc2_idx_out) HIPCHK(hipMemcpyAsync(pc2_idx_out, c->m_idx.p, (size_t)Q * sizeof(int64_t), hipMemcpyDefault, c->stream));
+    if (dist_out) HIPCHK(hipMemcpyAsync(dist_out, c->dist.p, (size_t)Q * sizeof(double), hipMemcpyDefault, c->stream));
+    CHK(sync(c));
+    c->have_corr = true;
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_corr_reject_planarity(sicp_ctx *c, double min_planarity, const float *pc1_planarity,
+                                           const float *pc2_planarity, int64_t *n_alive_out)
+{
+    CHK(check_corr(c));
+    if (std::isnan(min_planarity)) return fail(SICP_ERR_INVALID, "min_planarity is NaN");
+    HIPCHK(hipSetDevice(c->device));
+    const long Q = c->Q;
+    CHK(c->corr_pl.reserve((size_t)2 * Q));
+    float *d1 = pc1_planarity ? c->corr_pl.p : nullptr, *d2 = pc2_planarity ? c->corr_pl.p + Q : nullptr;
+    if (d1) HIPCHK(hipMemcpyAsync(d1, pc1_planarity, (size_t)Q * sizeof(float), hipMemcpyDefault, c->stream));
+    if (d2) HIPCHK(hipMemcpyAsync(d2, pc2_planarity, (size_t)Q * sizeof(float), hipMemcpyDefault, c->stream));
+    launch_corr_planarity(c->stream, c->keep.p, d1, d2, (float)min_planarity, Q);
+    HIPCHK(hipGetLastError());
+    double *h_st;
+    CHK(corr_alive_stats(c, nullptr, &h_st));
+    if (n_alive_out) *n_alive_out = (int64_t)h_st[4];
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_corr_reject_distances(sicp_ctx *c, double *median_out, double *mad_out, int64_t *n_alive_out)
+{
+    CHK(check_corr(c));
+    HIPCHK(hipSetDevice(c->device));
+    const long Q = c->Q;
+    // the selection kernels read the candidates' mask and write the survivors' into distinct buffers
+    HIPCHK(hipMemcpyAsync(c->flag.p, c->keep.p, (size_t)Q, hipMemcpyDeviceToDevice, c->stream));
+    double *h_st = c->h_small + 160;
+    {
+        Timed t(c, SICP_K_SELECT);
+        if (Q > REJECT_MAX_Q) {
+            const double seq = (double)(++c->solve_seq);
+            CHK(c->rj_keys.reserve((reject_select_scratch_bytes() + 7) / 8));
+            if (reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
+                                 (unsigned long long *)(c->small.p + 56), c->ne_partial.p, c->ticket.p, h_st, seq) != hipSuccess)
+                return fail(SICP_ERR_HIP, "rejection by digit selection failed");
+            HIPCHK(hipGetLastError());
+            CHK(wait_ticket(c, h_st + 15, seq));
+        } else {
+            launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p);
+            CHK(corr_alive_stats(c, c->small.p, &h_st));
+        }
+    }
+    if (median_out) *median_out = h_st[1];
+    if (mad_out) *mad_out = h_st[2];
+    if (n_alive_out) *n_alive_out = (int64_t)h_st[3];
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_estimate_parameters(sicp_ctx *c, const sicp_iter_params *P, const double *pc2_xyz, sicp_iter_result *R)
+{
+    if (!P || !R) return fail(SICP_ERR_INVALID, "null argument");
+    CHK(check_corr(c));
+    for (int j = 0; j < 6; ++j)
+        if (std::isnan(P->obs_weight[j]) || P->obs_weight[j] < 0) return fail(SICP_ERR_INVALID, "obs_weight[%d] must be >= 0", j);
+    HIPCHK(hipSetDevice(c->device));
+    const long Q = c->Q;
+    std::memset(R, 0, sizeof *R);
+    if (pc2_xyz) {
+        HIPCHK(hipMemcpyAsync(c->m_p2.p, pc2_xyz, (size_t)3 * Q * sizeof(double), hipMemcpyDefault, c->stream));
+        c->have_prev_match = false;                           // no longer points of the searched cloud: not a search bound
+    }
+    double *h_st;
+    CHK(corr_alive_stats(c, nullptr, &h_st));
+    R->n_queries = Q;
+    R->n_kept = (int64_t)h_st[4];
+    R->n_planar = R->n_kept;
+    R->median = R->mad = std::numeric_limits<double>::quiet_NaN();
+    R->dist_mean = h_st[5]; R->dist_std = h_st[6];
+    c->resid_slot = 0;
+    c->have_last_ne = false;
+    std::memcpy(R->x, P->x, sizeof R->x);
+    if (R->n_kept < 6) return too_few((long long)R->n_kept);
+    CHK(host_lm_solve(c, P, R));
+    c->have_iter = true;
     return SICP_OK;
 }
 

@@ -23,6 +23,7 @@ constexpr long   STATS_MB_MIN_Q = 16384;  // above: mean / std over many workgro
 
 constexpr int SOLVE_MAX_Q = 2048;   // single-launch tail (sicp_tail.hip): 8 staged Jacobian columns x 2048 x 8 B = 128 KiB of LDS
 void launch_fill_f32(hipStream_t s, float *dst, long n, float v);
+void launch_corr_planarity(hipStream_t s, uint8_t *alive, const float *pl1, const float *pl2, float min_planarity, long Q);
 void launch_scatter_f32(hipStream_t s, float *dst, const int64_t *rows, const float *vals, long m);
 
 // ---- device-chained iteration loop (sicp_tail.hip) ----

@@ -834,6 +834,20 @@ __global__ void k_postmatch(const double *__restrict__ qx, const double *__restr
     flag[q] = f ? 1 : 0;
 }
 
+// CorrPts.reject_wrt_planarity as an operator of its own (corrpts.py:139-163): a correspondence stays alive when the
+// planarity of its point in pc1 -- and in pc2, iff that cloud has the column -- reaches the threshold (NaN fails).
+// pl1 / pl2 are per CORRESPONDENCE (the reference's `pc.iloc[idx]["planarity"]`); a null column is not tested.
+__global__ void k_corr_planarity(uint8_t *__restrict__ alive, const float *__restrict__ pl1, const float *__restrict__ pl2,
+                                 float min_planarity, long Q)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    bool f = alive[q] != 0;
+    if (f && pl1) f = pl1[q] >= min_planarity;
+    if (f && pl2) f = pl2[q] >= min_planarity;
+    alive[q] = f ? 1 : 0;
+}
+
 __global__ void k_fill_f32(float *__restrict__ dst, long n, float v)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1569,6 +1583,11 @@ void launch_postmatch(hipStream_t s, const double *qx, const double *qy, const d
 {
     hipLaunchKernelGGL(k_postmatch, dim3(cdiv(Q, 256)), dim3(256), 0, s, qx, qy, qz, normals, planarity, p2, idx, Q, H,
                        min_planarity, pl2, pl2_n, dist, flag, st);
+}
+
+void launch_corr_planarity(hipStream_t s, uint8_t *alive, const float *pl1, const float *pl2, float min_planarity, long Q)
+{
+    if (Q > 0) hipLaunchKernelGGL(k_corr_planarity, dim3(cdiv(Q, 256)), dim3(256), 0, s, alive, pl1, pl2, min_planarity, Q);
 }
 
 void launch_fill_f32(hipStream_t s, float *dst, long n, float v)

@@ -87,6 +87,7 @@ class SimpleICP:
         t_start = time.time()
         pc1, pc2 = self.pc1, self.pc2
         ctx = backend.get_context()
+        ctx._corr_owner = None            # (an operator-level CorrPts object loses the device state to this run)
         import os
         sharded = dist.is_distributed() or (os.environ.get("SICP_FORCE_EXCHANGE") == "1" and dist.is_initialized())
 

@@ -1,0 +1,83 @@
+"""Host logic of the Python mirror without a GPU: ``SimpleICP.run``'s orchestration / log / side effects and the
+bookkeeping of ``CorrPts`` / ``SimpleICPOptimization`` run against tests/oracle_backend.py (a stand-in context that
+answers with the CPU oracle) and are held against the fixtures of the unmodified reference.  What is under test here is
+simpleicp_amd/{icp,pointcloud,corrpts,optimization}.py; the kernels are checked by the ``-m gpu`` tests, which run the
+same flows (tests/operator_flow.py) on the real library."""
+import logging
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import operator_flow as flow
+import oracle_backend
+from conftest import load_golden
+
+
+@pytest.fixture
+def ctx(monkeypatch):
+    return oracle_backend.install(monkeypatch)
+
+
+@pytest.mark.parametrize("name", ["dragon", "bunny_obs", "dragon_chain"])
+def test_reference_loop_with_mirror_classes(ctx, name, clouds):
+    flow.reference_loop(name, clouds)
+    # one match / two rejections / one estimate per iteration went to the backend, nothing was computed on the side
+    g, _, _ = load_golden(name)
+    for op in ("corr_match", "corr_reject_distances", "estimate_parameters"):
+        assert ctx.calls.count(op) == int(g["iterations"])
+
+
+def test_corrpts_bookkeeping(ctx, clouds, tmp_path):
+    flow.corrpts_object_semantics(clouds, tmp_path)
+
+
+def test_backend_stand_in_agrees_with_itself(ctx):
+    """(keeps the stand-in honest: its operator-level answers equal its fused iteration's)"""
+    flow.abi_operators_vs_oracle(oracle_backend.OracleContext, 300, n=5000)
+    flow.rejections_commute(oracle_backend.OracleContext, n=4000)
+
+
+@pytest.mark.parametrize("name", ["dragon", "bunny"])
+def test_run_orchestration_on_the_stand_in(ctx, name, clouds):
+    """SimpleICP.run end to end (overlap pre-pass, selection, normals, loop, final transform): the reference's H,
+    iteration count, log lines and side effects -- host logic only, the numbers come from the oracle."""
+    from simpleicp_amd import PointCloud, SimpleICP
+    g, files, kw = load_golden(name)
+    pc_fix = PointCloud(clouds(files[0]), columns=["x", "y", "z"])
+    pc_mov = PointCloud(clouds(files[1]).copy(), columns=["x", "y", "z"])
+    sel = g["sel_idx"]
+    for j, c in enumerate(("nx", "ny", "nz", "planarity")):
+        v = np.full(len(pc_fix), np.nan, np.float32)
+        v[sel] = g["planarity"] if c == "planarity" else g["normals"][:, j]
+        pc_fix[c] = pd.arrays.SparseArray(v)
+    records = []
+    handler = logging.Handler()
+    handler.emit = lambda r: records.append(r.getMessage())
+    log = logging.getLogger("simpleicp_amd")
+    log.addHandler(handler)
+    old = log.level
+    log.setLevel(logging.INFO)
+    try:
+        icp = SimpleICP(verbose=False)
+        icp.add_point_clouds(pc_fix, pc_mov)
+        X0 = pc_mov.X
+        H, X, rbp, res = icp.run(**kw)
+    finally:
+        log.removeHandler(handler)
+        log.setLevel(old)
+    assert np.abs(H - g["H"]).max() < 1e-7
+    assert icp.last_run_info["iterations"] == int(g["iterations"])
+    assert np.abs(np.array([s[0] for s in icp.last_run_info["stats"]]) - g["counts"]).max() <= 2
+    assert np.array_equal(pc_fix.idx_selected, sel)                       # selection left at the sub-sample (simpleicp.py:254)
+    assert np.array_equal(X, pc_mov.X) and not np.array_equal(X, X0)      # movable cloud transformed in place (simpleicp.py:316)
+    assert np.abs(X[:64] - g["X_mov_transformed_head"]).max() < 1e-5
+    assert abs(len(res) - len(g["residuals"])) <= 2
+    # normals were injected (the reference's own bypass, simpleicp.py:176), so its "Estimate normals ..." line is not due
+    theirs = [m for m in str(g["log"]).splitlines() if not m.startswith(("Finished in", "Estimate normals"))]
+    mine = [m for m in records if not m.startswith("Finished in")]
+    assert len(mine) == len(theirs)
+    assert sum(a == b for a, b in zip(mine, theirs)) >= len(theirs) - 4          # a count can differ by one on a tie flip
+    assert [m for m in mine if "|" not in m and "[" not in m] == [m for m in theirs if "|" not in m and "[" not in m]
+    assert records[-1].startswith("Finished in ") and records[-1].endswith(" seconds!")
+    assert "icp_run" in ctx.calls and ctx.calls.count("upload") >= 2
