@@ -82,7 +82,25 @@ int main(int argc, char **argv)
            (long long)R[its - 1].n_kept, R[its - 1].res_std);
     printf("x = %.6f %.6f %.6f %.5f %.5f %.5f   max |x - x_true| = %.2e\n", R[its - 1].x[0], R[its - 1].x[1], R[its - 1].x[2],
            R[its - 1].x[3], R[its - 1].x[4], R[its - 1].x[5], err);
+
+    /* The same iterations operator by operator, the way the reference's own loop drives its classes (simpleicp.py:190-227):
+     * CorrPts.match, .reject_wrt_planarity, .reject_wrt_point_to_plane_distances, SimpleICPOptimization.estimate_parameters. */
+    sicp_iter_params Po = P;
+    sicp_iter_result Ro;
+    int64_t alive = 0;
+    for (int64_t it = 0; it < its; ++it) {
+        double Hx[16], median, mad;
+        CHECK(sicp_params_to_H(Po.x, Hx));
+        CHECK(sicp_corr_match(ctx, Hx, NULL, NULL));
+        CHECK(sicp_corr_reject_planarity(ctx, P.min_planarity, planarity, NULL, &alive));
+        CHECK(sicp_corr_reject_distances(ctx, &median, &mad, &alive));
+        CHECK(sicp_estimate_parameters(ctx, &Po, NULL, &Ro));
+        for (int j = 0; j < 6; ++j) Po.x[j] = Ro.x[j];
+    }
+    double diff = 0.0;
+    for (int j = 0; j < 6; ++j) diff = fmax(diff, fabs(Ro.x[j] - R[its - 1].x[j]));
+    printf("operator by operator: %lld alive in the last iteration, max |x - x_run| = %.2e\n", (long long)alive, diff);
     sicp_ctx_destroy(ctx);
     free(fix); free(mov); free(sel); free(normals); free(planarity);
-    return err < 5e-3 ? 0 : 1;
+    return (err < 5e-3 && diff < 1e-6 && llabs((long long)(alive - R[its - 1].n_kept)) <= 2) ? 0 : 1;
 }

@@ -81,3 +81,57 @@ def test_run_orchestration_on_the_stand_in(ctx, name, clouds):
     assert [m for m in mine if "|" not in m and "[" not in m] == [m for m in theirs if "|" not in m and "[" not in m]
     assert records[-1].startswith("Finished in ") and records[-1].endswith(" seconds!")
     assert "icp_run" in ctx.calls and ctx.calls.count("upload") >= 2
+
+
+def _small_pair(clouds, n=4000):
+    from simpleicp_amd import PointCloud
+    X1, X2 = clouds("bunny_part1")[:n], clouds("bunny_part2")[:n]
+    return PointCloud(X1, columns=["x", "y", "z"]), PointCloud(X2.copy(), columns=["x", "y", "z"])
+
+
+def test_run_debug_dumps_and_iterate_path(ctx, clouds, tmp_path):
+    """debug_dirpath (simpleicp.py:140-142,193-203,222-227,317-321): the loop then runs iteration by iteration
+    (sicp_icp_iterate) and writes the reference's files under the reference's names."""
+    from simpleicp_amd import SimpleICP
+    pc_fix, pc_mov = _small_pair(clouds)
+    icp = SimpleICP(verbose=False)
+    icp.add_point_clouds(pc_fix, pc_mov)
+    out = tmp_path / "dbg" / "nested"
+    H, X, rbp, res = icp.run(correspondences=300, max_iterations=2, min_change=0.0, debug_dirpath=str(out))
+    names = sorted(p.name for p in out.iterdir())
+    assert names == ["iteration000_preoptim_correspondences.xyz", "iteration000_preoptim_pcfix.xyz",
+                     "iteration000_preoptim_pcmov.xyz", "iteration001_postoptim_pcmov.xyz",
+                     "iteration001_preoptim_correspondences.xyz", "iteration001_preoptim_pcmov.xyz"]
+    assert ctx.calls.count("icp_iterate") == 2 and "icp_run" not in ctx.calls
+    corr = np.loadtxt(out / "iteration001_preoptim_correspondences.xyz", comments="//")
+    assert corr.shape[1] == 7 and 6 <= len(corr) <= 300
+    # column 7 is the point-to-plane distance of the row's two points along pc1's normal: recompute it from the frame
+    sel = pc_fix.idx_selected
+    p1 = pc_fix.X[sel]
+    row = {tuple(p): i for i, p in enumerate(np.round(p1, 12))}
+    at = np.array([row[tuple(p)] for p in np.round(corr[:, :3], 12)])
+    nv = np.column_stack([np.asarray(pc_fix[c].to_numpy(), dtype=np.float64)[sel][at] for c in ("nx", "ny", "nz")])
+    d = np.sum((corr[:, 3:6] - corr[:, :3]) * nv, axis=1)
+    assert np.abs(d - corr[:, 6]).max() < 1e-12
+    post = np.loadtxt(out / "iteration001_postoptim_pcmov.xyz", comments="//")
+    assert post.shape == X.shape and np.abs(post - X).max() <= 5.01e-4          # "%.3f"
+    assert (out / "iteration000_preoptim_pcfix.xyz").read_text().splitlines()[0] == "//X Y Z"
+
+
+def test_run_exceptions_on_the_stand_in(ctx, clouds):
+    """Messages of simpleicp.py:165-170,209-214 reach the caller as SimpleICPException from either loop flavour."""
+    from simpleicp_amd import PointCloud, SimpleICP, SimpleICPException
+    pc_fix, pc_mov = _small_pair(clouds)
+    icp = SimpleICP(verbose=False)
+    icp.add_point_clouds(pc_fix, pc_mov)
+    with pytest.raises(SimpleICPException, match=r"Too few correspondences! .* number of correspondences is 0\."):
+        icp.run(correspondences=200, min_planarity=2.0)
+    far = PointCloud(pc_mov.X + 1000.0, columns=["x", "y", "z"])
+    icp.add_point_clouds(pc_fix, far)
+    with pytest.raises(SimpleICPException, match="do not overlap within max_overlap_distance = 0.50000"):
+        icp.run(max_overlap_distance=0.5)
+    # automatic distance weight (simpleicp.py:229-234): frozen after the first iteration
+    pc_fix, pc_mov = _small_pair(clouds)
+    icp.add_point_clouds(pc_fix, pc_mov)
+    H, X, rbp, res = icp.run(correspondences=300, max_iterations=3, distance_weights=None)
+    assert np.isfinite(H).all() and len(res) >= 6
