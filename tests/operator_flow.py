@@ -157,7 +157,7 @@ def abi_operators_vs_oracle(make_ctx, Q, n=60_000):
         F = ctx.icp_iterate(x0, z, z, 0.3, None)
         fidx, fdist, fkeep, _ = ctx.icp_state()
         assert np.array_equal(fidx, idx) and np.array_equal(fdist, dist) and np.array_equal(fkeep, alive)
-        assert F.median == med and F.mad == mad and np.abs(np.array(F.x[:]) - x).max() < 1e-9
+        assert F.median == med and F.mad == mad and np.abs(np.array(F.x[:]) - x).max() < 2e-9      # (each within 1e-9 of the oracle)
         # ... after which the operators have no correspondences of their own any more
         with pytest.raises(_lib.BackendError):
             ctx.corr_reject_distances()
