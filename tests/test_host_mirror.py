@@ -135,3 +135,16 @@ def test_run_exceptions_on_the_stand_in(ctx, clouds):
     icp.add_point_clouds(pc_fix, pc_mov)
     H, X, rbp, res = icp.run(correspondences=300, max_iterations=3, distance_weights=None)
     assert np.isfinite(H).all() and len(res) >= 6
+
+
+@pytest.mark.parametrize("dataset", ["Bunny", "Multisensor"])
+def test_reference_test_module_on_the_stand_in(ctx, dataset, clouds, tmp_path):
+    """tests/test_reference_suite.py (the reference's own test module, package name swapped) -- here with the stand-in
+    context: .xyz round trip through the native reader / writer, debug dumps, fixed and observed parameters."""
+    import test_reference_suite as suite
+    for case in suite.test_simpleicp.pytestmark[0].args[1]:
+        if case[0] == dataset:
+            suite.test_simpleicp(*case, clouds, tmp_path)
+            assert ctx.calls.count("icp_iterate") >= 2 and "icp_run" not in ctx.calls
+            return
+    raise AssertionError(dataset)
