@@ -148,3 +148,23 @@ def test_reference_test_module_on_the_stand_in(ctx, dataset, clouds, tmp_path):
             assert ctx.calls.count("icp_iterate") >= 2 and "icp_run" not in ctx.calls
             return
     raise AssertionError(dataset)
+
+
+def test_cli_in_process_on_the_stand_in(ctx, clouds, tmp_path, capsys):
+    """python -m simpleicp_amd (cli.main) end to end: .xyz in, the README's H line out (python/README.md:62), the
+    transformed cloud written; a missing file and a failed run come back as exit code 1 with the reference CLI's text."""
+    from simpleicp_amd import cli, io
+    g, files, kw = load_golden("bunny")
+    io.write_xyz(tmp_path / "f.xyz", clouds(files[0]), decimals=4, header=None)
+    io.write_xyz(tmp_path / "m.xyz", clouds(files[1]), decimals=4, header=None)
+    rc = cli.main(["-f", str(tmp_path / "f.xyz"), "-m", str(tmp_path / "m.xyz"), "-o", "1", "--quiet",
+                   "--output", str(tmp_path / "out.xyz")])
+    out = capsys.readouterr().out.splitlines()
+    assert rc == 0 and len(out) == 4
+    Hq = np.array([[float(v) for v in row.split()] for row in out])
+    assert np.abs(Hq - g["H"]).max() < 1e-4 and out[3].split() == ["0.000000000", "0.000000000", "0.000000000", "1.000000000"]
+    assert io.read_xyz(tmp_path / "out.xyz").shape == clouds(files[1]).shape
+    assert cli.main(["-f", str(tmp_path / "nope.xyz"), "-m", str(tmp_path / "m.xyz"), "--quiet"]) == 1
+    assert "Caught exception:" in capsys.readouterr().err
+    assert cli.main(["-f", str(tmp_path / "f.xyz"), "-m", str(tmp_path / "m.xyz"), "-p", "2", "--quiet"]) == 1
+    assert "Too few correspondences" in capsys.readouterr().err
