@@ -168,3 +168,36 @@ def test_cli_in_process_on_the_stand_in(ctx, clouds, tmp_path, capsys):
     assert "Caught exception:" in capsys.readouterr().err
     assert cli.main(["-f", str(tmp_path / "f.xyz"), "-m", str(tmp_path / "m.xyz"), "-p", "2", "--quiet"]) == 1
     assert "Too few correspondences" in capsys.readouterr().err
+
+
+def test_pointcloud_operators_on_the_stand_in(ctx, clouds):
+    """The PointCloud mirror's own operators as a caller uses them (pointcloud.py:132-217): the overlap pre-pass +
+    sub-sampling reproduce the reference's selection, estimate_normals leaves the reference's column layout, the
+    transform is contract (T)."""
+    from oracle import orc
+    from simpleicp_amd import PointCloud
+    g, files, kw = load_golden("bunny")
+    X_fix, X_mov = clouds(files[0]), clouds(files[1])
+    pc = PointCloud(X_fix, columns=["x", "y", "z"])
+    pc.select_in_range(X_mov, max_range=kw["max_overlap_distance"])        # simpleicp.py:161-163 with H0 = identity
+    assert 0 < pc.num_selected_points < pc.num_points
+    pc.select_n_points(1000)
+    assert np.array_equal(pc.idx_selected, g["sel_idx"])
+    pc.estimate_normals(10)
+    sel = pc.idx_selected
+    nn, _ = orc.knn(X_fix, X_fix[sel], k=10)
+    nv, pl = orc.normals(X_fix, nn)
+    for j, c in enumerate(("nx", "ny", "nz")):
+        assert str(pc[c].dtype) == "Sparse[float32, nan]"
+        dense = pc[c].to_numpy()
+        assert np.array_equal(dense[sel], nv[:, j]) and np.isnan(np.delete(dense, sel)).all()
+    assert np.array_equal(pc["planarity"].to_numpy()[sel], pl)
+    # empty selection: nothing to do, nothing breaks (the reference's loops are empty then)
+    pc.unselect_all_points()
+    pc.select_in_range(X_mov, max_range=1.0)
+    assert pc.num_selected_points == 0
+    pc.select_all_points()
+    Hm = orc.params_to_H(np.array([0.1, 0.2, 0.3, 1, 2, 3]))
+    pc.transform_by_H(Hm)
+    assert np.array_equal(pc.X, orc.transform(Hm, X_fix))
+    assert pc["x"].to_numpy().flags.c_contiguous and np.array_equal(pc.x, pc.X[:, 0])
