@@ -376,6 +376,8 @@ def run(args):
         "kernels_instrumented": {name: {"avg_ms": avg[name], "launches": timing[name]["launches"]} for name in timing},
         "gpu_ms_per_step_instrumented": match_ms + solve_total + select_ms,
         "setup": {**setup, "normals_knn_kernel_ms": knnk["ms"],
+                  # the normals' k-NN as Q * k neighbours per second of its search kernel
+                  "normals_knn_neighbours_per_s": (nq * k / (knnk["ms"] * 1e-3)) if knnk["ms"] > 0 else None,
                   "note": "once per run(), outside `value`: host->HBM upload of both clouds (pageable memory), "
                           "estimate_normals for the Q selected points (with the fixed cloud's grid), the movable cloud's grid"},
         "solver": {"normal_eq_evaluations_per_iteration": evals_per_it, "final_n_kept": int(last.n_kept),
