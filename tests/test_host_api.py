@@ -237,3 +237,24 @@ def test_c_host_runs_an_icp(tmp_path):
     exe = _build_c_demo(tmp_path)
     r = subprocess.run([str(exe), "200000", "1000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "max |x - x_true|" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_every_export_refuses_null_arguments():
+    """'Nothing throws across the ABI' includes not crashing: every entry point called with a NULL context / NULL
+    pointers returns a negative code and leaves a message (sicp_ctx_destroy(NULL) is a no-op, like free)."""
+    import subprocess
+    from simpleicp_amd import _lib
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "helpers" / "null_abi_probe.py")], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    seen = {}
+    for line in r.stdout.splitlines():
+        name, rc, *msg = line.split(" ", 2)
+        seen[name] = (int(rc), msg[0] if msg else "")
+    expected = [n for n in _lib.EXPORTS if n not in ("sicp_abi_version", "sicp_last_error")]
+    assert sorted(seen) == sorted(expected)
+    for name, (rc, msg) in seen.items():
+        if name == "sicp_ctx_destroy":
+            assert rc == 0
+        else:
+            assert rc == _lib.ERR_INVALID and msg, (name, rc, msg)
