@@ -57,6 +57,11 @@ def abi_errors():
     x = np.array([0.1, -0.2, 0.3, 1.0, 2.0, 3.0])
     assert L.sicp_params_to_H(x.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p)) == 0
     assert abs(np.linalg.det(H.reshape(4, 4)[:3, :3]) - 1) < 1e-14
+    # every export with a NULL context / NULL pointers: a code and a message, never a wild access
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "helpers"))
+    import null_abi_probe
+    for name, (rc, msg) in null_abi_probe.probe().items():
+        assert (rc == 0 and name == "sicp_ctx_destroy") or (rc < 0 and msg), (name, rc, msg)
     n = C.c_int(-1)
     L.sicp_device_count(C.byref(n))
     return n.value
@@ -77,6 +82,30 @@ def gpu_run():
         assert np.abs(Xt - X).max() < 0.1 and len(res) > 100
 
 
+def gpu_operators():
+    """the operator-by-operator road (sicp_corr_* / sicp_estimate_parameters behind the mirror classes) under the sanitizers"""
+    from simpleicp_amd import PointCloud
+    from simpleicp_amd.corrpts import CorrPts
+    from simpleicp_amd.optimization import SimpleICPOptimization
+    rng = np.random.default_rng(2)
+    for n, q in ((30_000, 800), (90_000, 20_000)):               # single-workgroup and multi-workgroup selection
+        xy = rng.uniform(-30, 30, (n, 2))
+        X = np.column_stack((xy, 2 * np.sin(xy[:, 0] / 5) * np.cos(xy[:, 1] / 7)))
+        pc_fix = PointCloud(X, columns=["x", "y", "z"])
+        pc_mov = PointCloud(X + [0.05, -0.03, 0.02] + rng.normal(0, 0.004, X.shape), columns=["x", "y", "z"])
+        pc_fix.select_n_points(q)
+        pc_fix.estimate_normals(10)
+        cp = CorrPts(pc_fix, pc_mov)
+        cp.match()
+        cp.reject_wrt_planarity(0.3)
+        cp.reject_wrt_point_to_plane_distances()
+        optim = SimpleICPOptimization(cp, None, (0.,) * 6, (0.,) * 6, (0., 0., np.inf, 0., 0., 1.0))
+        res = optim.estimate_parameters()
+        optim.estimate_parameter_uncertainties()
+        x = np.array(optim.rbp.get_parameter_attributes_as_list("estimated_value"))
+        assert len(res) == cp.num_corr_pts > 100 and x[2] == 0.0 and abs(x[3] + 0.05) < 0.01, x
+
+
 if __name__ == "__main__":
     with tempfile.TemporaryDirectory() as d:
         io_round_trips(Path(d))
@@ -84,5 +113,6 @@ if __name__ == "__main__":
     if "--gpu" in sys.argv:
         assert devices > 0
         gpu_run()
+        gpu_operators()
     print("asan exercise OK", "(with device run)" if "--gpu" in sys.argv else "", flush=True)
     os._exit(0)     # skip interpreter teardown: numpy/pandas extension destructors are not what is under test
