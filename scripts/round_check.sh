@@ -18,5 +18,7 @@ timeout ${T_BENCH:-240} python bench.py --out "$OUT/bench_C4.json" > "$OUT/bench
 stamp "bench rc=$?"
 timeout ${T_OPCOST:-120} python scripts/operator_cost.py > "$OUT/operator_cost.txt" 2>&1
 stamp "operator cost rc=$?"
+SICP_HOST_TRACE=1 timeout 120 python scripts/trace_c4.py 2>&1 | grep -E "\[host\]|iterations:" | tail -26 > "$OUT/host_enqueue.txt"
+stamp "host enqueue trace rc=$?"
 tail -3 "$OUT/ops.log"; tail -3 "$OUT/suite.log"; cat "$OUT/steps.log"
 cat "$OUT/operator_cost.txt"

@@ -162,16 +162,27 @@ def test_two_ranks_sharing_one_gpu_agree_with_one_rank(tmp_path):
         assert int(z["gn_it"]) == it and np.abs(z["gn_H"] - H).max() < 1e-9
 
 
-@pytest.mark.parametrize("partition", ["cloud", "queries"])
-def test_bench_two_ranks_self_launched(partition):
+@pytest.mark.parametrize("partition,launcher", [("cloud", "self"), ("queries", "self"), ("cloud", "torchrun")])
+def test_bench_two_ranks_self_launched(partition, launcher):
     """`python bench.py --gpus 2` from a plain interpreter: the file spawns its own ranks, shards the movable cloud (or the
     queries), times with barrier + MAX over ranks, and rank 0 prints ONE JSON line whose parity leg (every rank in the
-    exchange, rank 0 against the oracle) is green.  SICP_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 over gloo."""
+    exchange, rank 0 against the oracle) is green.  SICP_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 over gloo.
+    `torchrun`: the same through the launcher command the round-end driver uses (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    from torch.distributed.run)."""
     import json
+    import socket
     env = dict(os.environ, SICP_BENCH_SHARE_GPU="1")
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--repeats", "2",
-                        "--points", "300000", "--partition", partition, "--no-cpu-baseline", "--no-end-to-end",
-                        "--no-bruteforce-leg"], env=env, capture_output=True, text=True, timeout=900)
+    args = [str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--repeats", "2", "--points", "300000",
+            "--partition", partition, "--no-cpu-baseline", "--no-end-to-end", "--no-bruteforce-leg"]
+    if launcher == "torchrun":
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + args
+    else:
+        cmd = [sys.executable] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
     d = json.loads(lines[0])
