@@ -2,7 +2,7 @@
 
 Run in the build container only (needs /root/reference; the GPU box has no copy):
 
-    python oracle/make_golden.py
+    python oracle/make_golden.py [--out DIR]      (default: tests/golden)
 
 What it does
   1. puts oracle/shim (a stand-in for the absent third-party ``lmfit``) and
@@ -198,6 +198,10 @@ def check_readme_kat(H, rbp, text):
 
 
 def main():
+    global GOLD, DATA
+    if len(sys.argv) > 2 and sys.argv[1] == "--out":          # regenerate somewhere else (tests/test_fixtures_regenerate.py)
+        GOLD = Path(sys.argv[2]).resolve()
+        DATA = GOLD / "data"
     os.chdir(ROOT)
     for name, (f1, f2, kw) in CASES.items():
         H, rbp, text, trace = run_case(name, f1, f2, kw)
