@@ -166,6 +166,7 @@ class Context:
             self._h = C.c_void_p()
             raise BackendError(self._L.sicp_last_error().decode(), rc)
         self.device = int(device)
+        self._corr_owner = None      # the CorrPts object whose correspondences the context holds (simpleicp_amd/corrpts.py)
 
     # -- plumbing --
     def _chk(self, rc):
