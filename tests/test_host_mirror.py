@@ -201,3 +201,29 @@ def test_pointcloud_operators_on_the_stand_in(ctx, clouds):
     pc.transform_by_H(Hm)
     assert np.array_equal(pc.X, orc.transform(Hm, X_fix))
     assert pc["x"].to_numpy().flags.c_contiguous and np.array_equal(pc.x, pc.X[:, 0])
+
+
+def test_frames_a_caller_may_hand_over(ctx, clouds):
+    """PointCloud is a DataFrame subclass: the mirror must take what pandas takes (pointcloud.py:15-49) -- a frame with
+    a foreign index, extra columns and another column order gives the SAME registration as the plain array; float32
+    input and a preset selection run through; the reference's error for a missing coordinate column."""
+    from simpleicp_amd import PointCloud, PointCloudException, SimpleICP
+    X1, X2 = clouds("bunny_part1"), clouds("bunny_part2")
+
+    def run(pc1, pc2):
+        icp = SimpleICP(verbose=False)
+        icp.add_point_clouds(pc1, pc2)
+        return icp.run(max_overlap_distance=1)[0]
+    H0 = run(PointCloud(X1, columns=["x", "y", "z"]), PointCloud(X2.copy(), columns=["x", "y", "z"]))
+    df1 = pd.DataFrame({"x": X1[:, 0], "y": X1[:, 1], "z": X1[:, 2], "intensity": np.arange(len(X1))},
+                       index=np.arange(len(X1))[::-1] + 1000)
+    df2 = pd.DataFrame({"z": X2[:, 2], "y": X2[:, 1], "x": X2[:, 0]})
+    assert np.array_equal(run(PointCloud(df1), PointCloud(df2)), H0)
+    H32 = run(PointCloud(X1.astype(np.float32), columns=["x", "y", "z"]), PointCloud(X2.astype(np.float32), columns=["x", "y", "z"]))
+    assert np.abs(H32 - H0).max() < 1e-3
+    pc1 = PointCloud(X1, columns=["x", "y", "z"])
+    pc1.select_by_indices(np.arange(0, len(X1), 2))
+    assert np.abs(run(pc1, PointCloud(X2.copy(), columns=["x", "y", "z"])) - H0).max() < 5e-3 and pc1.num_selected_points == 1000
+    assert PointCloud(X1[:50].tolist(), columns=["x", "y", "z"]).X.dtype == np.float64
+    with pytest.raises(PointCloudException, match='Column "z" is missing'):
+        PointCloud(X1[:5, :2], columns=["x", "y"])
