@@ -52,6 +52,8 @@ CASES = {
                 "rbp_observation_weights": (0.0, 0.0, 0.0, 0.0, 0.0, 0.0)}),
     # extra coverage of kwargs the reference supports but does not test:
     "dragon_q5000": ("dragon1.xyz", "dragon2.xyz", {"correspondences": 5000, "neighbors": 20}),
+    "dragon_kw": ("dragon1.xyz", "dragon2.xyz", {"correspondences": 500, "neighbors": 7, "min_planarity": 0.5,
+                                                 "distance_weights": 4.0, "min_change": 3.0, "max_iterations": 6}),
     "bunny_obs": ("bunny_part1.xyz", "bunny_part2.xyz",
                   {"max_overlap_distance": 1, "distance_weights": None,
                    "rbp_observed_values": (0.0, 0.0, 10.0, 0.0, 0.0, 0.0),

@@ -12,7 +12,7 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 GOLDEN = ROOT / "tests" / "golden"
-GOLDEN_CASES = ["dragon", "bunny", "multisensor", "webots", "dragon_q5000", "bunny_obs"]
+GOLDEN_CASES = ["dragon", "bunny", "multisensor", "webots", "dragon_q5000", "bunny_obs", "dragon_kw"]
 # the movable cloud carries a `planarity` column (and, dragon_chain, a partial `selected` mask): it was the fixed
 # cloud of an earlier reference run (oracle/make_golden.py CHAIN_CASES; corrpts.py:131-135,158-163)
 GOLDEN_CHAIN = ["dragon_chain", "bunny_chain"]

@@ -22,7 +22,7 @@ def test_committed_fixtures_are_what_the_reference_produces(tmp_path):
     assert "known-answer (Bunny H, rbp, uncertainties): reproduced to all printed digits" in r.stdout
     committed = sorted(p.relative_to(GOLDEN) for p in GOLDEN.rglob("*.npz"))
     fresh = sorted(p.relative_to(tmp_path) for p in tmp_path.rglob("*.npz"))
-    assert committed == fresh and len(committed) == 16
+    assert committed == fresh and len(committed) == 17
     for rel in committed:
         a, b = np.load(GOLDEN / rel, allow_pickle=False), np.load(tmp_path / rel, allow_pickle=False)
         assert sorted(a.files) == sorted(b.files), rel
