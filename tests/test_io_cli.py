@@ -102,3 +102,31 @@ def test_cli_end_to_end(tmp_path, clouds):
     assert "Estimated transformation matrix H:" in text and "Finished in" in text
     assert "[    0.984798    -0.173702    -0.000053     0.000676]" in text          # python/README.md:62
     assert io.read_xyz(tmp_path / "out.xyz").shape == clouds(files[1]).shape
+
+
+def test_xyz_round_trip_properties(tmp_path):
+    """Property test (hypothesis): any finite double written with any `decimals` has Python's own '%.<d>f' / '%.18e' bytes,
+    and what the reader returns is float() of those bytes -- for every thread count, with and without a header."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+    from simpleicp_amd import io
+
+    doubles = st.floats(allow_nan=False, allow_infinity=False, width=64)
+    rows = st.lists(st.tuples(doubles, doubles, doubles), min_size=0, max_size=40)
+
+    @settings(max_examples=120, deadline=None)
+    @given(rows=rows, decimals=st.integers(min_value=-1, max_value=17), threads=st.integers(min_value=1, max_value=5),
+           header=st.sampled_from([None, "//X Y Z", "# anything"]))
+    def check(rows, decimals, threads, header):
+        X = np.array(rows, dtype=np.float64).reshape(-1, 3)
+        f = tmp_path / "p.xyz"
+        io.write_xyz(f, X, decimals=decimals, header=header, threads=threads)
+        fmt = "%.18e" if decimals < 0 else f"%.{decimals}f"
+        want = ([header] if header is not None else []) + [" ".join(fmt % v for v in r) for r in X]
+        text = f.read_text()
+        assert text == "".join(line + "\n" for line in want)
+        back = io.read_xyz(f, threads=threads)
+        ref = np.array([[float(fmt % v) for v in r] for r in X], dtype=np.float64).reshape(-1, 3)
+        assert back.shape == ref.shape and np.array_equal(back, ref)
+        assert np.array_equal(np.signbit(back), np.signbit(ref))          # -0.0 stays -0.0
+    check()
