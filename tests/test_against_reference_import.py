@@ -88,6 +88,11 @@ def test_pointcloud_selection_bookkeeping_call_by_call(ref):
     with pytest.raises(PointCloudException) as e1:
         Mine(np.zeros((3, 2)), columns=["x", "y"])
     assert str(e0.value) == str(e1.value)
+    with pytest.raises(ref["pointcloud"].PointCloudException) as e0:         # pointcloud.py:158-159, before any search
+        Theirs(np.zeros((3, 3)), columns=["x", "y", "z"]).select_in_range(np.zeros((4, 2)), 1.0)
+    with pytest.raises(PointCloudException) as e1:
+        Mine(np.zeros((3, 3)), columns=["x", "y", "z"]).select_in_range(np.zeros((4, 2)), 1.0)
+    assert str(e0.value) == str(e1.value)
 
 
 def test_rigid_body_parameters_schema_and_H(ref):
