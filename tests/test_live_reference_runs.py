@@ -1,0 +1,111 @@
+"""Fresh data every time instead of the nine committed fixtures: the UNMODIFIED reference (imported; build container
+only) and this package's SimpleICP.run (its host logic on the oracle-backed stand-in context, tests/oracle_backend.py)
+register the same seeded random cloud pairs with the same keyword arguments -- partial overlap, fixed and observed
+parameters, an automatic weight, few iterations.  The reference's own normals are handed over (its LAPACK signs are
+arbitrary and its result depends on them), as the fixtures do.  Then: the same iteration count, the same
+correspondence counts up to a cKDTree tie pick, H to the reference's solver tolerance.  CPU only; skipped where
+/root/reference does not exist."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import oracle_backend
+from conftest import ROOT
+from oracle import orc
+
+REF = Path("/root/reference/python")
+pytestmark = pytest.mark.skipif(not (REF / "simpleicp").exists(), reason="the reference package is not on this machine")
+
+CASES = [
+    (0, {}),
+    (1, {"max_overlap_distance": 0.6, "correspondences": 400}),
+    (2, {"correspondences": 300, "neighbors": 6, "min_planarity": 0.45, "distance_weights": None, "max_iterations": 5}),
+    (3, {"rbp_observed_values": (0.0, 0.0, 1.0, 0.05, 0.0, 0.0), "rbp_observation_weights": (np.inf, 0.0, 20.0, 100.0, 0.0, 0.0)}),
+    (4, {"min_change": 0.01, "max_iterations": 9, "correspondences": 700}),
+]
+
+
+def _pair(seed):
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.integers(4000, 9000))
+    xy = rng.uniform(-8, 8, (n, 2))
+    z = 1.5 * np.sin(xy[:, 0] / 2.0) * np.cos(xy[:, 1] / 3.0) + 0.4 * np.sin(xy[:, 0] * 1.3 + 1) + rng.normal(0, 0.005, n)
+    P = np.column_stack((xy, z))
+    x_true = np.concatenate((rng.uniform(-0.01, 0.01, 2), [np.deg2rad(1.0) + rng.uniform(-0.004, 0.004)], rng.uniform(-0.06, 0.06, 3)))
+    M = orc.transform(np.linalg.inv(orc.params_to_H(x_true)), P[rng.permutation(n)[: n - 500]] + rng.normal(0, 0.005, (n - 500, 3)))
+    if seed == 1:
+        M = M[M[:, 0] > -3.0]                                  # partial overlap
+    return np.ascontiguousarray(P), np.ascontiguousarray(M)
+
+
+@pytest.mark.parametrize("seed,kwargs", CASES)
+def test_reference_and_mirror_agree_on_fresh_data(seed, kwargs, monkeypatch):
+    for p in (str(ROOT / "oracle" / "shim"), str(REF)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import simpleicp as ref
+    from simpleicp_amd import PointCloud, SimpleICP
+    P, M = _pair(seed)
+    a_fix, a_mov = ref.PointCloud(P, columns=["x", "y", "z"]), ref.PointCloud(M.copy(), columns=["x", "y", "z"])
+    a = ref.SimpleICP(verbose=False)
+    a.add_point_clouds(a_fix, a_mov)
+    with _Capture("simpleicp") as log_a:
+        H0, X0, rbp0, res0 = a.run(**kwargs)
+
+    oracle_backend.install(monkeypatch)
+    b_fix, b_mov = PointCloud(P, columns=["x", "y", "z"]), PointCloud(M.copy(), columns=["x", "y", "z"])
+    sel = a_fix.idx_selected                                   # the rows the reference estimated normals for
+    for c in ("nx", "ny", "nz", "planarity"):
+        v = np.full(len(P), np.nan, np.float32)
+        v[sel] = a_fix[c].to_numpy()[sel]
+        b_fix[c] = pd.arrays.SparseArray(v)
+    b = SimpleICP(verbose=False)
+    b.add_point_clouds(b_fix, b_mov)
+    with _Capture("simpleicp_amd") as log_b:
+        H1, X1, rbp1, res1 = b.run(**kwargs)
+
+    assert np.array_equal(b_fix.idx_selected, sel)             # overlap pre-pass + sub-sampling: the same rows
+    assert np.abs(H1 - H0).max() < 2e-6, np.abs(H1 - H0).max()
+    assert abs(len(res1) - len(res0)) <= 2 and abs(res1.std() - res0.std()) < 1e-5
+    assert np.abs(X1 - X0).max() < 1e-4 and np.array_equal(X1, b_mov.X)
+    x0 = np.array(rbp0.get_parameter_attributes_as_list("estimated_value"))
+    x1 = np.array(rbp1.get_parameter_attributes_as_list("estimated_value"))
+    ow = np.array(kwargs.get("rbp_observation_weights", (0.,) * 6), float)
+    assert np.abs(x1 - x0).max() < 2e-6 and np.array_equal(x1[~np.isfinite(ow)], x0[~np.isfinite(ow)])
+    s0 = np.array(rbp0.get_parameter_attributes_as_list("estimated_uncertainty"))
+    s1 = np.array(rbp1.get_parameter_attributes_as_list("estimated_uncertainty"))
+    free = np.isfinite(ow)
+    assert np.allclose(s1[free], s0[free], rtol=5e-3) and np.all(np.isnan(s1[~free])) and np.all(np.isnan(s0[~free]))
+    # iteration count: one table row per iteration (simpleicp.py:275-280), except the converging one (it breaks before its row)
+    stopped = [any(m.startswith("Convergence criteria fulfilled") for m in log) for log in (log_a, log_b)]
+    assert _rows(log_a) == _rows(log_b) > 0 and stopped[0] == stopped[1]
+    assert b.last_run_info["iterations"] == _rows(log_b) + int(stopped[1])
+
+
+def _rows(records):
+    import re
+    return sum(1 for m in records if re.match(r"^\s*\d+ \|", m))
+
+
+class _Capture:
+    """Collects the INFO messages of one package's loggers for the duration of a run."""
+
+    def __init__(self, name):
+        import logging
+        self.log, self.records = logging.getLogger(name), []
+        self.handler = logging.Handler()
+        self.handler.emit = lambda r: self.records.append(r.getMessage())
+
+    def __enter__(self):
+        import logging
+        self.old = self.log.level
+        self.log.setLevel(logging.INFO)
+        self.log.addHandler(self.handler)
+        return self.records
+
+    def __exit__(self, *exc):
+        self.log.removeHandler(self.handler)
+        self.log.setLevel(self.old)
