@@ -14,7 +14,7 @@ import pytest
 
 import oracle_backend
 from conftest import ROOT
-from oracle import orc
+from live_data import cloud_pair as _pair
 
 REF = Path("/root/reference/python")
 pytestmark = pytest.mark.skipif(not (REF / "simpleicp").exists(), reason="the reference package is not on this machine")
@@ -26,19 +26,6 @@ CASES = [
     (3, {"rbp_observed_values": (0.0, 0.0, 1.0, 0.05, 0.0, 0.0), "rbp_observation_weights": (np.inf, 0.0, 20.0, 100.0, 0.0, 0.0)}),
     (4, {"min_change": 0.01, "max_iterations": 9, "correspondences": 700}),
 ]
-
-
-def _pair(seed):
-    rng = np.random.default_rng(500 + seed)
-    n = int(rng.integers(4000, 9000))
-    xy = rng.uniform(-8, 8, (n, 2))
-    z = 1.5 * np.sin(xy[:, 0] / 2.0) * np.cos(xy[:, 1] / 3.0) + 0.4 * np.sin(xy[:, 0] * 1.3 + 1) + rng.normal(0, 0.005, n)
-    P = np.column_stack((xy, z))
-    x_true = np.concatenate((rng.uniform(-0.01, 0.01, 2), [np.deg2rad(1.0) + rng.uniform(-0.004, 0.004)], rng.uniform(-0.06, 0.06, 3)))
-    M = orc.transform(np.linalg.inv(orc.params_to_H(x_true)), P[rng.permutation(n)[: n - 500]] + rng.normal(0, 0.005, (n - 500, 3)))
-    if seed == 1:
-        M = M[M[:, 0] > -3.0]                                  # partial overlap
-    return np.ascontiguousarray(P), np.ascontiguousarray(M)
 
 
 @pytest.mark.parametrize("seed,kwargs", CASES)
