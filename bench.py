@@ -451,11 +451,22 @@ def parity_oracle(rec, Xf, Xm, sel, normals, planarity, obs, ow):
                    "max_abs_dx": float(np.abs(np.array(R.x[:]) - o["x"]).max())}
             res["x_within_1e-9"] = res["max_abs_dx"] < 1e-9
         else:
+            # the match (Q x N_m pairs) on a bounded sample of the queries, brute force over the WHOLE movable cloud; everything
+            # downstream of it -- distances, planarity / MAD rejection, the minimiser -- on ALL correspondences, recomputed by the
+            # oracle from the device's matched indices (per-correspondence work and reductions: cheap on the host at any Q)
             pick = np.unique(np.round(np.linspace(0, nq - 1, max(1, cap))).astype(np.int64))
-            nn, _ = orc.knn(Xm, Xf[sel[pick]], k=1, H=orc.params_to_H(x))
-            d = orc.point_to_plane(Xf[sel[pick]], normals[pick], Xm[nn[:, 0]], orc.params_to_H(x))
-            res = {"indices_equal": bool(np.array_equal(idx[pick], nn[:, 0])), "distances_equal": bool(np.array_equal(dist[pick], d)),
-                   "queries_sampled": int(len(pick))}
+            Hx = orc.params_to_H(x)
+            nn, _ = orc.knn(Xm, Xf[sel[pick]], k=1, H=Hx)
+            p1, p2 = Xf[sel], Xm[idx]
+            d = orc.point_to_plane(p1, normals, p2, Hx)
+            okeep, on, omed, omad = orc.reject(d, planarity, 0.3)
+            ox, _ = orc.solve(x, 1.0, obs, ow, p1, normals, p2, okeep)
+            res = {"indices_equal": bool(np.array_equal(idx[pick], nn[:, 0])), "queries_sampled": int(len(pick)),
+                   "distances_equal": bool(np.array_equal(dist, d)), "keep_mask_equal": bool(np.array_equal(keep, okeep)),
+                   "median_mad_equal": bool(R.median == omed and R.mad == omad and R.n_kept == on),
+                   "max_abs_dx": float(np.abs(np.array(R.x[:]) - ox).max()),
+                   "scope": "indices on the sample; distances, keep mask, median / MAD, minimiser on all correspondences"}
+            res["x_within_1e-9"] = res["max_abs_dx"] < 1e-9
         ok_all = ok_all and all(v for kk, v in res.items() if isinstance(v, bool))
         out[f"iteration_{it}"] = res
     out["ok"] = bool(ok_all)

@@ -36,7 +36,10 @@
 extern "C" {
 #endif
 
-#define SICP_ABI_VERSION 1
+/* 1: round 1.  2: + sicp_corr_*, sicp_estimate_parameters, sicp_comm_*, sicp_set_partition, sicp_cloud_set_planarity,
+ * sicp_cloud_download_columns, sicp_match_work; sicp_timing_enable(ctx, 2); every upload resets the slot's planarity
+ * column.  3: + sicp_comm_info.  A binding checks sicp_abi_version() against the header it was written for. */
+#define SICP_ABI_VERSION 3
 
 #define SICP_OK               0
 #define SICP_ERR_INVALID     -1   /* bad argument / wrong call order                         */
@@ -147,10 +150,13 @@ typedef struct sicp_iter_result {
     int64_t ne_evals;       /* fused normal-equation reductions launched                    */
 } sicp_iter_result;
 
-/* One full iteration on the GPU: match (brute-force 1-NN of the Q selected fixed points in
- * the movable cloud transformed by H(x)), point-to-plane distances, planarity + raw-MAD
- * rejection, then minimisation of the reference's objective (optimization.py:65-124) by
- * Levenberg-Marquardt on fused 6x6 normal-equation reductions with a host-side solve.     */
+/* One full iteration on the GPU (simpleicp.py:186-250): match -- the EXACT nearest neighbour, order (K), of each of the
+ * Q selected fixed points in the movable cloud under H(x); by default a pruned search on a uniform grid built once per
+ * upload, queries pulled back by the rigid inverse of H (bit-identical to the brute-force scan, which runs instead for a
+ * non-rigid H or on request) --, point-to-plane distances, planarity + raw-MAD rejection, then minimisation of the
+ * reference's objective (optimization.py:65-124) by Levenberg-Marquardt on fused normal-equation reductions with the
+ * 6x6 solves on the device (no host round trip inside the iteration; the operator sicp_estimate_parameters below is
+ * the variant with the host-side solve).  A chain of length one of what sicp_icp_run enqueues. */
 int sicp_icp_iterate(sicp_ctx *ctx, const sicp_iter_params *params, sicp_iter_result *result);
 
 /* The whole iteration loop of simpleicp.py:184-261 in one call: repeats sicp_icp_iterate from
@@ -275,15 +281,16 @@ int sicp_xyz_write(const char *path, const double *data, int64_t n, int cols, in
                    const char *header, int threads);
 
 /* ---- kernel timing (HIP events on the library's own stream) -------------------------- */
-#define SICP_K_KNN1     0   /* brute-force 1-NN scan (dominant kernel)  */
-#define SICP_K_KNNK     1   /* brute-force k-NN scan                    */
-#define SICP_K_NORMALEQ 2   /* fused residual + normal-equation reduce  */
-#define SICP_K_SELECT   3   /* median / MAD selection                   */
+#define SICP_K_KNN1     0   /* the 1-NN search of the match, whichever flavour ran (sicp_last_match_kernel)          */
+#define SICP_K_KNNK     1   /* the k-NN search of estimate_normals                                                  */
+#define SICP_K_NORMALEQ 2   /* the solver's launches: k_icp_tail (Q <= 2048: the whole tail) or k_lm_eval/k_lm_finish */
+#define SICP_K_SELECT   3   /* distances + median / MAD selection + keep mask when they are launches of their own   */
 #define SICP_K_COUNT    4
 int sicp_timing_enable(sicp_ctx *ctx, int on);   /* 0 off, 1 kernel timing, 2 timing + the grid search's work tallies (sicp_match_work) */
 /* which 1-NN flavour the last sicp_knn(k=1) / sicp_icp_iterate used: 0 exact scan, 1 filtered scan
  * with inline verification, 2 grid search, 3 filtered scan (VALU filter) with recorded candidates + fix-up kernel,
- * 4 the same with the filter on the FP32 matrix pipe (all return identical results) */
+ * 4 the same with the filter on the FP32 matrix pipe, 5 grid search with four queries per wave (all return identical
+ * results) */
 int sicp_last_match_kernel(sicp_ctx *ctx, int *kind_out);
 int sicp_timing_reset(sicp_ctx *ctx);
 /* Work the pruned grid search did in its launches since sicp_timing_reset, counted by the kernel itself while

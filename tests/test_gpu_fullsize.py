@@ -139,3 +139,163 @@ def test_iterations_equal_oracle_at_full_size(data):
             assert np.abs(x - o["x"]).max() < 1e-9
         whole = c.icp_run(z, z, z, 0.3, 1.0, max_iterations=3, min_change=0.0)
         assert np.abs(np.array(whole[-1].x[:]) - x).max() < 1e-13
+
+
+# ---- round 3: the operators that had no oracle check at the headline size ------------------------------------------
+
+def test_normals_knn_equals_oracle_at_full_size(data):
+    """estimate_normals at 10 M (pointcloud.py:185-198): the k = 10 search itself (k_grid_knn) against the oracle's
+    brute-force k-NN -- indices bit for bit incl. their (d2, idx) order -- then normals / planarity against the
+    oracle's covariance + eigen step on those neighbours (float32 store, one ulp of a unit vector's component)."""
+    from simpleicp_amd import _lib
+    from oracle import orc
+    Xf, Xm, H_true, sel = data
+    with _ctx(None) as c:
+        c.upload(_lib.FIX, Xf)
+        nv, pl, nn = c.estimate_normals(_lib.FIX, sel, 10, want_nn=True)
+    onn, _ = orc.knn(Xf, Xf[sel], k=10)
+    assert np.array_equal(nn, onn)
+    assert np.array_equal(nn[:, 0], sel)                         # the query itself is its own nearest neighbour
+    onv, opl = orc.normals(Xf, onn)
+    # same operation order on both sides; 1 ulp(float32) of a unit vector's components for the fp64 sqrt / div paths
+    assert np.abs(nv - onv).max() <= 2e-7 and np.abs(pl - opl).max() <= 2e-6
+    # and another neighbourhood size through the same kernel (webots' k = 40, pointcloud.py:173)
+    sub = sel[::10]
+    with _ctx(None) as c:
+        c.upload(_lib.FIX, Xf)
+        _, _, nn40 = c.estimate_normals(_lib.FIX, sub, 40, want_nn=True)
+    assert np.array_equal(nn40, orc.knn(Xf, Xf[sub], k=40)[0])
+
+
+def test_select_in_range_at_full_size(data):
+    """select_in_range with ALL 10 M fixed points as queries against the 10 M movable cloud under a rigid H
+    (pointcloud.py:161-167, strict `<`): 2000 sampled verdicts against orc.knn(max_dist), plus a bound chosen ON a
+    sampled nearest-neighbour distance (strictness at full size) and the two trivial bounds."""
+    from simpleicp_amd import _lib
+    from oracle import orc
+    Xf, Xm, H_true, sel = data
+    pick = np.unique(np.round(np.linspace(0, N - 1, 2000)).astype(np.int64))
+    oidx, od2 = orc.knn(Xm, Xf[pick], k=1, H=H_true)
+    dist = np.sqrt(od2[:, 0])
+    with _ctx(None) as c:
+        c.upload(_lib.FIX, Xf)
+        c.upload(_lib.MOV, Xm)
+        for bound in (float(np.median(dist)), float(np.sort(dist)[len(dist) // 10]), float(dist[7]), float(np.nextafter(dist[11], 0))):
+            near = c.select_in_range(_lib.FIX, _lib.MOV, None, H_true, bound)
+            assert near.shape == (N,)
+            ridx, _ = orc.knn(Xm, Xf[pick], k=1, H=H_true, max_dist=bound)
+            assert np.array_equal(near[pick], ridx[:, 0] >= 0)
+            assert 0 < near.sum() < N
+        # a bound whose SQUARE is exactly a nearest-neighbour's squared distance: that point is NOT in range (the rule
+        # is d2 < max_range * max_range, strict, like cKDTree's distance_upper_bound); one ulp more and it is
+        j = int(np.flatnonzero((dist * dist == od2[:, 0]) & (dist > 0))[0])
+        assert not c.select_in_range(_lib.FIX, _lib.MOV, pick[j:j + 1], H_true, float(dist[j]))[0]
+        assert c.select_in_range(_lib.FIX, _lib.MOV, pick[j:j + 1], H_true, float(np.nextafter(dist[j], np.inf)))[0]
+        # a sub-selection gives the same verdicts as the full pass
+        sub = c.select_in_range(_lib.FIX, _lib.MOV, pick, H_true, float(np.median(dist)))
+        full = c.select_in_range(_lib.FIX, _lib.MOV, None, H_true, float(np.median(dist)))
+        assert np.array_equal(sub, full[pick])
+        assert c.select_in_range(_lib.FIX, _lib.MOV, None, H_true, np.inf).all()
+
+
+def test_run_on_dataframes_at_full_size(data):
+    """SimpleICP.run() itself on C4 DataFrames (simpleicp.py:135-324) against the oracle's whole-loop driver on the same
+    arrays: selection, iteration count, per-iteration correspondence counts, H to 1e-9; the result against H_true;
+    side effects (simpleicp.py:254,316: pc_fix keeps the sub-sample and gains sparse float32 columns, pc_mov is
+    transformed in place)."""
+    from simpleicp_amd import PointCloud, SimpleICP
+    from oracle import orc
+    Xf, Xm, H_true, sel = data
+    pc_fix = PointCloud(Xf, columns=["x", "y", "z"])
+    pc_mov = PointCloud(Xm.copy(), columns=["x", "y", "z"])
+    icp = SimpleICP(verbose=False)
+    icp.add_point_clouds(pc_fix, pc_mov)
+    H, X, rbp, res = icp.run(correspondences=Q, neighbors=10)
+    o = orc.run(Xf, Xm, correspondences=Q, neighbors=10)
+    assert np.array_equal(pc_fix.idx_selected, o["sel"]) and np.array_equal(o["sel"], sel)
+    assert icp.last_run_info["iterations"] == o["iterations"]
+    assert [s[0] for s in icp.last_run_info["stats"]] == [s[0] for s in o["stats"]]
+    assert np.abs(H - o["H"]).max() < 1e-9
+    assert np.abs(np.array(rbp.get_parameter_attributes_as_list("estimated_value")) - o["x"]).max() < 1e-9
+    assert np.allclose(np.array(rbp.get_parameter_attributes_as_list("estimated_uncertainty")), o["sigma"], rtol=1e-6)
+    assert len(res) == len(o["residuals"]) and np.abs(res - o["residuals"]).max() < 1e-9
+    # the two samplings of the surface are independent: H_true is met to the data's noise, not to rounding
+    assert np.abs(H - H_true).max() < 2e-2 and np.abs(H[:3, :3] - H_true[:3, :3]).max() < 1e-4
+    # side effects
+    assert X.shape == (N, 3) and np.array_equal(X, pc_mov.X)
+    assert np.array_equal(X[::9973], orc.transform(H, Xm[::9973]))
+    for col in ("nx", "ny", "nz", "planarity"):
+        assert str(pc_fix[col].dtype) == "Sparse[float32, nan]"
+    got = np.column_stack([pc_fix[c].to_numpy()[sel] for c in ("nx", "ny", "nz")])
+    assert np.abs(got - o["normals"]).max() <= 2e-7
+
+
+@pytest.fixture(scope="module")
+def big_q(data):
+    """The throughput regime on the same clouds: 1 M selected points -> k_grid_nn16, k_hsel_*, k_keep_stats,
+    k_lm_eval / k_lm_finish (none of which run at Q = 1000)."""
+    from simpleicp_amd import _lib
+    Xf, Xm, H_true, _ = data
+    sel = np.unique(np.round(np.linspace(0, N - 1, 1_000_000)).astype(np.int64))
+    c = _ctx(None)
+    c.upload(_lib.FIX, Xf)
+    c.upload(_lib.MOV, Xm)
+    nv, pl = c.estimate_normals(_lib.FIX, sel, 10)
+    yield c, sel, nv, pl
+    c.close()
+
+
+def check_large_q_iteration(c, Xf, Xm, sel, nv, pl, x, R, n_sample, min_planarity=0.3):
+    """One large-Q iteration against the oracle: the match on a sample of the queries (brute force over the WHOLE
+    movable cloud), then everything downstream on ALL correspondences -- distances, keep mask, median, MAD, the
+    minimiser -- from the device's matched indices (each stage is per-correspondence or a reduction the oracle
+    recomputes in full; only the 1e13-pair match itself has to be sampled)."""
+    from oracle import orc
+    idx, dist, keep, resid = c.icp_state()
+    H = orc.params_to_H(x)
+    pick = np.unique(np.round(np.linspace(0, len(sel) - 1, n_sample)).astype(np.int64))
+    nn, _ = orc.knn(Xm, Xf[sel[pick]], k=1, H=H)
+    assert np.array_equal(idx[pick], nn[:, 0])
+    p1, p2 = Xf[sel], Xm[idx]
+    od = orc.point_to_plane(p1, nv, p2, H)
+    assert np.array_equal(dist, od)
+    okeep, on, omed, omad = orc.reject(od, pl, min_planarity)
+    assert np.array_equal(keep, okeep) and R.n_kept == on and R.median == omed and R.mad == omad
+    ox, _ = orc.solve(x, 1.0, np.zeros(6), np.zeros(6), p1, nv, p2, okeep)
+    assert np.abs(np.array(R.x[:]) - ox).max() < 1e-9
+    ores = orc.residuals(ox, p1, nv, p2, okeep)
+    assert np.abs(resid[keep] - ores).max() < 1e-9
+    return ox
+
+
+def test_large_q_iterations_equal_oracle_at_full_size(data, big_q):
+    """10 M clouds, Q = 1 M: three iterations of the many-workgroup path (a6-a10 at C5-class Q)."""
+    Xf, Xm, H_true, _ = data
+    c, sel, nv, pl = big_q
+    z = np.zeros(6)
+    c.icp_setup(sel, nv, pl)
+    x = z.copy()
+    for it in range(3):
+        R = c.icp_iterate(x, z, z, 0.3, 1.0)
+        assert c.last_match_kernel() == "k_grid_nn16"
+        check_large_q_iteration(c, Xf, Xm, sel, nv, pl, x, R, 3000)
+        x = np.array(R.x[:])
+    # the chained loop lands on the same estimates
+    c.icp_setup(sel, nv, pl)
+    whole = c.icp_run(z, z, z, 0.3, 1.0, max_iterations=3, min_change=0.0)
+    assert np.abs(np.array(whole[-1].x[:]) - x).max() < 1e-12
+    assert whole[-1].n_kept == R.n_kept and whole[-1].median == R.median and whole[-1].mad == R.mad
+
+
+def test_mid_q_iteration_equals_oracle_at_full_size(data, big_q):
+    """... and Q = 100 000 (SURVEY 8d's throughput point) on the same resident clouds."""
+    Xf, Xm, H_true, _ = data
+    c, sel, nv, pl = big_q
+    z = np.zeros(6)
+    s = slice(None, None, 10)
+    c.icp_setup(sel[s], nv[s], pl[s])
+    x = z.copy()
+    for it in range(2):
+        R = c.icp_iterate(x, z, z, 0.3, 1.0)
+        check_large_q_iteration(c, Xf, Xm, sel[s], nv[s], pl[s], x, R, 3000)
+        x = np.array(R.x[:])
