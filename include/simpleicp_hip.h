@@ -38,7 +38,7 @@ extern "C" {
 
 /* 1: round 1.  2: + sicp_corr_*, sicp_estimate_parameters, sicp_comm_*, sicp_set_partition, sicp_cloud_set_planarity,
  * sicp_cloud_download_columns, sicp_match_work; sicp_timing_enable(ctx, 2); every upload resets the slot's planarity
- * column.  3: + sicp_comm_info.  A binding checks sicp_abi_version() against the header it was written for. */
+ * column.  3: + sicp_comm_activate, sicp_comm_info, sicp_device_memory; SICP_K_XCHG; sicp_comm_init bounded + handshake.  A binding checks sicp_abi_version() against the header it was written for. */
 #define SICP_ABI_VERSION 3
 
 #define SICP_OK               0
@@ -239,7 +239,9 @@ int sicp_params_to_H(const double x[6], double H_out[16]);
 typedef int (*sicp_exchange_fn)(void *user, int what, void *a, void *b, void *c, int64_t count);
 /* With an exchange registered, sicp_knn(k == 1) and the iteration's match return JOB-WIDE winners.
  * gn_shard: 0 = every rank reduces all correspondences (no collective in the solver),
- *           1 = rank r reduces slice r of the correspondences + SUM exchange per step.   */
+ *           1 = rank r reduces slice r of the correspondences + ONE SUM exchange per evaluation: the 8x8 Gram block
+ *               [J^T J | J^T r | sum r, sum r^2, n] (64 doubles) on the device solver (more than 2048 correspondences; below
+ *               that the single-workgroup tail ignores the flag), the 30 sums of the host-side solve under SICP_SOLVE=host. */
 int sicp_set_exchange(sicp_ctx *ctx, sicp_exchange_fn fn, void *user, int rank, int world, int gn_shard);
 /* The same exchange issued by the library itself: one RCCL communicator per ctx (one process per GPU), collectives
  * enqueued on the ctx's stream between its kernels -- no host callback, nothing blocks (SURVEY 8b `sicp_comm_init`).
@@ -251,6 +253,20 @@ int sicp_set_exchange(sicp_ctx *ctx, sicp_exchange_fn fn, void *user, int rank, 
 int sicp_comm_unique_id(void *id128);
 int sicp_comm_init(sicp_ctx *ctx, const void *id128, int rank, int world, int gn_shard);
 int sicp_comm_destroy(sicp_ctx *ctx);
+/* sicp_comm_init never blocks for good: the rendezvous (ncclCommInitRank) and a first small all-gather on the ctx's stream
+ * are both awaited with a deadline (SICP_COMM_TIMEOUT_S, default 60 s) and what RCCL reports (ncclCommCount /
+ * ncclCommUserRank) is checked against rank / world; any failure returns SICP_ERR_EXCHANGE and leaves the ctx without a
+ * communicator, so the host can send every rank down another road together.  Inside a run a result that does not arrive within
+ * SICP_XCHG_TIMEOUT_S (default 120 s) while collectives are in flight is SICP_ERR_EXCHANGE as well, not a hang.
+ *   sicp_comm_activate : the communicator stays with the ctx between runs; on = 1 makes the ctx's searches and iterations
+ *                        job-wide again (with this gn_shard), on = 0 parks it (single-GPU behaviour, communicator kept).
+ *   sicp_comm_info     : out[0] exchange in force: 0 none, 1 host callback, 2 the library's RCCL communicator;
+ *                        out[1] ranks and out[2] this rank -- for 2 as RCCL itself counts them (ncclCommCount /
+ *                        ncclCommUserRank); out[3] partition; out[4] gn_shard; out[5] a communicator exists (active or parked). */
+int sicp_comm_activate(sicp_ctx *ctx, int on, int gn_shard);
+int sicp_comm_info(sicp_ctx *ctx, int out[6]);
+/* free / total bytes of the ctx's device (hipMemGetInfo): what a host consults before it replicates a cloud on every rank */
+int sicp_device_memory(sicp_ctx *ctx, int64_t *free_out, int64_t *total_out);
 /* What the ranks shard:
  *   SICP_PART_CLOUD   (default) every rank holds a contiguous index range of the searched cloud and all Q queries; one
  *                     all-gather of per-query winners + lexicographic minimum per iteration;
@@ -285,7 +301,8 @@ int sicp_xyz_write(const char *path, const double *data, int64_t n, int cols, in
 #define SICP_K_KNNK     1   /* the k-NN search of estimate_normals                                                  */
 #define SICP_K_NORMALEQ 2   /* the solver's launches: k_icp_tail (Q <= 2048: the whole tail) or k_lm_eval/k_lm_finish */
 #define SICP_K_SELECT   3   /* distances + median / MAD selection + keep mask when they are launches of their own   */
-#define SICP_K_COUNT    4
+#define SICP_K_XCHG     4   /* the multi-GPU exchange of an iteration: pack + collective + unpack / lexicographic minimum   */
+#define SICP_K_COUNT    5
 int sicp_timing_enable(sicp_ctx *ctx, int on);   /* 0 off, 1 kernel timing, 2 timing + the grid search's work tallies (sicp_match_work) */
 /* which 1-NN flavour the last sicp_knn(k=1) / sicp_icp_iterate used: 0 exact scan, 1 filtered scan
  * with inline verification, 2 grid search, 3 filtered scan (VALU filter) with recorded candidates + fix-up kernel,

@@ -20,8 +20,9 @@ FIX, MOV = 0, 1
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_TOO_FEW, ERR_NUMERIC, ERR_EXCHANGE = 0, -1, -2, -3, -4, -5, -6
 XCHG_ALLGATHER_F64, XCHG_SUM_F64 = 1, 2
 PART_CLOUD, PART_QUERIES = 0, 1
-K_KNN1, K_KNNK, K_NORMALEQ, K_SELECT = 0, 1, 2, 3
-KERNEL_NAMES = {K_KNN1: "match", K_KNNK: "knnk_scan", K_NORMALEQ: "solve", K_SELECT: "reject_select"}
+K_KNN1, K_KNNK, K_NORMALEQ, K_SELECT, K_XCHG = 0, 1, 2, 3, 4
+ABI_VERSION = 3          # include/simpleicp_hip.h SICP_ABI_VERSION this binding was written for
+KERNEL_NAMES = {K_KNN1: "match", K_KNNK: "knnk_scan", K_NORMALEQ: "solve", K_SELECT: "reject_select", K_XCHG: "exchange"}
 MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1_frec", 4: "k_knn1_fmfma", 5: "k_grid_nn16"}
 
 EXPORTS = [
@@ -30,7 +31,7 @@ EXPORTS = [
     "sicp_cloud_download", "sicp_cloud_download_columns", "sicp_cloud_set_planarity", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
     "sicp_corr_match", "sicp_corr_reject_planarity", "sicp_corr_reject_distances", "sicp_estimate_parameters",
-    "sicp_set_exchange", "sicp_comm_unique_id", "sicp_comm_init", "sicp_comm_destroy", "sicp_set_partition", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_last_match_kernel",
+    "sicp_set_exchange", "sicp_comm_unique_id", "sicp_comm_init", "sicp_comm_destroy", "sicp_comm_activate", "sicp_comm_info", "sicp_device_memory", "sicp_set_partition", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_last_match_kernel",
     "sicp_xyz_count", "sicp_xyz_read", "sicp_xyz_write",
 ]
 
@@ -79,6 +80,10 @@ def load():
         raise BackendError(f"cannot load {LIB_PATH}: {exc}") from exc
     vp, i64, dbl, cint = C.c_void_p, C.c_int64, C.c_double, C.c_int
     L.sicp_abi_version.restype = cint
+    if L.sicp_abi_version() != ABI_VERSION:
+        # (SICP_LIBRARY makes it easy to point at a stale build: its entry points would be called with the wrong arguments)
+        raise BackendError(f"{LIB_PATH} implements ABI version {L.sicp_abi_version()}, this binding needs {ABI_VERSION}; "
+                           "rebuild with `python -m simpleicp_amd.build`")
     L.sicp_last_error.restype = C.c_char_p
     L.sicp_device_count.argtypes = [C.POINTER(cint)]
     L.sicp_ctx_create.argtypes = [cint, C.POINTER(vp)]
@@ -109,6 +114,9 @@ def load():
     L.sicp_comm_unique_id.argtypes = [vp]
     L.sicp_comm_init.argtypes = [vp, vp, cint, cint, cint]
     L.sicp_comm_destroy.argtypes = [vp]
+    L.sicp_comm_activate.argtypes = [vp, cint, cint]
+    L.sicp_comm_info.argtypes = [vp, C.POINTER(cint * 6)]
+    L.sicp_device_memory.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.sicp_set_partition.argtypes = [vp, cint]
     L.sicp_ctx_stream.argtypes = [vp, C.POINTER(vp)]
     L.sicp_lexmin_gathered.argtypes = [vp, vp, cint, i64, vp, vp, vp]
@@ -428,6 +436,24 @@ class Context:
 
     def comm_destroy(self):
         self._chk(self._L.sicp_comm_destroy(self._h))
+
+    def comm_activate(self, on=True, gn_shard=False):
+        """Use (on) or park (off) the communicator the context already owns."""
+        self._chk(self._L.sicp_comm_activate(self._h, int(bool(on)), int(bool(gn_shard))))
+
+    def comm_info(self):
+        """What exchange is in force: backend none / callback / rccl, ranks and rank (for rccl as RCCL counts them)."""
+        out = (C.c_int * 6)()
+        self._chk(self._L.sicp_comm_info(self._h, C.byref(out)))
+        return {"backend": ("none", "callback", "rccl")[out[0]], "nranks": out[1], "rank": out[2],
+                "partition": "queries" if out[3] == PART_QUERIES else "cloud", "gn_shard": bool(out[4]),
+                "communicator": bool(out[5])}
+
+    def device_memory(self):
+        """(free, total) bytes of the context's device."""
+        f, t = C.c_int64(), C.c_int64()
+        self._chk(self._L.sicp_device_memory(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def set_partition(self, mode):
         """PART_CLOUD: ranks hold index ranges of the searched cloud; PART_QUERIES: ranks hold the whole cloud and

@@ -15,7 +15,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/simpleicp_hip.h"
@@ -123,15 +127,25 @@ struct Rccl {
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    std::string why;               // why the library is unusable (dlerror is read ONCE, where it is fresh)
 };
+Rccl &rccl_state() { static Rccl R; return R; }
 Rccl *rccl()
 {
-    static Rccl R;
+    Rccl &R = rccl_state();
     static bool tried = false;
     if (!tried) {
         tried = true;
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names) { R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (R.h) break; }
+        for (const char *n : names) {
+            R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (R.h) break;
+            const char *e = dlerror();
+            R.why += std::string(R.why.empty() ? "" : "; ") + (e ? e : "dlopen failed");
+        }
         if (R.h) {
             R.GetUniqueId = (decltype(R.GetUniqueId))dlsym(R.h, "ncclGetUniqueId");
             R.CommInitRank = (decltype(R.CommInitRank))dlsym(R.h, "ncclCommInitRank");
@@ -139,7 +153,11 @@ Rccl *rccl()
             R.AllGather = (decltype(R.AllGather))dlsym(R.h, "ncclAllGather");
             R.AllReduce = (decltype(R.AllReduce))dlsym(R.h, "ncclAllReduce");
             R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.h, "ncclGetErrorString");
-            if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather || !R.AllReduce || !R.GetErrorString) R.h = nullptr;
+            R.CommCount = (decltype(R.CommCount))dlsym(R.h, "ncclCommCount");
+            R.CommUserRank = (decltype(R.CommUserRank))dlsym(R.h, "ncclCommUserRank");
+            R.CommAbort = (decltype(R.CommAbort))dlsym(R.h, "ncclCommAbort");
+            if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather || !R.AllReduce || !R.GetErrorString ||
+                !R.CommCount || !R.CommUserRank || !R.CommAbort) { R.h = nullptr; R.why = "librccl lacks an entry point this library needs"; }
         }
     }
     return R.h ? &R : nullptr;
@@ -294,9 +312,14 @@ struct sicp_ctx {
     sicp_exchange_fn xfn = nullptr;
     void *xuser = nullptr;
     ncclComm_t comm = nullptr;
+    bool comm_active = false;      // a communicator stays with the ctx between runs (sicp_comm_activate): building one costs ~0.1-1 s
+    int comm_rank = 0, comm_world = 1;
+    double xchg_timeout_s = 120.0; // a record that does not arrive within this while collectives are in flight = SICP_ERR_EXCHANGE, not a hang
+    DevBuf<double> lm_gsum;        // sharded 6x6 reduction on the device solver: this rank's 8x8 Gram block, summed over ranks in place
+    bool resid_sharded = false;    // ... after which only this rank's slice of the residuals is current (recomputed on demand)
     int rank = 0, world = 1, gn_shard = 0;
     int partition = SICP_PART_CLOUD;   // what is sharded over the ranks: the searched cloud or the queries
-    bool collective() const { return xfn != nullptr || comm != nullptr; }
+    bool collective() const { return xfn != nullptr || (comm != nullptr && comm_active); }
     // timing
     bool timing = false;
     bool count_work = false;       // sicp_timing_enable(ctx, 2): the grid search also tallies its candidates / rows
@@ -350,6 +373,23 @@ int wait_ticket(sicp_ctx *c, const double *flag_word, double seq)
         __builtin_ia32_pause();
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen && c->collective()) {
+        // collectives are enqueued between the kernels: a rank that left the job (or a rank whose launches went out of step)
+        // would leave this stream waiting forever -- give up with an error instead of hanging the process
+        const auto t0 = std::chrono::steady_clock::now();
+        while (*flag != seq) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return fail(SICP_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(q));
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->xchg_timeout_s)
+                return fail(SICP_ERR_EXCHANGE, "no result after %.0f s with a multi-GPU exchange in flight (rank %d of %d): a rank left "
+                                               "the job or the ranks' collectives are out of step (SICP_XCHG_TIMEOUT_S)",
+                            c->xchg_timeout_s, c->rank, c->world);
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        seen = *flag == seq;
+    }
     if (!seen) return sync(c);
     if (c->timing) collect_ready(c);
     return SICP_OK;
@@ -383,7 +423,7 @@ struct Timed {
 // recv[world][count] <- every rank's send[count], enqueued in order on the library's stream
 int all_gather_f64(sicp_ctx *c, double *send, double *recv, long count)
 {
-    if (c->comm) {
+    if (c->comm && c->comm_active) {
         const ncclResult_t r = rccl()->AllGather(send, recv, (size_t)count, ncclDouble, c->comm, c->stream);
         if (r != ncclSuccess) return fail(SICP_ERR_EXCHANGE, "ncclAllGather failed: %s", rccl()->GetErrorString(r));
         return SICP_OK;
@@ -395,7 +435,7 @@ int all_gather_f64(sicp_ctx *c, double *send, double *recv, long count)
 }
 int all_reduce_sum_f64(sicp_ctx *c, double *buf, long count)
 {
-    if (c->comm) {
+    if (c->comm && c->comm_active) {
         const ncclResult_t r = rccl()->AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->comm, c->stream);
         if (r != ncclSuccess) return fail(SICP_ERR_EXCHANGE, "ncclAllReduce failed: %s", rccl()->GetErrorString(r));
         return SICP_OK;
@@ -409,6 +449,7 @@ int all_reduce_sum_f64(sicp_ctx *c, double *buf, long count)
 int exchange_best(sicp_ctx *c, double *d2, int64_t *idx, double *p2, long Q)
 {
     if (!c->collective() || c->partition != SICP_PART_CLOUD) return SICP_OK;
+    Timed t(c, SICP_K_XCHG);
     CHK(c->x_send.reserve((size_t)5 * Q));
     CHK(c->x_recv.reserve((size_t)5 * Q * c->world));
     launch_pack_best(c->stream, d2, idx, p2, Q, c->x_send.p);
@@ -431,6 +472,7 @@ int exchange_query_slices(sicp_ctx *c, double *d2, int64_t *idx, double *p2, lon
 {
     const long per = (Q + c->world - 1) / c->world;
     long lo; const long cnt = query_slice(c, Q, &lo);
+    Timed t(c, SICP_K_XCHG);
     CHK(c->x_send.reserve((size_t)5 * per));
     CHK(c->x_recv.reserve((size_t)5 * per * c->world));
     if (cnt > 0) launch_pack_best(c->stream, d2 + lo, idx + lo, p2 + 3 * lo, cnt, c->x_send.p);
@@ -976,6 +1018,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_REJECT_SPLIT")) c->reject_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_COARSE_ITERS")) c->coarse_iters = std::atoi(e);
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
+    if (const char *e = std::getenv("SICP_XCHG_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) c->xchg_timeout_s = v; }
     if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
     if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : !std::strcmp(e, "mfma") ? 2 : 0;
     if (const char *e = std::getenv("SICP_FSCAN_CAP")) c->fscan_cap = std::atol(e);
@@ -1298,7 +1341,7 @@ SICP_EXPORT int sicp_icp_setup(sicp_ctx *c, const int64_t *sel_idx, int64_t Q, c
     CHK(c->m_idx.reserve(Q)); CHK(c->m_d2.reserve(Q)); CHK(c->m_p2.reserve((size_t)3 * Q));
     CHK(c->dist.reserve(Q)); CHK(c->resid.reserve(Q)); CHK(c->flag.reserve(Q)); CHK(c->keep.reserve(Q));
     if (Q > SOLVE_MAX_Q) CHK(c->resid2.reserve(Q));
-    c->resid_slot = 0;
+    c->resid_slot = 0; c->resid_sharded = false;
     HIPCHK(hipMemcpyAsync(c->m_idx.p, sel_idx, (size_t)Q * sizeof(int64_t), hipMemcpyDefault, c->stream));
     launch_gather_queries(c->stream, cl.x(), cl.y(), cl.z(), c->m_idx.p, Q, c->qpad, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad);
     HIPCHK(hipGetLastError());
@@ -1329,7 +1372,8 @@ int check_iter_args(sicp_ctx *c, const sicp_iter_params *P)
 }
 
 // does this configuration run the single-launch tail (sicp_tail.hip) with the loop state on the device?
-bool device_tail(const sicp_ctx *c) { return !(c->gn_shard && c->collective()) && c->solve_mode != 2; }
+// (a sharded 6x6 reduction -- gn_shard -- runs there as well: one all-reduce of the 8x8 Gram block per evaluation)
+bool device_tail(const sicp_ctx *c) { return c->solve_mode != 2; }
 
 // ---- iterations enqueued back to back, loop state on the device --------------------------------------------------
 // Q <= SOLVE_MAX_Q: match + ONE tail launch per iteration (sicp_tail.hip).  Larger Q: match, distances, rejection,
@@ -1348,6 +1392,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
     *done_out = 0;
     if (max_it <= 0) return SICP_OK;
     c->have_corr = false;
+    c->resid_sharded = false;
     // the pruned exact search on the static grid serves every rigid H, i.e. every H(x) of the loop
     const bool grid = (c->knn1_mode == 0 || c->knn1_mode == 3) && cl.n < (1LL << 31);
     if (grid) CHK(grid_build(c, SICP_MOV));
@@ -1476,10 +1521,21 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                     }
                 }
                 {
+                    // gn_shard: every rank evaluates its slice of the correspondences, ONE all-reduce adds the
+                    // 8x8 Gram blocks (J^T J, J^T r, sum r, sum r^2, n) up, a one-wave launch advances the replicated solver
+                    const bool shard = c->gn_shard && c->collective();
+                    if (shard) CHK(c->lm_gsum.reserve(64));
+                    c->resid_sharded = shard;
                     Timed t(c, SICP_K_NORMALEQ);
-                    for (int e = 0; e < c->lm_evals; ++e)
+                    for (int e = 0; e < c->lm_evals; ++e) {
                         launch_lm_eval(c->stream, qx, qy, qz, c->normals.p, c->m_p2.p, c->keep.p, Q, A, c->icp_dev.p, c->lm_dev.p,
-                                       c->small.p + 4, c->ne_partial.p, c->ticket.p, c->resid.p, c->resid2.p);
+                                       c->small.p + 4, c->ne_partial.p, c->ticket.p, c->resid.p, c->resid2.p,
+                                       shard ? c->rank : 0, shard ? c->world : 1, shard ? c->lm_gsum.p : nullptr);
+                        if (shard) {
+                            CHK(all_reduce_sum_f64(c, c->lm_gsum.p, 64));
+                            launch_lm_advance(c->stream, A, c->icp_dev.p, c->lm_dev.p, c->small.p + 4, c->lm_gsum.p);
+                        }
+                    }
                     launch_lm_finish(c->stream, qx, qy, qz, c->normals.p, c->m_p2.p, c->keep.p, Q, A, c->icp_dev.p, c->lm_dev.p,
                                      c->small.p, c->small.p + 4, c->resid.p, c->resid2.p, rec);
                 }
@@ -1612,7 +1668,7 @@ int iterate_host_lm(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
 {
     std::memset(R, 0, sizeof *R);
     const long Q = c->Q;
-    c->resid_slot = 0;
+    c->resid_slot = 0; c->resid_sharded = false;
     c->have_corr = false;
     // ---- match: simpleicp.py:188-202, corrpts.py:124-137 (transform fused into the scan) ----
     double H12[12];
@@ -1714,6 +1770,12 @@ SICP_EXPORT int sicp_icp_get_state(sicp_ctx *c, int64_t *pc2_idx, double *dist, 
     if (pc2_idx) HIPCHK(hipMemcpyAsync(pc2_idx, c->m_idx.p, Q * sizeof(int64_t), hipMemcpyDefault, c->stream));
     if (dist) HIPCHK(hipMemcpyAsync(dist, c->dist.p, Q * sizeof(double), hipMemcpyDefault, c->stream));
     if (keep) HIPCHK(hipMemcpyAsync(keep, c->keep.p, Q * sizeof(uint8_t), hipMemcpyDefault, c->stream));
+    if (residual && c->resid_sharded && c->have_iter) {
+        // the sharded reduction left only this rank's slice of the residuals current: one pass over all of them at the estimate
+        double ne[30];
+        CHK(normal_eq_host(c, c->last_x, true, false, ne));
+        c->resid_slot = 0; c->resid_sharded = false; c->resid_sharded = false;
+    }
     if (residual) HIPCHK(hipMemcpyAsync(residual, c->resid_slot ? c->resid2.p : c->resid.p, Q * sizeof(double), hipMemcpyDefault, c->stream));
     return sync(c);
 }
@@ -1796,7 +1858,7 @@ SICP_EXPORT int sicp_corr_match(sicp_ctx *c, const double *H, int64_t *pc2_idx_o
     CHK(exchange_best(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
     c->have_last_ne = false;
     c->have_iter = false;                                     // no estimate belongs to these correspondences yet
-    c->resid_slot = 0;
+    c->resid_slot = 0; c->resid_sharded = false;
     // distances (contract (P)); the flags of this launch are not used: nothing is rejected yet
     launch_postmatch(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, c->m_p2.p,
                      c->m_idx.p, Q, X, -std::numeric_limits<float>::infinity(), nullptr, 0, c->dist.p, c->flag.p);
@@ -1878,7 +1940,7 @@ SICP_EXPORT int sicp_estimate_parameters(sicp_ctx *c, const sicp_iter_params *P,
     R->n_planar = R->n_kept;
     R->median = R->mad = std::numeric_limits<double>::quiet_NaN();
     R->dist_mean = h_st[5]; R->dist_std = h_st[6];
-    c->resid_slot = 0;
+    c->resid_slot = 0; c->resid_sharded = false;
     c->have_last_ne = false;
     std::memcpy(R->x, P->x, sizeof R->x);
     if (R->n_kept < 6) return too_few((long long)R->n_kept);
@@ -1900,7 +1962,7 @@ SICP_EXPORT int sicp_set_exchange(sicp_ctx *c, sicp_exchange_fn fn, void *user, 
     if (!c) return fail(SICP_ERR_INVALID, "null ctx");
     if (world < 1 || rank < 0 || rank >= world) return fail(SICP_ERR_INVALID, "bad rank/world");
     if (world > 1 && !fn) return fail(SICP_ERR_INVALID, "world > 1 needs an exchange callback");
-    if (c->comm) CHK(sicp_comm_destroy(c));                // a callback replaces the library's own communicator
+    c->comm_active = false;                                // a callback replaces the library's own communicator (which stays parked)
     c->xfn = fn; c->xuser = user; c->rank = rank; c->world = world; c->gn_shard = gn_shard ? 1 : 0;
     return SICP_OK;
 }
@@ -1909,7 +1971,7 @@ SICP_EXPORT int sicp_comm_unique_id(void *id128)
 {
     if (!id128) return fail(SICP_ERR_INVALID, "null argument");
     Rccl *R = rccl();
-    if (!R) return fail(SICP_ERR_EXCHANGE, "librccl could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+    if (!R) return fail(SICP_ERR_EXCHANGE, "librccl could not be loaded: %s", rccl_state().why.c_str());
     ncclUniqueId id;
     const ncclResult_t r = R->GetUniqueId(&id);
     if (r != ncclSuccess) return fail(SICP_ERR_EXCHANGE, "ncclGetUniqueId failed: %s", R->GetErrorString(r));
@@ -1927,24 +1989,137 @@ SICP_EXPORT int sicp_comm_destroy(sicp_ctx *c)
         (void)rccl()->CommDestroy(c->comm);
         c->comm = nullptr;
     }
+    c->comm_active = false;
     if (!c->xfn) { c->rank = 0; c->world = 1; c->gn_shard = 0; }
     return SICP_OK;
 }
+
+namespace {
+// ncclCommInitRank is a rendezvous: it returns when EVERY rank has called it.  A rank that never does (it crashed, it took
+// another code path) would leave the callers blocked for good, so the call runs on a helper thread and the caller waits for it
+// with a deadline; on a timeout the helper stays behind (there is no handle to abort yet) and the caller reports an error --
+// simpleicp_amd/dist.py then sends every rank to the torch.distributed callback exchange together.
+struct CommInit {
+    std::mutex m; std::condition_variable cv;
+    bool done = false;
+    ncclResult_t r = ncclSuccess;
+    ncclComm_t comm = nullptr;
+};
+}  // namespace
 
 SICP_EXPORT int sicp_comm_init(sicp_ctx *c, const void *id128, int rank, int world, int gn_shard)
 {
     if (!c || !id128) return fail(SICP_ERR_INVALID, "null argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(SICP_ERR_INVALID, "bad rank/world");
     Rccl *R = rccl();
-    if (!R) return fail(SICP_ERR_EXCHANGE, "librccl could not be loaded");
+    if (!R) return fail(SICP_ERR_EXCHANGE, "librccl could not be loaded: %s", rccl_state().why.c_str());
     CHK(sicp_comm_destroy(c));
     HIPCHK(hipSetDevice(c->device));
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
-    const ncclResult_t r = R->CommInitRank(&c->comm, world, id, rank);
-    if (r != ncclSuccess) { c->comm = nullptr; return fail(SICP_ERR_EXCHANGE, "ncclCommInitRank failed: %s", R->GetErrorString(r)); }
+    double timeout_s = 60.0;
+    if (const char *e = std::getenv("SICP_COMM_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) timeout_s = v; }
+    auto job = std::make_shared<CommInit>();
+    const int device = c->device;
+    std::thread([job, R, id, rank, world, device] {
+        (void)hipSetDevice(device);
+        ncclComm_t comm = nullptr;
+        const ncclResult_t r = R->CommInitRank(&comm, world, id, rank);
+        std::lock_guard<std::mutex> g(job->m);
+        job->r = r; job->comm = comm; job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    {
+        std::unique_lock<std::mutex> g(job->m);
+        if (!job->cv.wait_for(g, std::chrono::duration<double>(timeout_s), [&] { return job->done; }))
+            return fail(SICP_ERR_EXCHANGE, "ncclCommInitRank did not return within %.0f s (rank %d of %d): not every rank joined "
+                                           "(SICP_COMM_TIMEOUT_S)", timeout_s, rank, world);
+        if (job->r != ncclSuccess) return fail(SICP_ERR_EXCHANGE, "ncclCommInitRank failed: %s", R->GetErrorString(job->r));
+        c->comm = job->comm;
+    }
+    // what the communicator says about itself must be what the caller said (a mixed-up id would pair the wrong processes)
+    int n = 0, r = -1;
+    if (R->CommCount(c->comm, &n) != ncclSuccess || R->CommUserRank(c->comm, &r) != ncclSuccess || n != world || r != rank) {
+        (void)R->CommAbort(c->comm); c->comm = nullptr;
+        return fail(SICP_ERR_EXCHANGE, "RCCL communicator reports rank %d of %d, expected %d of %d", r, n, rank, world);
+    }
+    c->comm_rank = r; c->comm_world = n;
+    // handshake: one small all-gather on the ctx's stream, awaited with a deadline -- the first collective is where a transport
+    // problem (a link that does not come up, a peer that cannot be mapped) shows, and it must show here, not inside a run
+    CHK(c->x_send.reserve(8)); CHK(c->x_recv.reserve((size_t)8 * world));
+    std::vector<double> h((size_t)8 * world, -1.0);
+    for (int j = 0; j < 8; ++j) h[j] = 1000.0 * rank + j;
+    HIPCHK(hipMemcpyAsync(c->x_send.p, h.data(), 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->comm_active = true;
+    int rc = all_gather_f64(c, c->x_send.p, c->x_recv.p, 8);
+    if (rc == SICP_OK) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { rc = fail(SICP_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(q)); break; }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+                rc = fail(SICP_ERR_EXCHANGE, "the first RCCL all-gather did not complete within %.0f s (rank %d of %d)", timeout_s, rank, world);
+                break;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+    }
+    if (rc == SICP_OK) {
+        if (hipMemcpy(h.data(), c->x_recv.p, (size_t)8 * world * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(SICP_ERR_HIP, "hipMemcpy after the handshake failed");
+        for (int k = 0; rc == SICP_OK && k < world; ++k)
+            for (int j = 0; j < 8; ++j)
+                if (h[(size_t)8 * k + j] != 1000.0 * k + j) { rc = fail(SICP_ERR_EXCHANGE, "RCCL handshake: slot %d holds %g, not rank %d's words", k, h[(size_t)8 * k + j], k); break; }
+    }
+    if (rc != SICP_OK) {
+        (void)R->CommAbort(c->comm); c->comm = nullptr; c->comm_active = false;
+        return rc;
+    }
     c->xfn = nullptr; c->xuser = nullptr;
     c->rank = rank; c->world = world; c->gn_shard = gn_shard ? 1 : 0;
+    return SICP_OK;
+}
+
+// The communicator stays with the ctx between runs; a run switches its use on, the end of the run off (a standalone
+// PointCloud operator on the same ctx must not issue a collective the other ranks never join).
+SICP_EXPORT int sicp_comm_activate(sicp_ctx *c, int on, int gn_shard)
+{
+    if (!c) return fail(SICP_ERR_INVALID, "null ctx");
+    if (on && !c->comm) return fail(SICP_ERR_INVALID, "no communicator: call sicp_comm_init first");
+    if (on) {
+        c->xfn = nullptr; c->xuser = nullptr;
+        c->comm_active = true; c->rank = c->comm_rank; c->world = c->comm_world; c->gn_shard = gn_shard ? 1 : 0;
+    } else {
+        c->comm_active = false;
+        if (!c->xfn) { c->rank = 0; c->world = 1; c->gn_shard = 0; }
+    }
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_comm_info(sicp_ctx *c, int out[6])
+{
+    if (!c || !out) return fail(SICP_ERR_INVALID, "null argument");
+    out[0] = c->xfn ? 1 : (c->comm && c->comm_active) ? 2 : 0;          // 0 none, 1 host callback, 2 the library's RCCL communicator
+    out[1] = c->world; out[2] = c->rank; out[3] = c->partition; out[4] = c->gn_shard;
+    out[5] = c->comm ? 1 : 0;                                            // a communicator exists (active or parked)
+    if (out[0] == 2) {
+        // as RCCL itself counts them, not as the caller declared them
+        int n = 0, r = -1;
+        if (rccl()->CommCount(c->comm, &n) != ncclSuccess || rccl()->CommUserRank(c->comm, &r) != ncclSuccess)
+            return fail(SICP_ERR_EXCHANGE, "ncclCommCount / ncclCommUserRank failed");
+        out[1] = n; out[2] = r;
+    }
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_device_memory(sicp_ctx *c, int64_t *free_out, int64_t *total_out)
+{
+    if (!c || !free_out || !total_out) return fail(SICP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    *free_out = (int64_t)f; *total_out = (int64_t)t;
     return SICP_OK;
 }
 

@@ -74,7 +74,8 @@ struct LmDev {
 int  lm_eval_grid(long Q);
 void launch_lm_eval(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
                     const uint8_t *keep, long Q, const TailArgs &A, const IcpDev *st, LmDev *L, const double *stats, double *partial,
-                    unsigned *ticket, double *resid0, double *resid1);
+                    unsigned *ticket, double *resid0, double *resid1, int rank = 0, int world = 1, double *gsum = nullptr);
+void launch_lm_advance(hipStream_t s, const TailArgs &A, const IcpDev *st, LmDev *L, const double *stats, const double *gsum);
 void launch_lm_finish(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
                       const uint8_t *keep, long Q, const TailArgs &A, IcpDev *st, LmDev *L, const double *rj4, const double *stats,
                       double *resid0, double *resid1, double *rec);

@@ -15,6 +15,7 @@
 // Residuals are accumulated relative to a shift (the kept distances' mean) so that their variance comes out of the
 // same pass without cancellation: no separate statistics launches.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include <stdint.h>
 
@@ -214,7 +215,9 @@ __global__ __launch_bounds__(LB) void k_lm_eval(
     const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep, long Q, TailArgs A,
     const IcpDev *__restrict__ st, LmDev *__restrict__ L, const double *__restrict__ stats /* n, mean, std of the kept distances */,
     double *__restrict__ partial /* [gridDim.x][64] */, unsigned *__restrict__ ticket, double *__restrict__ resid0,
-    double *__restrict__ resid1)
+    double *__restrict__ resid1, long chunk_lo, long chunk_hi /* this rank's LB-row chunks (all of them: 0, nchunks) */,
+    double *__restrict__ gsum /* != NULL: leave the folded Gram here instead of advancing the solver (k_lm_advance does, after
+                                 the ranks' sums have been added up) */)
 {
     __shared__ LmShared S;
     if (st->stop || L->done || stats[0] < 6.0) return;             // uniform: run over / solver finished / too few correspondences
@@ -224,8 +227,9 @@ __global__ __launch_bounds__(LB) void k_lm_eval(
     for (int j = 0; j < 6; ++j) { x[j] = L->xt[j]; sc[j] = L->sct[j]; }
     const int slot = L->cur ^ 1;
     const double shift = L->first ? stats[1] : L->shift;
-    const long nchunks = (Q + LB - 1) / LB;
-    block_gram(S, qx, qy, qz, normals, p2, keep, Q, x, sc, shift, blockIdx.x, gridDim.x, nchunks, slot ? resid1 : resid0);
+    // (block b starts at chunk_lo + b * LCH: block_gram takes its first round from `first * LCH`, so the range's start is
+    // folded into the arrays' base -- chunk_lo is a multiple of LCH)
+    block_gram(S, qx, qy, qz, normals, p2, keep, Q, x, sc, shift, chunk_lo / LCH + blockIdx.x, gridDim.x, chunk_hi, slot ? resid1 : resid0);
     if (tid < 64) partial[(long)blockIdx.x * 64 + tid] = S.gb[tid];
     // publish this block's partial, then take a ticket (stores -> vmcnt(0) -> barrier -> one-lane agent release ->
     // ticket; last arriver: agent acquire -> plain loads)
@@ -261,8 +265,22 @@ __global__ __launch_bounds__(LB) void k_lm_eval(
         for (int w = 0; w < LW; ++w) g += S.gp[w][0][tid];
         S.gb[tid] = g;
         if (tid == 0) *ticket = 0;                          // re-arm for the next launch on this stream
-        lm_advance(S, L, A, stats, shift);
+        if (gsum) gsum[tid] = g;                            // sharded reduction: the job-wide sum comes first
+        else lm_advance(S, L, A, stats, shift);
     }
+}
+
+// Sharded 6x6 reduction (gn_shard; SURVEY 8e step 3, the north star's "RCCL all-reduce of the 6x6 ATA / ATb and residual
+// stats"): every rank evaluated its slice of the correspondences (k_lm_eval with gsum), ONE ncclAllReduce(sum) added the
+// 64-double Gram blocks up -- the same bits on every rank --, and this one-wave launch advances the (replicated) solver.
+__global__ __launch_bounds__(64) void k_lm_advance(TailArgs A, const IcpDev *__restrict__ st, LmDev *__restrict__ L,
+                                                   const double *__restrict__ stats, const double *__restrict__ gsum)
+{
+    __shared__ LmShared S;
+    if (st->stop || L->done || stats[0] < 6.0) return;             // the evaluation in front of the collective exited on the same test
+    const double shift = L->first ? stats[1] : L->shift;
+    S.gb[threadIdx.x] = gsum[threadIdx.x];
+    lm_advance(S, L, A, stats, shift);
 }
 
 // One workgroup.  rj4: (m, median, mad, n_kept) of the rejection; stats: (n, mean, std) of the kept distances.
@@ -389,10 +407,20 @@ int lm_eval_grid(long Q)
 
 void launch_lm_eval(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
                     const uint8_t *keep, long Q, const TailArgs &A, const IcpDev *st, LmDev *L, const double *stats, double *partial,
-                    unsigned *ticket, double *resid0, double *resid1)
+                    unsigned *ticket, double *resid0, double *resid1, int rank, int world, double *gsum)
 {
-    hipLaunchKernelGGL(k_lm_eval, dim3(lm_eval_grid(Q)), dim3(LB), 0, s, qx, qy, qz, normals, p2, keep, Q, A, st, L, stats, partial,
-                       ticket, resid0, resid1);
+    // this rank's share of the LB-row chunks, in whole rounds of LCH chunks (world == 1: all of them)
+    const long nchunks = (Q + LB - 1) / LB;
+    const long rounds = (nchunks + LCH - 1) / LCH, per = (rounds + world - 1) / world;
+    const long lo = std::min(rounds, per * rank) * LCH, hi = std::min(nchunks, std::min(rounds, per * (rank + 1)) * LCH);
+    const long mine = std::max(0L, hi - lo) * LB;
+    hipLaunchKernelGGL(k_lm_eval, dim3(lm_eval_grid(mine)), dim3(LB), 0, s, qx, qy, qz, normals, p2, keep, Q, A, st, L, stats,
+                       partial, ticket, resid0, resid1, lo, hi, gsum);
+}
+
+void launch_lm_advance(hipStream_t s, const TailArgs &A, const IcpDev *st, LmDev *L, const double *stats, const double *gsum)
+{
+    hipLaunchKernelGGL(k_lm_advance, dim3(1), dim3(64), 0, s, A, st, L, stats, gsum);
 }
 
 void launch_lm_finish(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,

@@ -70,12 +70,19 @@ def test_run_with_reference_normals(name, clouds):
         assert min(len(g[f"it{i:03d}_after_planarity_pc1_idx"]) for i in range(int(g["iterations"]))) < n_pl1
 
 
-# The reference's result depends on the (arbitrary, LAPACK-internal) SIGN of each normal through the
-# signed-median/MAD filter: re-signing its own normals moves H by 1e-6 (Dragon), 2e-11..3e-7 (Bunny),
-# 9e-5..1.5e-3 (Webots) and 2e-3..6e-2 (Multisensor: 316 radar points, two fixed parameters) --
-# measured with the oracle.  So: tight against the oracle run with the same sign convention, and a
-# per-dataset sensitivity-sized tolerance against the reference's H.
-OWN_NORMALS_TOL = {"dragon": 1e-4, "bunny": 1e-4, "webots": 5e-3, "multisensor": 5e-3}
+# The reference's result depends on things its normals leave open: the (arbitrary, LAPACK-internal) SIGN of each normal --
+# through the signed-median / MAD filter -- and cKDTree's pick among equidistant k-th neighbours.  oracle/normal_sensitivity.py
+# measured by how much (the UNMODIFIED reference re-run with its own normals re-signed under 12 patterns, and with the
+# normals this package computes; committed as tests/golden/normal_sensitivity.json, held together by
+# tests/test_normal_sensitivity.py): H moves by 1e-6 (Dragon), 2e-4 (Bunny), 1.5e-3 (Webots), 6e-2 (Multisensor), the
+# iteration count by several.  So two comparisons with EARNED tolerances:
+#   * against the reference's published-style result (the fixture): inside the spread the reference itself shows;
+#   * against the reference FED THE SAME NORMALS ("oracle" run of that file): tight, same iteration count.
+import json as _json
+from conftest import GOLDEN as _GOLDEN
+SENS = _json.loads((_GOLDEN / "normal_sensitivity.json").read_text())["cases"]
+OWN_NORMALS_TOL = {name: r["spread_H"] * 1.001 + 1e-7 for name, r in SENS.items()}
+SAME_NORMALS_TOL = {"dragon": 1e-7, "bunny": 1e-7, "webots": 5e-7, "multisensor": 5e-7}
 
 
 @pytest.mark.parametrize("name", ["dragon", "bunny", "multisensor", "webots"])
@@ -89,7 +96,13 @@ def test_run_own_normals(name, clouds):
     assert icp.last_run_info["iterations"] == o["iterations"]
     assert [s[0] for s in icp.last_run_info["stats"]] == [s[0] for s in o["stats"]]
     assert np.abs(H - o["H"]).max() < 1e-9
-    assert np.abs(H - g["H"]).max() < OWN_NORMALS_TOL[name]
+    # the unmodified reference, handed these normals, takes the same number of iterations to the same H
+    same = SENS[name]["runs"]["oracle"]
+    assert icp.last_run_info["iterations"] == same["iterations"]
+    assert abs(icp.last_run_info["stats"][-1][0] - same["final_correspondences"]) <= 2
+    assert np.abs(H - np.array(same["H"])).max() < SAME_NORMALS_TOL[name]
+    # and against the reference with its own (LAPACK-signed, cKDTree-tie-picked) normals: inside the reference's own spread
+    assert np.abs(H - g["H"]).max() <= OWN_NORMALS_TOL[name]
     for c in ("nx", "ny", "nz", "planarity"):
         assert str(pc_fix[c].dtype) == "Sparse[float32, nan]"           # pointcloud.py:180-183,200-203
         assert np.isnan(pc_fix[c].to_numpy()).sum() == len(pc_fix) - len(g["sel_idx"])
