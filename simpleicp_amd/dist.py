@@ -118,16 +118,25 @@ def allgather_into(recv, send, group=None):
 
 def attach(ctx, gn_shard=False, partition=None, group=None):
     """Give `ctx` the job's collectives.  Default: the library's OWN RCCL communicator -- rank 0's ncclUniqueId is
-    broadcast over the existing torch.distributed group and every rank calls sicp_comm_init; all-gather / all-reduce
-    are then enqueued by the library on its stream between its kernels, no Python in the loop.  SICP_XCHG=callback
-    (or a group without GPUs) registers the torch.distributed callback of `make_exchange` instead.
-    Returns "rccl" or "callback"."""
+    broadcast over the existing torch.distributed group and every rank calls sicp_comm_init (rendezvous + a first
+    all-gather, both awaited with a deadline: it cannot hang); all-gather / all-reduce are then enqueued by the library on
+    its stream between its kernels, no Python in the loop.  The communicator STAYS with the context: the next run on the
+    same group switches it back on (sicp_comm_activate) instead of building another one.  SICP_XCHG=callback (or a group
+    without GPUs) registers the torch.distributed callback of `make_exchange` instead.  Returns "rccl" or "callback"."""
     import os
     import torch.distributed as td
     rank, world = td.get_rank(group), td.get_world_size(group)
     if partition is not None:
         ctx.set_partition(partition)
     if os.environ.get("SICP_XCHG", "rccl") != "callback" and td.get_backend(group) != "gloo":
+        pg = group if group is not None else td.group.WORLD
+        key = (id(pg), rank, world)                  # (ctx._comm_group keeps `pg` alive, so the id cannot be recycled)
+        if getattr(ctx, "_comm_key", None) == key and getattr(ctx, "_comm_group", None) is pg:
+            # an earlier run left its communicator parked on this context.  Every rank is in the same position: a
+            # communicator is only ever kept when ALL ranks reported success below, so no agreement round is needed
+            ctx.comm_activate(True, gn_shard=gn_shard)
+            return "rccl"
+        ctx._comm_key = ctx._comm_group = None
         err = None
         try:
             box = [ctx.comm_unique_id() if rank == 0 else None]
@@ -146,6 +155,7 @@ def attach(ctx, gn_shard=False, partition=None, group=None):
         td.all_gather_object(verdicts, None if err is None else f"rank {rank}: {err}", group=group)
         failed = [v for v in verdicts if v is not None]
         if not failed:
+            ctx._comm_key, ctx._comm_group = key, pg
             return "rccl"
         ctx.comm_destroy()
         if rank == 0:
@@ -156,10 +166,30 @@ def attach(ctx, gn_shard=False, partition=None, group=None):
 
 
 def detach(ctx):
-    """Back to single-GPU behaviour (the exchange lives on the process-wide context)."""
-    ctx.comm_destroy()
+    """Back to single-GPU behaviour (the exchange lives on the process-wide context); a communicator is parked, not
+    destroyed -- Context.close() / comm_destroy() ends it."""
+    ctx.comm_activate(False)
     ctx.set_exchange(None, 0, 1)
     ctx.set_partition(_lib.PART_CLOUD)
+
+
+def agree(flag: bool, group=None) -> bool:
+    """True iff `flag` is true on EVERY rank (one tiny object all-gather; only called when a job is about to choose a
+    partition from a per-rank measurement)."""
+    import torch.distributed as td
+    votes = [None] * td.get_world_size(group)
+    td.all_gather_object(votes, bool(flag), group=group)
+    return all(votes)
+
+
+def queries_partition_fits(ctx, n_points, headroom=0.5):
+    """Query shards replicate the WHOLE searched cloud on every rank: coordinates (24 B / point), the grid's packed records
+    (32 B), cell offsets and the subsample (about 8 B) -- take that road only when it fits comfortably in what is free now."""
+    try:
+        free, _total = ctx.device_memory()
+    except Exception:  # noqa: BLE001
+        return False
+    return 64 * int(n_points) <= headroom * free
 
 
 def exchange_query_slices(d2, idx, xyz, group=None):

@@ -114,8 +114,12 @@ class SimpleICP:
 
         # what the ranks shard: index ranges of the movable cloud by default; the QUERIES (cloud
         # replicated on every rank) when the match dominates, i.e. for large correspondence counts
+        # ... and only when a whole copy of the cloud (+ its grid) fits comfortably in every rank's free memory; a cloud that
+        # only fits in shards stays sharded whatever the correspondence count (the verdict is the same on every rank of a
+        # homogeneous node; SICP_PARTITION pins it explicitly)
         qshard = sharded and (os.environ.get("SICP_PARTITION", "") == "queries"
-                              or (os.environ.get("SICP_PARTITION", "") != "cloud" and correspondences >= 100_000))
+                              or (os.environ.get("SICP_PARTITION", "") != "cloud" and correspondences >= 100_000
+                                  and dist.agree(dist.queries_partition_fits(ctx, n_search))))
 
         def upload_movable(rows=None):
             n = pc2.num_points if rows is None else len(rows)

@@ -19,6 +19,7 @@ import pandas as pd
 
 from . import _lib, backend
 
+_PANDAS_MAJOR = int(pd.__version__.split(".")[0])
 _XYZ = ["x", "y", "z"]
 _ALL = object()          # selection sentinel: "every point" (no index vector materialised)
 _ATTRS = ("nx", "ny", "nz", "planarity")
@@ -287,13 +288,21 @@ class PointCloud(pd.DataFrame):
         return Xt
 
     def _adopt_column(self, name, values):
-        """``self[name] = values`` for an array this object just created: same result, no copy."""
-        try:
-            if name not in self.columns or len(values) != len(self.index) or values.dtype != np.float64:
-                raise TypeError
-            self._set_item_mgr(name, values)              # (pandas-internal: what __setitem__ calls after sanitising)
-        except Exception:                                 # noqa: BLE001  -- any other pandas: the public road
-            self[name] = values
+        """``self[name] = values`` for an array this object just created: same result, no copy.
+        The copy-free road is pandas-internal (`DataFrame._set_item_mgr`, what `__setitem__` calls after sanitising) and
+        is taken only on the pandas line it was written and tested against (2.x: 2.0 ... 2.3, tests/test_host_mirror.py);
+        every other pandas -- and every column that is not a plain float64 vector of the frame's length -- goes through
+        the public `__setitem__` and pays the copy."""
+        fast = (_PANDAS_MAJOR == 2 and hasattr(self, "_set_item_mgr") and name in self.columns
+                and isinstance(values, np.ndarray) and values.dtype == np.float64 and values.ndim == 1
+                and len(values) == len(self.index))
+        if fast:
+            try:
+                self._set_item_mgr(name, values)
+                return
+            except (TypeError, AttributeError):           # another signature after all: the public road
+                pass
+        self[name] = values
 
     # ---- I/O (pointcloud.py:219-226) ------------------------------------------------------
     def write_xyz(self, file: Path):

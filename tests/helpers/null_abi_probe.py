@@ -44,6 +44,9 @@ def build_calls():
         "sicp_comm_unique_id": lambda: L.sicp_comm_unique_id(None),
         "sicp_comm_init": lambda: L.sicp_comm_init(None, None, 0, 1, 0),
         "sicp_comm_destroy": lambda: L.sicp_comm_destroy(None),
+        "sicp_comm_activate": lambda: L.sicp_comm_activate(None, 1, 0),
+        "sicp_comm_info": lambda: L.sicp_comm_info(None, None),
+        "sicp_device_memory": lambda: L.sicp_device_memory(None, None, None),
         "sicp_set_partition": lambda: L.sicp_set_partition(None, 0),
         "sicp_ctx_stream": lambda: L.sicp_ctx_stream(None, C.byref(vp)),
         "sicp_lexmin_gathered": lambda: L.sicp_lexmin_gathered(None, None, 1, 1, None, None, None),

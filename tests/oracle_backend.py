@@ -244,6 +244,9 @@ class OracleContext:
     def comm_destroy(self):
         pass
 
+    def comm_activate(self, on=True, gn_shard=False):
+        pass
+
     def set_partition(self, mode):
         pass
 

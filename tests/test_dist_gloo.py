@@ -171,6 +171,9 @@ class _FakeCtx:
     def comm_destroy(self):
         self.calls.append(("comm_destroy",))
 
+    def comm_activate(self, on=True, gn_shard=False):
+        self.calls.append(("comm_activate", bool(on)))
+
     def set_exchange(self, fn, rank, world, gn_shard=False):
         self.calls.append(("callback", rank, world))
 
@@ -189,6 +192,12 @@ def _worker_attach(rank, world, port, tmp):
         # every rank's communicator comes up -> the library-owned RCCL path on every rank
         c = _FakeCtx(rank, fail_on=None)
         assert dist.attach(c, partition=1) == "rccl" and ("comm_init", rank, world) in c.calls and ("callback", rank, world) not in c.calls
+        # the communicator stays with the context: end of the run parks it, the next run on the same group switches it back
+        # on without another rendezvous
+        dist.detach(c)
+        assert c.calls[-3:] == [("comm_activate", False), ("callback", 0, 1), ("partition", 0)]
+        n_init = sum(x[0] == "comm_init" for x in c.calls)
+        assert dist.attach(c) == "rccl" and c.calls[-1] == ("comm_activate", True) and sum(x[0] == "comm_init" for x in c.calls) == n_init
         # ONE rank fails -> ALL ranks drop their communicator and register the callback exchange
         c = _FakeCtx(rank, fail_on=1)
         assert dist.attach(c) == "callback" and ("comm_destroy",) in c.calls and c.calls[-1] == ("callback", rank, world)
