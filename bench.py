@@ -105,6 +105,29 @@ def load_workload(name, points=None, correspondences=None):
     return Xf, Xm, H_true, Q, cfg["k"], cfg["kwargs"], desc
 
 
+def csrc_hash():
+    """sha256 over the kernel sources (name + bytes, sorted): what a committed PMC summary is valid for."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "simpleicp_amd" / "csrc").iterdir()):
+        if f.suffix in (".hip", ".cpp", ".h"):
+            h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    """profiles/latest_pmc.json (HBM bytes per launch and kernel from separate rocprofv3 --pmc passes, written by
+    scripts/summarize_profile.py) -- only if it was measured on THESE kernel sources; a stale file would describe other kernels."""
+    pmc_file = ROOT / "profiles" / "latest_pmc.json"
+    if not pmc_file.exists():
+        return {}, None
+    pmc = json.loads(pmc_file.read_text())
+    if pmc.get("_csrc_hash") != csrc_hash():
+        return {}, (f"profiles/latest_pmc.json is stale (measured on csrc {pmc.get('_csrc_hash')}, this tree is {csrc_hash()}): "
+                    "traffic withheld")
+    return pmc, f"profiles/latest_pmc.json ({pmc.get('_note', 'separate rocprofv3 --pmc passes')}); NOT collected in this run"
+
+
 def iterate(ctx, n_it, x, obs, ow):
     """n_it iterations of the hot path behind one ABI call (sicp_icp_run; min_change=0 never converges early)."""
     if n_it <= 0:
@@ -133,6 +156,10 @@ def parse_args(argv=None):
                          "queries (cloud replicated, default from 1e5 correspondences)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="register the multi-GPU exchange even with one rank (measures its overhead on one GPU)")
+    ap.add_argument("--throughput-q", type=str, default="100000,1000000",
+                    help="correspondence counts of the `throughput_point` legs (synthetic configs; same clouds, same K steps "
+                         "from cold; N > 1: under query shards); 0 = none")
+    ap.add_argument("--throughput-repeats", type=int, default=7)
     ap.add_argument("--out", type=str, default=None, help="also write the JSON line to this file")
     return ap.parse_args(argv)
 
@@ -281,6 +308,16 @@ def run(args):
 
     # parity leg, device side (every rank takes part in the exchange; only rank 0 consults the oracle)
     parity_rec = None if args.no_parity else parity_device(ctx, sel, normals, planarity, obs, ow)
+    comm = comm_record(ctx, exchange, transport, qshard, world, hi - lo, len(sel), timing, args.steps)
+
+    # throughput legs ("additionally Q = 100 k for a throughput point"): same clouds, Q large enough that the
+    # machine is full; N > 1: query shards (the whole cloud on every rank, Q / N queries each)
+    tps = []
+    tq = [int(v) for v in args.throughput_q.split(",") if v.strip() and int(v) > 0] if H_true is not None else []
+    for Qt in tq:
+        if Qt == len(sel) or Qt > Nf:
+            continue
+        tps.append(throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu))
 
     if rank != 0:
         if exchange:
@@ -300,16 +337,12 @@ def run(args):
     evals_per_it = ne_evals / args.steps
     bytes_bruteforce = n_local * 24 + nq * (24 + 16)        # read the searched cloud once + queries + (idx, d2)
     bytes_solve = int(last.n_kept) * 72 * evals_per_it + (nq * 8 * 3 if fused else 0)
-    pmc, pmc_src = {}, None
-    pmc_file = ROOT / "profiles" / "latest_pmc.json"
-    if pmc_file.exists():
-        pmc = json.loads(pmc_file.read_text())
-        pmc_src = f"profiles/latest_pmc.json ({pmc.get('_note', 'separate rocprofv3 --pmc passes')}); NOT collected in this run"
+    pmc, pmc_src = load_pmc()
 
     def roof(kernel, ms, bytes_alg, note, extra=None):
         ach = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-             "traffic": pmc.get(kernel), "traffic_source": pmc_src if pmc.get(kernel) is not None else None,
+             "traffic": pmc.get(kernel), "traffic_source": pmc_src if (pmc.get(kernel) is not None or not pmc) else None,
              "kernel": kernel, "avg_ms": ms, "bytes_alg_per_launch": int(bytes_alg), "note": note}
         if extra:
             d.update(extra)
@@ -387,8 +420,16 @@ def run(args):
     if H_true is not None:
         out["accuracy"] = {"max_abs_H_minus_H_true": float(np.abs(H - H_true).max())}
 
+    if comm is not None:
+        out["comm"] = comm
     if parity_rec is not None:
         out["parity"] = parity_oracle(parity_rec, Xf, Xm, sel, normals, planarity, obs, ow)
+    for i, tp in enumerate(tps):
+        if "_parity_args" in tp:
+            # sampled oracle leg, 1e10 pairs (the full-size legs of tests/test_gpu_fullsize.py check 3 000 queries per iteration)
+            rec_t, sel_t, nv_t, pl_t, obs_t, ow_t = tp.pop("_parity_args")
+            tp["parity"] = parity_oracle(rec_t, Xf, Xm, sel_t, nv_t, pl_t, obs_t, ow_t, pair_cap=1e10)
+        out["throughput_point" if i == 0 else f"throughput_point_q{tp['correspondences']}"] = tp
     if world == 1 and not args.no_end_to_end:
         out["run_end_to_end"] = end_to_end(Xf, Xm, Q, k, kw)
     if world == 1 and not args.no_bruteforce_leg and Nm * nq <= 2e11:
@@ -419,12 +460,133 @@ def run(args):
     print(line, flush=True)
 
 
-def parity_device(ctx, sel, normals, planarity, obs, ow):
+def comm_record(ctx, exchange, transport, qshard, world, shard_rows, nq, timing, steps):
+    """What exchange ran, as the library itself reports it (sicp_comm_info: for RCCL the rank count comes from
+    ncclCommCount, not from what this script believes), and what it cost per iteration."""
+    if not exchange:
+        return None
+    info = ctx.comm_info()
+    x = timing.get("exchange", {"ms": 0.0, "launches": 0})
+    return {"backend": info["backend"], "nranks": info["nranks"], "rank": info["rank"], "partition": info["partition"],
+            "gn_shard": info["gn_shard"], "transport_chosen_by_attach": transport,
+            "shard_rows_this_rank": int(shard_rows), "queries_this_rank": int((nq + world - 1) // world if qshard else nq),
+            "exchange_us_per_iteration": x["ms"] * 1e3 / max(1, x["launches"]), "exchanges_timed": x["launches"],
+            "note": "pack + collective + unpack / lexicographic minimum, HIP events on the library's stream (instrumented pass)"}
+
+
+def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu):
+    """The same clouds with Qt correspondences: K steps from the cold state, repeated; kernel split, the grid search's own
+    bytes, parity.  Every rank calls this; rank 0 gets the record."""
+    import torch
+    import torch.distributed as td
+    from simpleicp_amd import _lib, dist
+    Nf, Nm = len(Xf), len(Xm)
+    sel = np.unique(np.round(np.linspace(0, Nf - 1, Qt)).astype(np.int64))
+    nq = len(sel)
+    transport = None
+    if exchange:
+        # query shards: every rank the whole movable cloud
+        dist.detach(ctx)
+        ctx.upload(_lib.MOV, Xm)
+        transport = dist.attach(ctx, gn_shard=False, partition=_lib.PART_QUERIES)
+    ctx.timing_enable(False)
+    t0 = time.perf_counter()
+    normals, planarity = ctx.estimate_normals(_lib.FIX, sel, k)
+    normals_ms = (time.perf_counter() - t0) * 1e3
+    obs, ow = np.zeros(6), np.zeros(6)
+
+    def cold():
+        ctx.icp_setup(sel, normals, planarity)
+
+    cold()
+    iterate(ctx, 2, obs.copy(), obs, ow)                          # grid build (after a re-upload), allocations
+    times = []
+    for _ in range(max(1, args.throughput_repeats)):
+        cold()
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x, ne_evals, last = iterate(ctx, args.steps, obs.copy(), obs, ow)
+        torch.cuda.synchronize()
+        if world > 1:
+            td.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            el = float(t.item())
+        times.append(el)
+    times = np.array(times)
+    elapsed = float(np.median(times))
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    cold()
+    iterate(ctx, args.steps, obs.copy(), obs, ow)
+    timing = ctx.timing()
+    kern = ctx.last_match_kernel()
+    ctx.timing_enable(True, count_work=True)
+    ctx.timing_reset()
+    cold()
+    iterate(ctx, args.steps, obs.copy(), obs, ow)
+    work = ctx.match_work()
+    ctx.timing_enable(False)
+    rec = None if args.no_parity else parity_device(ctx, sel, normals, planarity, obs, ow, iterations=1)
+    comm = comm_record(ctx, exchange, transport, True, world, Nm, nq, timing, args.steps)
+    if rank != 0:
+        return None
+    avg = {name: v["ms"] / max(1, v["launches"]) for name, v in timing.items()}
+    nq_local = (nq + world - 1) // world if exchange else nq
+    per = {kk: v / max(1, work["launches"]) for kk, v in work.items() if kk != "launches"}
+    bytes_match = per["candidates"] * 32 + per["rows"] * 8 + nq_local * (24 + 24 + 48)
+    pmc, pmc_src = load_pmc()
+    tag = f"@Q{Qt}"
+
+    def roof(kernel, ms, bytes_alg, note, extra=None):
+        ach = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "traffic": pmc.get(kernel + tag), "traffic_source": pmc_src if (pmc.get(kernel + tag) is not None or not pmc) else None,
+             "kernel": kernel, "avg_ms": ms, "bytes_alg_per_launch": int(bytes_alg), "note": note}
+        d.update(extra or {})
+        return d
+
+    evals = ne_evals / args.steps
+    out = {"correspondences": nq, "n_fixed": Nf, "n_movable": Nm, "n_gpus": world, "steps": args.steps,
+           "ms_per_step": elapsed / args.steps * 1e3, "iterations_per_s": args.steps / elapsed,
+           "correspondences_per_s": nq * args.steps / elapsed,
+           "repeat_stats": {"repeats": len(times), "ms_per_step_p10": float(np.percentile(times, 10)) / args.steps * 1e3,
+                            "ms_per_step_p90": float(np.percentile(times, 90)) / args.steps * 1e3,
+                            "timed_region": "K steps from the cold state (icp_setup just called), min_change=0, events off"},
+           "parallelism": f"query shards x{world}, movable cloud replicated" if exchange else "1 GPU",
+           "roofline": roof(kern, avg["match"], bytes_match,
+                            "exact 1-NN on the static grid, four cell-ordered queries per wave; bytes = the candidates (32-B records) and "
+                            "grid rows the search itself tallied + 96 B per query; scattered 32..512-B reads: bandwidth- and "
+                            "issue-bound", {"candidates_per_query": per["candidates"] / max(1, nq_local),
+                                           "grid_rows_per_query": per["rows"] / max(1, nq_local),
+                                           "pruning_ratio": (Nm * 24 + nq_local * 40) / max(1.0, bytes_match)}),
+           "roofline_solver": roof("k_lm_eval", avg["solve"], int(last.n_kept) * 72 * evals,
+                                   "the iteration's solver launches together (evaluations + finish): 72 B per kept correspondence and "
+                                   "evaluation, 8x8 Gram on the FP64 matrix pipe", {"evaluations_per_iteration": evals}),
+           "roofline_rejection": roof("k_hsel_pass" if nq > 16384 else "k_reject", avg["reject_select"], nq * 9 * (5 if nq > 16384 else 1),
+                                      "distances' median / MAD by digit selection + keep mask + statistics: 9 B per correspondence and pass "
+                                      "(two selection passes each for median and MAD, one keep / statistics pass)"),
+           "kernels_instrumented": {name: {"avg_ms": avg[name], "launches": timing[name]["launches"]} for name in timing},
+           "setup": {"normals_ms": normals_ms},
+           "solver": {"final_n_kept": int(last.n_kept), "final_res_std": last.res_std}}
+    if comm is not None:
+        out["comm"] = comm
+    if rec is not None:
+        # the oracle leg runs on the host after every GPU leg is over (the other ranks must not wait in a collective for it)
+        out["_parity_args"] = (rec, sel, normals, planarity, obs, ow)
+    return out
+
+
+def parity_device(ctx, sel, normals, planarity, obs, ow, iterations=2):
     """Outside the timed region: two iterations from the cold state through the product path; what they produced."""
     rec = []
     x = obs.copy()
     ctx.icp_setup(sel, normals, planarity)
-    for it in range(2):
+    for it in range(iterations):
         R = ctx.icp_iterate(x, obs, ow, 0.3, 1.0)
         idx, dist, keep, _ = ctx.icp_state()
         rec.append((x.copy(), R, idx, dist, keep))
@@ -432,13 +594,13 @@ def parity_device(ctx, sel, normals, planarity, obs, ow):
     return rec
 
 
-def parity_oracle(rec, Xf, Xm, sel, normals, planarity, obs, ow):
+def parity_oracle(rec, Xf, Xm, sel, normals, planarity, obs, ow, pair_cap=3e10):
     """... checked against the CPU oracle (brute-force match, distances, rejection, solve).  At Q x N_m <= 3e10 pairs
     the oracle runs the whole problem; above that a bounded sample of the queries is checked (the match is per
     query, so a sample pins it just as well)."""
     from oracle import orc
     nq = len(sel)
-    cap = int(3e10 // len(Xm))
+    cap = int(pair_cap // len(Xm))
     out = {"oracle": "oracle/sicp_oracle.c (brute-force CPU restatement, pinned against the unmodified reference)",
            "iterations_checked": len(rec)}
     ok_all = True

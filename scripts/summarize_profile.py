@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/prof_<tag>/ (scripts/gpu_profile.sh) into the committed summaries under
-profiles/<tag>/ and profiles/latest_pmc.json (per-kernel HBM bytes per launch, read by bench.py).
+"""Turn gpurun_out/prof_<tag>[_q<Q>]/ (scripts/gpu_profile.sh) into the committed summaries under profiles/<tag>/ and
+profiles/latest_pmc.json (per-kernel HBM bytes per launch, read by bench.py).
 
-HBM bytes per launch = FETCH_SIZE * cal + WRITE_SIZE  (both counters are in KiB).  On gfx950
-FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section); `cal` is
-measured in the same run on k_aos_to_soa, whose read volume is known (24 B per point)."""
+    python scripts/summarize_profile.py r3            # prof_r3 (default line) + every prof_r3_q<Q> (large-Q legs)
+
+HBM bytes per launch = FETCH_SIZE * cal + WRITE_SIZE  (both counters are in KiB).  On gfx950 FETCH_SIZE under-reports wide
+coalesced reads by 2x (MI355X_MICROARCH.md, HBM section); `cal` is measured in the same run on k_aos_to_soa, whose read volume
+is known (24 B per point).  Kernels of a large-Q leg are keyed "<kernel>@Q<Q>".  The file is stamped with the hash of the kernel
+sources it was measured on (bench.csrc_hash): bench.py withholds `traffic` when the tree has moved on."""
 import collections
 import csv
 import glob
@@ -15,9 +18,10 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 tag = sys.argv[1]
-src = ROOT / "gpurun_out" / f"prof_{tag}"
 dst = ROOT / "profiles" / tag
 dst.mkdir(parents=True, exist_ok=True)
+WATCH = ("grid_nn", "icp_tail", "knn1_f", "lm_eval", "lm_finish", "lm_advance", "k_reject", "k_scatter", "k_cell_ids", "k_cloud_stats",
+         "hsel", "keep_stats", "postmatch", "grid_knn", "k_normals", "query_order", "pack_best", "lexmin")
 
 
 def short(name):
@@ -32,61 +36,83 @@ def newest(pattern):
     return [max(files, key=lambda f: Path(f).stat().st_mtime)] if files else []
 
 
-stats = newest(str(src / "trace" / "**" / "*kernel_stats.csv"))
-if stats:
-    shutil.copy(stats[0], dst / "kernel_stats.csv")
-for f in ("bench_trace.json",):
-    if (src / f).exists():
-        shutil.copy(src / f, dst / "bench_under_rocprof.json")
-
-per = collections.defaultdict(dict)
-for tagc, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    files = newest(str(src / tagc / "**" / "*counter_collection.csv"))
-    if not files:
-        continue
+def counters(src, tagc):
+    """(kernel, counter) -> (total, launches) of one PMC pass (aggregated on the GPU box, or the raw dump of older runs)."""
     agg = collections.defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(files[0])):
-        if r["Counter_Name"] != counter:
-            continue
-        a = agg[short(r["Kernel_Name"])]
-        a[0] += float(r["Counter_Value"]); a[1] += 1
-    with open(dst / f"{tagc}_summary.csv", "w") as o:
-        o.write("kernel,counter,launches,total_KiB,per_launch_KiB\n")
-        for k, (v, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-            o.write(f"{k},{counter},{n},{v:.6g},{v / n:.6g}\n")
-            per[k][counter] = v / n * 1024.0
+    files = newest(str(src / tagc / "**" / "counter_summary.csv"))
+    if files:
+        for r in csv.DictReader(open(files[0])):
+            a = agg[(short(r["Kernel_Name"]), r["Counter_Name"])]
+            a[0] += float(r["total"]); a[1] += int(r["launches"])
+        return agg
+    for f in newest(str(src / tagc / "**" / "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            a = agg[(short(r["Kernel_Name"]), r["Counter_Name"])]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+    return agg
 
-# SQ counter passes -> one text summary (per-launch averages of the kernels of the default path and the brute-force leg)
-lines = []
-for tagc in ("pmc_sq1", "pmc_sq2"):
-    files = newest(str(src / tagc / "**" / "*counter_collection.csv"))
-    if not files:
+
+def one(src, suffix):
+    """summaries of one profile directory; returns {kernel: HBM bytes per launch}"""
+    sfx = f"_{suffix}" if suffix else ""
+    stats = newest(str(src / "trace" / "**" / "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], dst / f"kernel_stats{sfx}.csv")
+    if (src / "bench_trace.json").exists():
+        shutil.copy(src / "bench_trace.json", dst / f"bench_under_rocprof{sfx}.json")
+    per = collections.defaultdict(dict)
+    for tagc, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        agg = {k: v for (k, c), v in counters(src, tagc).items() if c == counter}
+        if not agg:
+            continue
+        with open(dst / f"{tagc}_summary{sfx}.csv", "w") as o:
+            o.write("kernel,counter,launches,total_KiB,per_launch_KiB\n")
+            for k, (v, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+                o.write(f"{k},{counter},{n},{v:.6g},{v / n:.6g}\n")
+                per[k][counter] = v / n * 1024.0
+    lines = []
+    for tagc in ("pmc_sq1", "pmc_sq2"):
+        agg = collections.defaultdict(dict)
+        for (k, c), (v, n) in counters(src, tagc).items():
+            if any(x in k for x in WATCH):
+                agg[k][c] = v / n
+        if agg:
+            lines.append(f"# {tagc}: rocprofv3 --pmc pass over bench.py (scripts/gpu_profile.sh {src.name[5:]}), per-launch averages")
+            for k, d in sorted(agg.items()):
+                lines.append(k + " " + str({c: f"{v:.4g}" for c, v in sorted(d.items())}))
+    if lines:
+        (dst / f"pmc_sq_summary{sfx}.txt").write_text("\n".join(lines) + "\n")
+    bench = {}
+    try:
+        bench = json.loads((src / "bench_trace.json").read_text().strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        pass
+    n_pts = bench.get("config", {}).get("n_fixed", 10_000_000)
+    cal = 2.0
+    if "k_aos_to_soa" in per and per["k_aos_to_soa"].get("FETCH_SIZE"):
+        cal = n_pts * 24.0 / per["k_aos_to_soa"]["FETCH_SIZE"]
+    return {k: d.get("FETCH_SIZE", 0.0) * cal + d.get("WRITE_SIZE", 0.0) for k, d in per.items()}, cal
+
+
+out = {}
+base = ROOT / "gpurun_out" / f"prof_{tag}"
+hashes = set()
+notes = []
+for src in [base] + sorted(ROOT.glob(f"gpurun_out/prof_{tag}_q*")):
+    if not src.exists():
         continue
-    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
-    for r in csv.DictReader(open(files[0])):
-        k = short(r["Kernel_Name"])
-        if not any(x in k for x in ("grid_nn", "icp_tail", "knn1_f", "lm_eval", "lm_finish", "k_reject", "k_scatter", "k_cell_ids", "k_cloud_stats")):
-            continue
-        a = agg[k][r["Counter_Name"]]
-        a[0] += float(r["Counter_Value"]); a[1] += 1
-    lines.append(f"# {tagc}: rocprofv3 --pmc pass over bench.py (scripts/gpu_profile.sh), per-launch averages")
-    for k, d in sorted(agg.items()):
-        lines.append(k + " " + str({c: f"{v / n:.4g}" for c, (v, n) in sorted(d.items())}))
-if lines:
-    (dst / "pmc_sq_summary.txt").write_text("\n".join(lines) + "\n")
-
-bench = {}
-try:
-    bench = json.loads((src / "bench_trace.json").read_text().strip().splitlines()[-1])
-except Exception:
-    pass
-n_pts = bench.get("config", {}).get("n_fixed", 10_000_000)
-cal = 2.0
-if "k_aos_to_soa" in per and per["k_aos_to_soa"].get("FETCH_SIZE"):
-    cal = n_pts * 24.0 / per["k_aos_to_soa"]["FETCH_SIZE"]
-out = {"_note": f"HBM bytes per launch = FETCH_SIZE*{cal:.3f} + WRITE_SIZE (KiB counters); cal from k_aos_to_soa; profile tag {tag}"}
-for k, d in per.items():
-    out[k] = d.get("FETCH_SIZE", 0.0) * cal + d.get("WRITE_SIZE", 0.0)
-(ROOT / "profiles" / "latest_pmc.json").write_text(json.dumps(out, indent=1))
-(dst / "hbm_bytes_per_launch.json").write_text(json.dumps(out, indent=1))
+    suffix = src.name[len(f"prof_{tag}"):].lstrip("_")
+    per, cal = one(src, suffix)
+    key = f"@Q{suffix[1:]}" if suffix else ""
+    for k, v in per.items():
+        out[k + key] = v
+    notes.append(f"{src.name}: cal {cal:.3f}")
+    h = src / "csrc_hash.txt"
+    if h.exists():
+        hashes.add(h.read_text().strip())
+out["_note"] = ("HBM bytes per launch = FETCH_SIZE*cal + WRITE_SIZE (KiB counters; cal from k_aos_to_soa of the same run, "
+                f"gfx950 under-reports wide reads 2x); {'; '.join(notes)}; '<kernel>@Q<n>' = the leg with n correspondences")
+out["_csrc_hash"] = hashes.pop() if len(hashes) == 1 else None
+(ROOT / "profiles" / "latest_pmc.json").write_text(json.dumps(out, indent=1) + "\n")
+(dst / "hbm_bytes_per_launch.json").write_text(json.dumps(out, indent=1) + "\n")
 print(json.dumps(out, indent=1))

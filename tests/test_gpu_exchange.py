@@ -41,13 +41,14 @@ import os, sys, numpy as np, torch, torch.distributed as td
 sys.path.insert(0, "%(root)s"); sys.path.insert(0, "%(root)s/tests")
 from conftest import load_golden, load_cloud
 from simpleicp_amd import PointCloud, SimpleICP
-def run():
-    g, files, kw = load_golden("bunny")
+def run(name="bunny"):
+    g, files, kw = load_golden(name)
     pf = PointCloud(load_cloud(files[0]), columns=["x", "y", "z"]); pm = PointCloud(load_cloud(files[1]), columns=["x", "y", "z"])
     icp = SimpleICP(verbose=False); icp.add_point_clouds(pf, pm)
     H, X, rbp, res = icp.run(**kw)
     return H, X, res, icp.last_run_info["iterations"]
 H0, X0, r0, it0 = run()                                # no process group: plain single-GPU path
+B0 = run("dragon_q5000")                               # ... and a case above 2048 correspondences (the many-workgroup solver)
 from simpleicp_amd import backend
 os.environ["SICP_SOLVE"] = "host"; backend.reset_context()
 Hh, Xh, rh, ith = run()                                # multi-kernel tail + host LM (what gn_shard builds on)
@@ -58,9 +59,18 @@ td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda
 H1, X1, r1, it1 = run()                                # same job through the library's own RCCL communicator (1 rank)
 assert it0 == it1 and np.array_equal(H0, H1) and np.array_equal(X0, X1) and np.array_equal(r0, r1), (H0 - H1)
 assert ith == it0 and np.abs(Hh - H0).max() < 1e-9     # device LM vs host LM: same minimiser
+from simpleicp_amd import backend as _b
+info = _b.get_context().comm_info()
+assert info["communicator"] and info["backend"] == "none", info      # parked between runs, kept for the next one
 os.environ["SICP_GN_SHARD"] = "1"
-H2, X2, r2, it2 = run()                                # + sharded 6x6 reduction with a SUM all-reduce per solver step
-assert it2 == ith and np.array_equal(H2, Hh) and np.array_equal(r2, rh), (H2 - Hh)
+H2, X2, r2, it2 = run()                                # sharded 6x6 reduction requested: the single-workgroup tail (Q <= 2048) ignores it
+assert it2 == it0 and np.array_equal(H2, H0) and np.array_equal(r2, r0), (H2 - H0)
+B2 = run("dragon_q5000")                               # Q = 5000: every evaluation's 8x8 Gram block through ncclAllReduce, then k_lm_advance
+assert B2[3] == B0[3] and np.abs(B2[0] - B0[0]).max() < 1e-12 and np.abs(B2[2] - B0[2]).max() < 1e-12, (B2[0] - B0[0])
+os.environ["SICP_SOLVE"] = "host"; backend.reset_context()
+H7, X7, r7, it7 = run()                                # the host-side solve with its 30 sums all-reduced per step
+assert it7 == ith and np.array_equal(H7, Hh) and np.array_equal(r7, rh), (H7 - Hh)
+del os.environ["SICP_SOLVE"]; backend.reset_context()
 del os.environ["SICP_GN_SHARD"]
 os.environ["SICP_PARTITION"] = "queries"
 H4, X4, r4, it4 = run()                                # query shards (cloud replicated): slices gathered in rank order
@@ -70,8 +80,8 @@ os.environ["SICP_XCHG"] = "callback"
 H5, X5, r5, it5 = run()                                # collectives supplied by the host: torch.distributed callback
 assert it5 == it0 and np.array_equal(H5, H0) and np.array_equal(r5, r0)
 os.environ["SICP_GN_SHARD"] = "1"
-H6, X6, r6, it6 = run()
-assert it6 == ith and np.array_equal(H6, Hh) and np.array_equal(r6, rh), (H6 - Hh)
+B6 = run("dragon_q5000")                               # the sharded reduction with the SUM supplied by the host callback
+assert B6[3] == B0[3] and np.abs(B6[0] - B0[0]).max() < 1e-12 and np.abs(B6[2] - B0[2]).max() < 1e-12
 os.environ["SICP_XCHG_SYNC"] = "1"; del os.environ["SICP_GN_SHARD"]
 H3, X3, r3, it3 = run()                                # blocking variant of the callback
 td.destroy_process_group()
@@ -114,7 +124,8 @@ res["queries"] = run()                                  # every rank the whole c
 res["queries_odd"] = run(correspondences=999)           # ... of unequal length (the last rank's slice is one short)
 del os.environ["SICP_PARTITION"]
 os.environ["SICP_GN_SHARD"] = "1"
-res["gn"] = run()                                       # + the 6x6 reduction sharded (SUM all-reduce per solver step)
+res["gn"] = run()                                       # + the 6x6 reduction sharded: ignored by the single-workgroup tail (Q <= 2048)
+res["gn_q5000"] = run("dragon_q5000")                   # Q = 5000: two real slices, one SUM of the 8x8 Gram block per evaluation
 del os.environ["SICP_GN_SHARD"]
 res["dragon_q5000"] = run("dragon_q5000")               # Q > 2048: the large-Q chain between the exchanges
 td.barrier()
@@ -160,6 +171,8 @@ def test_two_ranks_sharing_one_gpu_agree_with_one_rank(tmp_path):
                 and np.array_equal(z[key + "_r"], res), (key, r, np.abs(z[key + "_H"] - H).max())
         H, X, res, it = ref["bunny"]
         assert int(z["gn_it"]) == it and np.abs(z["gn_H"] - H).max() < 1e-9
+        H, X, res, it = ref["dragon_q5000"]               # sums grouped by rank: equal to rounding, residuals of BOTH slices current
+        assert int(z["gn_q5000_it"]) == it and np.abs(z["gn_q5000_H"] - H).max() < 1e-9 and np.abs(z["gn_q5000_r"] - res).max() < 1e-9
 
 
 @pytest.mark.parametrize("partition,launcher", [("cloud", "self"), ("queries", "self"), ("cloud", "torchrun")])
@@ -173,7 +186,8 @@ def test_bench_two_ranks_self_launched(partition, launcher):
     import socket
     env = dict(os.environ, SICP_BENCH_SHARE_GPU="1")
     args = [str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--repeats", "2", "--points", "300000",
-            "--partition", partition, "--no-cpu-baseline", "--no-end-to-end", "--no-bruteforce-leg"]
+            "--partition", partition, "--no-cpu-baseline", "--no-end-to-end", "--no-bruteforce-leg", "--throughput-q", "40000",
+            "--throughput-repeats", "2"]
     if launcher == "torchrun":
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
@@ -189,3 +203,10 @@ def test_bench_two_ranks_self_launched(partition, launcher):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["value"] > 0
     assert d["parity"]["ok"] is True, d["parity"]
     assert "callback" in d["config"]["parallelism"] and ("query" in d["config"]["parallelism"]) == (partition == "queries")
+    # the record says what exchange ran, as the library counts it
+    assert d["comm"]["backend"] == "callback" and d["comm"]["nranks"] == 2 and d["comm"]["partition"] == partition, d["comm"]
+    assert d["comm"]["exchanges_timed"] == 6 and d["comm"]["exchange_us_per_iteration"] > 0
+    # the throughput leg ran under query shards on both ranks and met the oracle
+    tp = d["throughput_point"]
+    assert tp["n_gpus"] == 2 and tp["comm"]["partition"] == "queries" and tp["comm"]["queries_this_rank"] == (tp["correspondences"] + 1) // 2
+    assert tp["parity"]["ok"] is True and tp["roofline"]["kernel"] in ("k_grid_nn", "k_grid_nn16"), tp
