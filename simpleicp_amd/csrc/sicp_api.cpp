@@ -307,6 +307,10 @@ struct sicp_ctx {
     int lm_evals = 4;              // evaluations enqueued per iteration for Q > SOLVE_MAX_Q (SICP_LM_EVALS; k_lm_finish completes the rest)
     double *h_rec = nullptr;       // pinned ring of per-iteration records the tail kernel streams to the host
     IcpDev *h_state = nullptr;     // pinned staging of the loop state
+    unsigned long long hsel_bar = 0;   // what the one-launch rejection's launches have added to its barrier counter so far
+    bool hsel_one_launch = true;   // SICP_HSEL=launches: the launch-per-phase form (A/B)
+    bool hsel_dirty = false;
+    bool match_epilogue = true;    // SICP_MATCH_EPILOGUE=0: distances + verdicts by k_postmatch even without an exchange (A/B)
     int chain_depth = 4;           // iterations enqueued ahead of the last record read (SICP_CHAIN_DEPTH)
     // exchange: an RCCL communicator of the library's own (sicp_comm_init) or a host callback (sicp_set_exchange)
     sicp_exchange_fn xfn = nullptr;
@@ -496,6 +500,35 @@ void plan_chunks(const sicp_ctx *c, long npad, long qblocks, size_t bytes_per_ch
     long tiles_per_chunk = (tiles + want - 1) / want;
     *chunk_pts = (int)(tiles_per_chunk * TILE_PTS);
     *nchunks = (int)((tiles + tiles_per_chunk - 1) / tiles_per_chunk);
+}
+
+// median / MAD rejection + keep mask + kept statistics for Q > REJECT_MAX_Q: ONE launch with grid barriers (default) or the
+// launch-per-phase form (SICP_HSEL=launches)
+int reject_select(sicp_ctx *c, long Q, double *host_out, double seq, const IcpDev *st)
+{
+    const size_t words = (reject_select_scratch_bytes() + 7) / 8;
+    if (c->rj_keys.cap < words) {
+        CHK(c->rj_keys.reserve(words));
+        HIPCHK(hipMemsetAsync(c->rj_keys.p, 0, words * 8, c->stream));      // the one-launch form keeps its state clean from here on
+        HIPCHK(hipMemsetAsync((char *)c->rj_keys.p + 8, 0xff, 16, c->stream));  // (HselAll::nxt[2] rests at ~0)
+        c->hsel_bar = 0;
+    }
+    hipError_t e;
+    if (c->hsel_one_launch) {
+        if (c->hsel_dirty) {                                                 // the other form ran in between (tests): start clean
+            HIPCHK(hipMemsetAsync(c->rj_keys.p, 0, words * 8, c->stream));
+            HIPCHK(hipMemsetAsync((char *)c->rj_keys.p + 8, 0xff, 16, c->stream));
+            c->hsel_bar = 0; c->hsel_dirty = false;
+        }
+        e = reject_by_select_one_launch(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
+                                        &c->hsel_bar, c->ne_partial.p, host_out, seq, st);
+    } else {
+        c->hsel_dirty = true;
+        e = reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
+                             (unsigned long long *)(c->small.p + 56), c->ne_partial.p, c->ticket.p, host_out, seq, st);
+    }
+    if (e != hipSuccess) return fail(SICP_ERR_HIP, "rejection by digit selection failed: %s", hipGetErrorString(e));
+    return SICP_OK;
 }
 
 int check_slot(sicp_ctx *c, int slot, bool need_data)
@@ -1018,6 +1051,8 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_REJECT_SPLIT")) c->reject_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_COARSE_ITERS")) c->coarse_iters = std::atoi(e);
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
+    if (const char *e = std::getenv("SICP_HSEL")) c->hsel_one_launch = std::strcmp(e, "launches") != 0;
+    if (const char *e = std::getenv("SICP_MATCH_EPILOGUE")) c->match_epilogue = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_XCHG_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) c->xchg_timeout_s = v; }
     if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
     if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : !std::strcmp(e, "mfma") ? 2 : 0;
@@ -1441,6 +1476,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
             const auto h0 = std::chrono::steady_clock::now();
             const double *prev = c->have_prev_match ? c->m_p2.p : nullptr;
             const bool qshard = c->collective() && c->partition == SICP_PART_QUERIES;
+            bool post_done = false;             // distances + planarity verdicts already written by the match kernel
             if (grid) {
                 // (query shards: this rank searches its slice of the queries in the whole cloud, results land in
                 // their place in the full arrays)
@@ -1463,12 +1499,16 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                                            cl.sub_grid.g, cl.sub_grid.cell_start.p, cl.sub_grid.rec.p, c->icp_dev.p, cl.rmax, 0,
                                            c->bound_d2.p + lo, c->bound_idx.p + lo, c->bound_p2.p + 3 * lo, nullptr,
                                            ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q);
+                // without an exchange the match is final when its kernel ends: the winning lanes leave the point-to-plane
+                // distance and the planarity verdict too (what k_postmatch would re-read 72 bytes per correspondence for)
+                post_done = !c->collective() && c->match_epilogue;
+                PostMatch pm = {c->normals.p, c->planarity.p, A.pl2, A.pl2_n, A.min_planarity, c->dist.p, c->flag.p};
                 if (cnt > 0)
                     launch_grid_nn_chained(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt,
                                            coarse ? c->bound_p2.p + 3 * lo : (prev ? prev + 3 * lo : nullptr), cl.grid.g,
                                            cl.grid.cell_start.p, cl.grid.rec.p, c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p + lo,
                                            c->m_idx.p + lo, c->m_p2.p + 3 * lo, c->count_work ? c->match_work.p : nullptr,
-                                           ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q, coarse);
+                                           ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q, coarse, post_done ? &pm : nullptr);
             } else if (qshard) {
                 return fail(SICP_ERR_INVALID, "query shards need the grid search (SICP_KNN1 forces another kernel)");
             } else {
@@ -1486,20 +1526,24 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
             seqs[launched % REC_RING] = A.seq;
             double *rec = c->h_rec + (launched % REC_RING) * REC_DOUBLES;
             const double *qx = c->q.p, *qy = c->q.p + c->qpad, *qz = c->q.p + 2 * c->qpad;
+            Xf unused = {};
             if (small_q) {
+                if (!post_done)
+                    launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
+                                     A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
                 Timed t(c, SICP_K_NORMALEQ);
-                launch_icp_tail(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, A, c->icp_dev.p, c->dist.p,
-                                c->keep.p, c->resid.p, rec);
+                launch_icp_tail(c->stream, qx, qy, qz, c->normals.p, c->m_p2.p, A, c->icp_dev.p, c->dist.p, c->flag.p, c->keep.p,
+                                c->resid.p, rec);
             } else {
                 // distances + rejections (corrpts.py:139-211), kept-distance statistics, then the solver chain
                 if (Q <= REJECT_MAX_Q) {
                     Timed t(c, SICP_K_SELECT);
-                    if (c->reject_split) {
-                        // distances + flags by the whole machine, then selection + keep mask + statistics by one workgroup on
-                        // the 9 bytes per correspondence it still has to read
-                        Xf unused = {};
-                        launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
-                                         A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
+                    if (c->reject_split || post_done) {
+                        // distances + flags by the whole machine (the match kernel's epilogue, or k_postmatch behind an exchange),
+                        // then selection + keep mask + statistics by one workgroup on the 9 bytes per correspondence it still has to read
+                        if (!post_done)
+                            launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
+                                             A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
                         launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->icp_dev.p, c->small.p + 4);
                     } else {
                         launch_dist_reject_stats(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q,
@@ -1507,17 +1551,13 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                                                  c->small.p + 4, c->icp_dev.p);
                     }
                 } else {
-                    Xf unused = {};
-                    launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
-                                     A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
+                    if (!post_done)
+                        launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
+                                         A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
                     {
                         // median / MAD by digit selection over many workgroups, keep mask + kept statistics in one more pass
                         Timed t(c, SICP_K_SELECT);
-                        CHK(c->rj_keys.reserve((reject_select_scratch_bytes() + 7) / 8));
-                        if (reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
-                                             (unsigned long long *)(c->small.p + 56), c->ne_partial.p, c->ticket.p, nullptr, 0.0,
-                                             c->icp_dev.p) != hipSuccess)
-                            return fail(SICP_ERR_HIP, "rejection by digit selection failed");
+                        CHK(reject_select(c, Q, nullptr, 0.0, c->icp_dev.p));
                     }
                 }
                 {
@@ -1690,11 +1730,8 @@ int iterate_host_lm(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
         if (Q > REJECT_MAX_Q) {
             // one workgroup cannot chew a million distances: exact order statistics by multi-workgroup digit selection,
             // keep mask and kept-distance statistics in its last pass
-            CHK(c->rj_keys.reserve((reject_select_scratch_bytes() + 7) / 8));
             CHK(c->ne_partial.reserve((size_t)NE_MAX_GRID * 64));
-            if (reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
-                                 (unsigned long long *)(c->small.p + 56), c->ne_partial.p, c->ticket.p, h_st, seq) != hipSuccess)
-                return fail(SICP_ERR_HIP, "rejection by digit selection failed");
+            CHK(reject_select(c, Q, h_st, seq, nullptr));
         } else {
             launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p);
             launch_stats(c->stream, c->dist.p, c->keep.p, Q, c->small.p + 4, c->small.p, h_st, seq, c->ne_partial.p, c->ticket.p);
@@ -1903,10 +1940,7 @@ SICP_EXPORT int sicp_corr_reject_distances(sicp_ctx *c, double *median_out, doub
         Timed t(c, SICP_K_SELECT);
         if (Q > REJECT_MAX_Q) {
             const double seq = (double)(++c->solve_seq);
-            CHK(c->rj_keys.reserve((reject_select_scratch_bytes() + 7) / 8));
-            if (reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
-                                 (unsigned long long *)(c->small.p + 56), c->ne_partial.p, c->ticket.p, h_st, seq) != hipSuccess)
-                return fail(SICP_ERR_HIP, "rejection by digit selection failed");
+            CHK(reject_select(c, Q, h_st, seq, nullptr));
             HIPCHK(hipGetLastError());
             CHK(wait_ticket(c, h_st + 15, seq));
         } else {

@@ -270,6 +270,20 @@ __device__ __forceinline__ void xf(const Xf &H, double x, double y, double z, do
     t = H.m[8] * x;  t = fma(H.m[9], y, t);  t = fma(H.m[10], z, t);  oz = t + H.m[11];
 }
 
+// What k_postmatch computes (sicp_kernels.hip), by the lane that holds the winner: signed point-to-plane distance of the matched
+// point under H, contract (P), and the planarity verdict of both clouds -- the same expressions, so the same bits.
+__device__ __forceinline__ void post_match(const PostMatch &post, const Xf &H, long q, int64_t m, double px, double py, double pz,
+                                           double ax, double ay, double az, float nx, float ny, float nz, float pl)
+{
+    double X, Y, Z;
+    xf(H, px, py, pz, X, Y, Z);
+    const double a = (X - ax) * (double)nx, b = (Y - ay) * (double)ny, c = (Z - az) * (double)nz;
+    post.dist[q] = (a + b) + c;
+    bool f = m >= 0 && pl >= post.min_planarity;
+    if (f && post.pl2) f = m < post.pl2_n && post.pl2[m] >= post.min_planarity;          // corrpts.py:158-163 (NaN fails)
+    post.flag[q] = f ? 1 : 0;
+}
+
 // CHAINED: the launch belongs to a run whose iterations are enqueued back to back -- H and its inverse come from
 // the device-resident loop state the previous tail launch left (sicp_tail.hip), and the launch exits at once
 // when that tail declared the run over.
@@ -288,7 +302,9 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
     const IcpDev *__restrict__ st, unsigned long long *__restrict__ work /* nullable: [0] candidates, [1] rows, [2] launches */,
     const uint32_t *__restrict__ order /* nullable: queries in cell order (grid size is a multiple of 8 then) */,
-    int tight /* prev_p2 is a bound to search in one go (the nearest point of a subsample), not an old match */)
+    int tight /* prev_p2 is a bound to search in one go (the nearest point of a subsample), not an old match */,
+    PostMatch post /* chained match of an ICP iteration: the winning lane also leaves the point-to-plane distance and the
+                      planarity verdict (corrpts.py:139-163,195-211) -- it holds the matched point, the query and H already */)
 {
     const int lane = threadIdx.x & 63;
     long q = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -304,6 +320,8 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     const double ax = qx[q], ay = qy[q], az = qz[q];      // (issued before the loop state is waited for)
     double px0 = 0, py0 = 0, pz0 = 0;
     if (prev_p2) { px0 = prev_p2[3 * q]; py0 = prev_p2[3 * q + 1]; pz0 = prev_p2[3 * q + 2]; }
+    float pnx = 0.f, pny = 0.f, pnz = 0.f, ppl = 0.f;     // the query's normal and planarity (wave-uniform; in flight during the search)
+    if (post.dist) { pnx = post.normals[3 * q]; pny = post.normals[3 * q + 1]; pnz = post.normals[3 * q + 2]; ppl = post.planarity[q]; }
     if (CHAINED) {
         H = st->H; Hinv = st->Hinv;
         if (st->stop) return;
@@ -478,12 +496,14 @@ __global__ __launch_bounds__(256) void k_grid_nn(
             const bool ok = found && (best < max_d2);
             if (winner || (!found && lane == 0)) {
                 d2_out[q] = ok ? best : __builtin_inf();
-                idx_out[q] = ok ? idx_base + (int64_t)bidx : (int64_t)-1;
+                const int64_t m = ok ? idx_base + (int64_t)bidx : (int64_t)-1;
+                idx_out[q] = m;
                 if (p2_out) {
                     p2_out[3 * q]     = ok ? bx : 0.0;
                     p2_out[3 * q + 1] = ok ? by : 0.0;
                     p2_out[3 * q + 2] = ok ? bz : 0.0;
                 }
+                if (post.dist) post_match(post, H, q, m, ok ? bx : 0.0, ok ? by : 0.0, ok ? bz : 0.0, ax, ay, az, pnx, pny, pnz, ppl);
             }
             break;
         }
@@ -513,7 +533,8 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
     const double *__restrict__ prev_p2, GridGeom G, const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
     Xf H, Xf Hinv, double rmax, double max_d2, int64_t idx_base,
     double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
-    const IcpDev *__restrict__ st, unsigned long long *__restrict__ work, const uint32_t *__restrict__ order, int tight)
+    const IcpDev *__restrict__ st, unsigned long long *__restrict__ work, const uint32_t *__restrict__ order, int tight,
+    PostMatch post)
 {
     const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48;
     long blk = blockIdx.x;
@@ -689,10 +710,15 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
                 if (winner || (!found && gl == 0)) {
                     d2_out[q] = ok ? best : __builtin_inf();
                     idx_out[q] = ok ? idx_base + (int64_t)bidx : (int64_t)-1;
-                    if (p2_out) {
+                    if (p2_out || post.dist) {
                         double4 W = make_double4(0.0, 0.0, 0.0, 0.0);
                         if (ok) W = rec[bpos];
-                        p2_out[3 * q] = W.x; p2_out[3 * q + 1] = W.y; p2_out[3 * q + 2] = W.z;
+                        if (p2_out) { p2_out[3 * q] = W.x; p2_out[3 * q + 1] = W.y; p2_out[3 * q + 2] = W.z; }
+                        // (normal and planarity are fetched here, not up front: this flavour lives at its register limit, and a
+                        // full machine hides the round trip)
+                        if (post.dist)
+                            post_match(post, H, q, ok ? idx_base + (int64_t)bidx : (int64_t)-1, W.x, W.y, W.z, ax, ay, az,
+                                       post.normals[3 * q], post.normals[3 * q + 1], post.normals[3 * q + 2], post.planarity[q]);
                     }
                 }
                 done = true;
@@ -1088,7 +1114,293 @@ __global__ __launch_bounds__(256) void k_keep_stats(const double *__restrict__ d
     }
 }
 
-size_t reject_select_scratch_bytes() { return sizeof(HselState); }
+
+// ------------------------------------------------------------------------------------
+// The same rejection in ONE launch (default): the passes of both statistics, the two finishing steps and the keep / statistics
+// pass are phases of a single kernel separated by GRID BARRIERS, so only the passes the data needs are executed (real distances:
+// two per statistic) and nothing is dispatched in between -- the launch-per-phase form above enqueues 6 + 1 + 6 + 1 + 1 kernels
+// of which 8 exit at once, ~4 us apiece: at 32 768 correspondences that was ALL of the 65 us this step took.
+//
+//   * every block is resident at once (at most one block per CU is asked for, 256 lanes, 16 KiB of LDS), so a barrier is a
+//     counter every block's lane 0 adds to and then polls.  The counter only ever grows: a launch adds exactly
+//     gridDim.x * HS_MAXB to it (blocks top their share up when they leave), the host hands every launch the value it starts
+//     from, barrier k of a launch waits for  base + gridDim.x * (k + 1).  No reset, no memset between launches;
+//   * a pass needs ONE barrier: blocks add their local histograms to hist[p % 3], meet, and then EVERY block reads the complete
+//     histogram and picks the bin itself (same integers, same answer) -- no second meeting to broadcast the pick.  The buffer two
+//     passes ahead, hist[(p + 2) % 3], is wiped right after the barrier of pass p: it was last read before barrier p was entered
+//     and is next added to after barrier p + 1;
+//   * polling is bounded (about two seconds): a launch that cannot meet itself flags an error and ends instead of hanging
+//     the queue.
+// Same integers as the launch-per-phase form, so median / MAD / keep mask are bit-identical; the kept statistics are folded
+// from the same per-block partials in the same order.
+// ------------------------------------------------------------------------------------
+constexpr int HS_MAXB = 2 * HS_PASSES + 3;
+struct HselAll {
+    unsigned long long bar;        // grid-barrier arrivals, monotone over the life of the buffer
+    unsigned long long nxt[2];     // per statistic: smallest key above the prefix interval (~0 between launches; offset 8, see reject_select)
+    unsigned ncand[2];             // per statistic: candidates appended (0 between launches)
+    unsigned error;                // a barrier timed out (sticky)
+    unsigned pad;
+    unsigned hist[3][HS_BINS];     // all zero between launches
+    unsigned long long cand[2][HS_CAP];
+};
+
+__device__ __forceinline__ void hs_barrier(HselAll *S, unsigned long long target)
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&S->bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long spins = 0;
+        while (__hip_atomic_load(&S->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1L << 21)) { __hip_atomic_store(&S->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
+                                                  HselAll *__restrict__ S, unsigned long long bar_base, uint8_t *__restrict__ keep,
+                                                  double *__restrict__ partial /*[3][NE_MAX_GRID]*/, double *__restrict__ out4,
+                                                  double *__restrict__ out3, double *__restrict__ host_out, double seq,
+                                                  const IcpDev *__restrict__ st)
+{
+    __shared__ unsigned hist[HS_BINS];
+    __shared__ unsigned scan[4];
+    __shared__ unsigned long long sc[HS_CAP];
+    __shared__ unsigned long long pnx[4], pick[2];
+    __shared__ unsigned long long sel[3];            // picked by the bin's owner: prefix, rank inside it, its count
+    __shared__ double red[4][3];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned g = gridDim.x;
+    int nb = 0;                                       // barriers this block has gone through
+    if (st && st->stop) {                             // the run is over: leave, but leave the counter where the next launch expects it
+        if (tid == 0) __hip_atomic_fetch_add(&S->bar, (unsigned long long)HS_MAXB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const long stride = (long)g * (256 * HS_UNROLL);
+    double val[2] = {0.0, 0.0};                       // median, MAD
+    unsigned long long m_first = 0;
+    int p = 0;                                        // running pass index over both statistics: hist[p % 3]
+    for (int which = 0; which < 2; ++which) {
+        const double ctr = which ? val[0] : 0.0;
+        unsigned long long prefix = 0, rank = 0, m = 0;
+        unsigned cnt = 0;
+        int fixed = 0;
+        bool done = false;
+        for (int pass = 0; pass < HS_PASSES && !done; ++pass, ++p) {
+            const int bits = pass < 5 ? 12 : 4, shift = pass < 5 ? 52 - 12 * pass : 0;
+            const unsigned mask = (1u << bits) - 1u;
+            unsigned *gh = S->hist[p % 3];
+            for (int i = tid; i < HS_BINS; i += 256) hist[i] = 0;
+            __syncthreads();
+            for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {      // block-uniform trip count
+                double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
+#pragma unroll
+                for (int u = 0; u < HS_UNROLL; ++u) {
+                    const long i = base + u * 256 + tid;
+                    f[u] = i < Q ? flag[i] : (uint8_t)0;
+                    d[u] = i < Q ? dist[i] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < HS_UNROLL; ++u) {
+                    const unsigned long long k = f[u] ? okey(which ? fabs(d[u] - ctr) : d[u]) : ~0ull;
+                    bool act = f[u] && (pass == 0 || (k >> (shift + bits)) == (prefix >> (shift + bits)));
+                    const unsigned bin = (unsigned)(k >> shift) & mask;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {       // distances share sign and exponent: whole waves hit one bin
+                        const unsigned long long am = __ballot(act);
+                        if (am == 0) break;
+                        const int leader = __ffsll((long long)am) - 1;
+                        const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+                        const unsigned long long same = __ballot(act && bin == b0);
+                        if (lane == leader) atomicAdd(&hist[b0], (unsigned)__popcll(same));
+                        act = act && bin != b0;
+                    }
+                    if (act) atomicAdd(&hist[bin], 1u);
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < HS_BINS; i += 256) if (hist[i]) atomicAdd(&gh[i], hist[i]);
+            hs_barrier(S, bar_base + (unsigned long long)g * (unsigned long long)(++nb));
+            // every block picks the bin itself: thread t owns bins 16t .. 16t+15 of the complete histogram
+            unsigned h[16], mine = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { h[j] = gh[16 * tid + j]; mine += h[j]; }
+            const unsigned incl = wscan_u32(mine);
+            if (lane == 63) scan[wid] = incl;
+            __syncthreads();
+            unsigned before = 0;
+            for (int w = 0; w < wid; ++w) before += scan[w];
+            const unsigned long long total = (unsigned long long)scan[0] + scan[1] + scan[2] + scan[3];
+            if (pass == 0) { m = total; rank = m ? (m - 1) / 2 : 0; }
+            unsigned long long acc = before + incl - mine;
+            if (m > 0 && rank >= acc && rank < acc + mine) {
+                int j = 0;
+                while (rank >= acc + h[j]) { acc += h[j]; ++j; }
+                sel[0] = prefix | ((unsigned long long)(16 * tid + j) << shift);
+                sel[1] = rank - acc;
+                sel[2] = h[j];
+            }
+            __syncthreads();
+            if (m > 0) {
+                prefix = sel[0]; rank = sel[1]; cnt = (unsigned)sel[2];
+                fixed = 64 - shift;
+                done = cnt <= (unsigned)HS_CAP || pass == HS_PASSES - 1;
+            } else { done = true; cnt = 0; fixed = 0; }
+            // wipe this block's share of the buffer two passes ahead (see the header)
+            {
+                unsigned *z = S->hist[(p + 2) % 3];
+                for (unsigned i = blockIdx.x * 256u + (unsigned)tid; i < (unsigned)HS_BINS; i += g * 256u)
+                    __hip_atomic_store(&z[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();                              // (sel / scan are rewritten by the next pass)
+        }
+        // ---- finish: survivors of the prefix interval, the smallest key above it ----
+        const bool collect = cnt <= (unsigned)HS_CAP;     // otherwise every bit is fixed: the interval is ONE value
+        const unsigned long long hi = fixed >= 64 ? prefix : (prefix | (~0ull >> fixed));
+        unsigned long long nxt = ~0ull;
+        if (m > 0) {
+            for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {
+                double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
+#pragma unroll
+                for (int u = 0; u < HS_UNROLL; ++u) {
+                    const long i = base + u * 256 + tid;
+                    f[u] = i < Q ? flag[i] : (uint8_t)0;
+                    d[u] = i < Q ? dist[i] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < HS_UNROLL; ++u) {
+                    if (!f[u]) continue;
+                    const unsigned long long k = okey(which ? fabs(d[u] - ctr) : d[u]);
+                    if (k > hi) nxt = k < nxt ? k : nxt;
+                    else if (collect && k >= prefix) {
+                        const unsigned pos = atomicAdd(&S->ncand[which], 1u);
+                        if (pos < (unsigned)HS_CAP) __hip_atomic_store(&S->cand[which][pos], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
+        { unsigned long long o;
+          o = lane_xor64<32>(nxt); nxt = o < nxt ? o : nxt;  o = lane_xor64<16>(nxt); nxt = o < nxt ? o : nxt;
+          o = lane_xor64<8>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<4>(nxt);  nxt = o < nxt ? o : nxt;
+          o = lane_xor64<2>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<1>(nxt);  nxt = o < nxt ? o : nxt; }
+        if (lane == 0) pnx[wid] = nxt;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long tn = pnx[0];
+            for (int w = 1; w < 4; ++w) tn = pnx[w] < tn ? pnx[w] : tn;
+            if (tn != ~0ull) atomicMin(&S->nxt[which], tn);
+        }
+        hs_barrier(S, bar_base + (unsigned long long)g * (unsigned long long)(++nb));
+        // every block ranks the survivors itself
+        const unsigned long long above = __hip_atomic_load(&S->nxt[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 2) pick[tid] = prefix;                  // (single-value interval: both middles are that value unless ...)
+        if (collect && m > 0) {
+            if (tid < (int)cnt) sc[tid] = __hip_atomic_load(&S->cand[which][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (tid < (int)cnt) {
+                const unsigned long long k = sc[tid];
+                unsigned r = 0;
+                for (unsigned j = 0; j < cnt; ++j) { const unsigned long long o = sc[j]; r += (o < k || (o == k && j < (unsigned)tid)) ? 1u : 0u; }
+                if (r == rank) pick[0] = k;
+                if (r == rank + 1) pick[1] = k;
+            }
+        }
+        __syncthreads();
+        {
+            const unsigned long long ka = pick[0];
+            unsigned long long kb = ka;
+            if (!(m & 1)) kb = (rank + 1 < cnt) ? pick[1] : above;   // even count: the next value up, inside the interval or just above it
+            val[which] = m > 0 ? (oval64(ka) + oval64(kb)) / 2.0 : __builtin_nan("");
+        }
+        if (which == 0) m_first = m;
+        // the buffer of this statistic's last pass is the one nothing has wiped yet (every block read it before the barrier above)
+        if (p > 0) {
+            unsigned *z = S->hist[(p - 1) % 3];
+            for (unsigned i = blockIdx.x * 256u + (unsigned)tid; i < (unsigned)HS_BINS; i += g * 256u)
+                __hip_atomic_store(&z[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+    // ---- keep mask + count / mean / std of the kept distances (sums relative to the median), as k_keep_stats ----
+    const double med = val[0], bound = 3 * val[1];
+    double n = 0, s1 = 0, s2 = 0;
+    for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {
+        double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < HS_UNROLL; ++u) {
+            const long i = base + u * 256 + tid;
+            f[u] = i < Q ? flag[i] : (uint8_t)0;
+            d[u] = i < Q ? dist[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < HS_UNROLL; ++u) {
+            const long i = base + u * 256 + tid;
+            const double e = d[u] - med;
+            const bool k = f[u] && fabs(e) <= bound;
+            if (i < Q) keep[i] = k ? 1 : 0;
+            if (k) { n += 1.0; s1 += e; s2 += e * e; }
+        }
+    }
+    n = wsum(n); s1 = wsum(s1); s2 = wsum(s2);
+    if (lane == 0) { red[wid][0] = n; red[wid][1] = s1; red[wid][2] = s2; }
+    __syncthreads();
+    if (tid < 3) partial[(long)tid * NE_MAX_GRID + blockIdx.x] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    hs_barrier(S, bar_base + (unsigned long long)g * (unsigned long long)(++nb));
+    if (blockIdx.x == 0) {
+        if (wid < 3) {
+            double t = 0;
+            for (unsigned blk = lane; blk < g; blk += 64) t += partial[(long)wid * NE_MAX_GRID + blk];
+            t = wsum(t);
+            if (lane == 0) red[0][wid] = t;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const bool bad = __hip_atomic_load(&S->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            const double cnt = bad ? 0.0 : red[0][0], mu = red[0][1] / cnt;
+            const double var = red[0][2] / cnt - mu * mu;
+            const double mean = med + mu, sd = sqrt(var > 0.0 ? var : 0.0);
+            out4[0] = (double)m_first; out4[1] = bad ? __builtin_nan("") : med; out4[2] = bad ? __builtin_nan("") : val[1]; out4[3] = cnt;
+            out3[0] = cnt; out3[1] = mean; out3[2] = sd;
+            if (host_out) {
+                host_out[0] = out4[0]; host_out[1] = out4[1]; host_out[2] = out4[2]; host_out[3] = cnt;
+                host_out[4] = cnt; host_out[5] = mean; host_out[6] = sd;
+                __threadfence_system();
+                __hip_atomic_store(host_out + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            // leave the state as the next launch expects it (every other block is past its last use of these words)
+            __hip_atomic_store(&S->nxt[0], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&S->nxt[1], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&S->ncand[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&S->ncand[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // top the counter up to this launch's fixed share
+    if (tid == 0 && nb < HS_MAXB)
+        __hip_atomic_fetch_add(&S->bar, (unsigned long long)(HS_MAXB - nb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+size_t reject_select_scratch_bytes() { return sizeof(HselAll) > sizeof(HselState) ? sizeof(HselAll) : sizeof(HselState); }
+
+// One-launch form.  `state` must have been zeroed (hipMemset) when it was allocated and is left clean by every launch;
+// *bar_total is the host's running count of what the launches on this buffer have added to its barrier counter.
+hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
+                                       double *out3, void *state, unsigned long long *bar_total, double *partial, double *host_out,
+                                       double seq, const IcpDev *st)
+{
+    static const long cap = [] { const char *e = std::getenv("SICP_HS_GRID"); const long v = e ? std::atol(e) : 0; return v > 0 && v <= 256 ? v : 256L; }();
+    const unsigned g = (unsigned)std::max<long>(1, std::min<long>(cap, (Q + 256 * HS_UNROLL - 1) / (256 * HS_UNROLL)));
+    hipLaunchKernelGGL(k_hsel_all, dim3(g), dim3(256), 0, s, dist, flag, Q, (HselAll *)state, *bar_total, keep, partial, out4, out3,
+                       host_out, seq, st);
+    *bar_total += (unsigned long long)g * HS_MAXB;
+    return hipGetLastError();
+}
+
 
 // state: reject_select_scratch_bytes() of device scratch; small: 4 x 8 bytes ([0] m, [2] median, [3] mad);
 // partial / ticket: the solver's block-partial scratch (3 * NE_MAX_GRID doubles) and its ticket word
@@ -1176,39 +1488,41 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
         if (H)
             hipLaunchKernelGGL((k_grid_nn16<true, false>), g16, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec,
                                *H, *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work,
-                               (const uint32_t *)nullptr, 0);
+                               (const uint32_t *)nullptr, 0, PostMatch{});
         else
             hipLaunchKernelGGL((k_grid_nn16<false, false>), g16, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec,
                                id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work,
-                               (const uint32_t *)nullptr, 0);
+                               (const uint32_t *)nullptr, 0, PostMatch{});
         return;
     }
     if (H)
         hipLaunchKernelGGL((k_grid_nn<true, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec, *H,
-                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work, (const uint32_t *)nullptr, 0);
+                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work, (const uint32_t *)nullptr, 0, PostMatch{});
     else
         hipLaunchKernelGGL((k_grid_nn<false, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec, id,
-                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work, (const uint32_t *)nullptr, 0);
+                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work, (const uint32_t *)nullptr, 0, PostMatch{});
 }
 
 // the match of a chained iteration: transform taken from the loop state on the device
 void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                             const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
                             int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
-                            const uint32_t *order, bool four_per_wave, bool tight)
+                            const uint32_t *order, bool four_per_wave, bool tight, const PostMatch *post)
 {
     Xf id = {};
+    PostMatch pm = {};
+    if (post) pm = *post;
     if (four_per_wave) {
         unsigned g16 = cdiv(Q, 16);
         if (order) g16 = (g16 + 7u) & ~7u;
         hipLaunchKernelGGL((k_grid_nn16<true, true>), dim3(g16), dim3(256), 0, s, qx, qy, qz, Q, prev_p2, G, cell_start,
-                           (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work, order, tight ? 1 : 0);
+                           (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work, order, tight ? 1 : 0, pm);
         return;
     }
     unsigned g = cdiv(Q, 4);
     if (order) g = (g + 7u) & ~7u;
     hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(g), dim3(256), 0, s, qx, qy, qz, Q, prev_p2, G, cell_start,
-                       (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work, order, tight ? 1 : 0);
+                       (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work, order, tight ? 1 : 0, pm);
 }
 
 void launch_stride_sample(hipStream_t s, const double *x, const double *y, const double *z, long n, long stride, long m, long mpad,

@@ -39,6 +39,17 @@ struct IcpDev {
     int stop;                     // the run is over (converged / failed): later launches of the chain exit at once
     int pad[2];
 };
+// what the match kernel of a chained iteration leaves besides the match itself (null dist = nothing): the point-to-plane
+// distance and the planarity verdict per query, i.e. k_postmatch's output
+struct PostMatch {
+    const float *normals;         // (Q,3)
+    const float *planarity;       // (Q)
+    const float *pl2;             // movable cloud's planarity column by GLOBAL index, or null
+    long pl2_n;
+    float min_planarity;
+    double *dist;                 // (Q) out
+    uint8_t *flag;                // (Q) out: 1 = matched and planar enough in both clouds
+};
 struct TailArgs {
     double obs[6], ow[6];
     double min_change;            // simpleicp.py:356-379, percent; < 0: no convergence test (single-iteration API)
@@ -58,7 +69,7 @@ constexpr int REC_RESID_SLOT = 61;  // larger Q: which of the two residual buffe
 constexpr int REC_TICKET = 63;
 constexpr int REC_DOUBLES = 64;
 void launch_icp_tail(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
-                     const float *planarity, const double *p2, const int64_t *idx, const TailArgs &A, IcpDev *st, double *dist,
+                     const double *p2, const TailArgs &A, IcpDev *st, const double *dist, const uint8_t *flag,
                      uint8_t *keep, double *resid, double *rec);
 
 // solver state of the multi-workgroup evaluation chain (sicp_lm.hip, Q > SOLVE_MAX_Q)
@@ -100,7 +111,7 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
 void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                             const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
                             int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
-                            const uint32_t *order, bool four_per_wave, bool tight = false);
+                            const uint32_t *order, bool four_per_wave, bool tight = false, const PostMatch *post = nullptr);
 void launch_stride_sample(hipStream_t s, const double *x, const double *y, const double *z, long n, long stride, long m, long mpad,
                           double *out);
 void launch_scatter_order(hipStream_t s, const uint32_t *ids, long n, uint32_t *cursor, uint32_t *order);
@@ -110,6 +121,9 @@ void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const do
 void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec);
 void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, double *d2, int64_t *idx, double *p2);
 size_t reject_select_scratch_bytes();
+hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
+                                       double *out3, void *state, unsigned long long *bar_total, double *partial, double *host_out,
+                                       double seq, const IcpDev *st);
 hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, double *out3,
                             void *state, unsigned long long *small, double *partial, unsigned *ticket, double *host_out = nullptr,
                             double seq = 0.0, const IcpDev *st = nullptr);

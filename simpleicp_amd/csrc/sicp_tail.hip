@@ -5,7 +5,8 @@
 // back -- match, tail, match, tail, ... -- and only reads the per-iteration records the kernel streams into
 // pinned memory.
 //
-//   point-to-plane distances + planarity flags            corrpts.py:139-163,195-211
+//   (point-to-plane distances + planarity flags arrive with the matches: corrpts.py:139-163,195-211 is the match kernel's
+//    epilogue, k_grid_nn / post_match, or k_postmatch behind a multi-GPU exchange)
 //   median / raw-MAD rejection                            corrpts.py:165-188
 //   kept-distance statistics, automatic weight            simpleicp.py:229-234
 //   Levenberg-Marquardt on fused 6x6 normal equations     optimization.py:65-124,172-288
@@ -300,8 +301,9 @@ __device__ __forceinline__ void publish(double *rec, double seq)
 template <int EPT>
 __global__ __launch_bounds__(TB, 1) void k_icp_tail(
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
-    const float *__restrict__ normals, const float *__restrict__ planarity, const double *__restrict__ p2,
-    const int64_t *__restrict__ idx, TailArgs A, IcpDev *__restrict__ st, double *__restrict__ dist,
+    const float *__restrict__ normals, const double *__restrict__ p2, TailArgs A, IcpDev *__restrict__ st,
+    const double *__restrict__ dist /* point-to-plane distances and planarity verdicts of this iteration's matches: left by */,
+    const uint8_t *__restrict__ flag /* the match kernel's winning lanes (or by k_postmatch behind a multi-GPU exchange)   */,
     uint8_t *__restrict__ keep, double *__restrict__ resid, double *__restrict__ rec)
 {
     __shared__ TailShared S;
@@ -309,27 +311,32 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
     const int Q = A.Q;
     long long tk[6]; tk[0] = clock64();
     // ---- loop state + this lane's correspondences: ONE global round trip (every load is issued before the first
-    //      barrier and before the stop flag is looked at) ----
-    Corr<EPT> C;
-    int64_t mi[EPT];
-    float pl[EPT];
+    //      barrier and before the stop flag is looked at).  The rejection needs only the distances and verdicts -- 9 bytes per
+    //      correspondence, asked for FIRST (loads return in order); the 60 bytes per correspondence the solver works on arrive
+    //      while the order statistics are being taken ----
+    double d[EPT];
+    uint8_t fb[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + e * TB;
         const int ic = i < Q ? i : Q - 1;                 // clamped: every lane loads, lanes past Q are masked below
-        C.px[e] = p2[3 * ic]; C.py[e] = p2[3 * ic + 1]; C.pz[e] = p2[3 * ic + 2];
-        C.qx[e] = qx[ic]; C.qy[e] = qy[ic]; C.qz[e] = qz[ic];
-        C.nx[e] = normals[3 * ic]; C.ny[e] = normals[3 * ic + 1]; C.nz[e] = normals[3 * ic + 2];
-        mi[e] = idx[ic]; pl[e] = planarity[ic];
+        d[e] = dist[ic]; fb[e] = flag[ic];
     }
-    double x[6], sc[6], H0[12];
+    double x[6], sc[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) { x[j] = st->x[j]; sc[j] = st->sc[j]; }
-#pragma unroll
-    for (int j = 0; j < 12; ++j) H0[j] = st->H.m[j];
     const double w_state = st->w, prev_mean = st->prev_mean, prev_std = st->prev_std;
     const int done_iters = st->done_iters;
     const int stop = st->stop;
+    Corr<EPT> C;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * TB;
+        const int ic = i < Q ? i : Q - 1;
+        C.px[e] = p2[3 * ic]; C.py[e] = p2[3 * ic + 1]; C.pz[e] = p2[3 * ic + 2];
+        C.qx[e] = qx[ic]; C.qy[e] = qy[ic]; C.qz[e] = qz[ic];
+        C.nx[e] = normals[3 * ic]; C.ny[e] = normals[3 * ic + 1]; C.nz[e] = normals[3 * ic + 2];
+    }
     unsigned *hc = reinterpret_cast<unsigned *>(&S.ja[0][0]);      // the row staging area is idle until the LM phase
     for (int i = tid; i < HC * 257; i += TB) hc[i] = 0u;
     if (tid == 0) S.ncand = 0u;
@@ -341,7 +348,6 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         return;
     }
 
-    double d[EPT];
     bool fl[EPT];
     unsigned long long key[EPT];
     unsigned nflag = 0;
@@ -349,17 +355,10 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + e * TB;
-        C.keep[e] = false; fl[e] = false; d[e] = 0.0; key[e] = NOKEY;
-        if (i < Q) {
-            bool f = mi[e] >= 0 && pl[e] >= A.min_planarity;
-            if (f && A.pl2) f = mi[e] < A.pl2_n && A.pl2[mi[e]] >= A.min_planarity;      // corrpts.py:158-163 (NaN fails)
-            double X, Y, Z;
-            xfm(H0, C.px[e], C.py[e], C.pz[e], X, Y, Z);
-            d[e] = pdist(X - C.qx[e], Y - C.qy[e], Z - C.qz[e], C.nx[e], C.ny[e], C.nz[e]);
-            dist[i] = d[e];
-            fl[e] = f;
-            if (f) { key[e] = okey(d[e]); dmn = fmin(dmn, d[e]); dmx = fmax(dmx, d[e]); }
-        }
+        C.keep[e] = false; key[e] = NOKEY;
+        fl[e] = i < Q && fb[e] != 0;
+        if (i >= Q) d[e] = 0.0;
+        if (fl[e]) { key[e] = okey(d[e]); dmn = fmin(dmn, d[e]); dmx = fmax(dmx, d[e]); }
         nflag += (unsigned)__popcll((long long)__ballot(fl[e]));
     }
     // survivors of the planarity test and the range of their distances: wave reductions + one barrier
@@ -602,18 +601,18 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
 }
 
 void launch_icp_tail(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
-                     const float *planarity, const double *p2, const int64_t *idx, const TailArgs &A, IcpDev *st, double *dist,
+                     const double *p2, const TailArgs &A, IcpDev *st, const double *dist, const uint8_t *flag,
                      uint8_t *keep, double *resid, double *rec)
 {
     // correspondences per lane: the register-resident copy is sized to the problem
     if (A.Q <= TB)
-        hipLaunchKernelGGL(k_icp_tail<1>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, planarity, p2, idx, A, st, dist, keep, resid, rec);
+        hipLaunchKernelGGL(k_icp_tail<1>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, p2, A, st, dist, flag, keep, resid, rec);
     else if (A.Q <= 2 * TB)
-        hipLaunchKernelGGL(k_icp_tail<2>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, planarity, p2, idx, A, st, dist, keep, resid, rec);
+        hipLaunchKernelGGL(k_icp_tail<2>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, p2, A, st, dist, flag, keep, resid, rec);
     else if (A.Q <= 4 * TB)
-        hipLaunchKernelGGL(k_icp_tail<4>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, planarity, p2, idx, A, st, dist, keep, resid, rec);
+        hipLaunchKernelGGL(k_icp_tail<4>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, p2, A, st, dist, flag, keep, resid, rec);
     else
-        hipLaunchKernelGGL(k_icp_tail<8>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, planarity, p2, idx, A, st, dist, keep, resid, rec);
+        hipLaunchKernelGGL(k_icp_tail<8>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, p2, A, st, dist, flag, keep, resid, rec);
 }
 
 }  // namespace sicp
