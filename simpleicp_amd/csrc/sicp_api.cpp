@@ -307,6 +307,9 @@ struct sicp_ctx {
     int lm_evals = 4;              // evaluations enqueued per iteration for Q > SOLVE_MAX_Q (SICP_LM_EVALS; k_lm_finish completes the rest)
     double *h_rec = nullptr;       // pinned ring of per-iteration records the tail kernel streams to the host
     IcpDev *h_state = nullptr;     // pinned staging of the loop state
+    DevBuf<unsigned long long> lm_bar_buf;   // grid barrier of the one-launch minimisation (zeroed when allocated)
+    unsigned long long lm_bar = 0;     // what its launches have added to the counter so far
+    bool lm_one_launch = true;         // SICP_LM=launches: one launch per evaluation + finish (A/B; always with a sharded reduction)
     unsigned long long hsel_bar = 0;   // what the one-launch rejection's launches have added to its barrier counter so far
     bool hsel_one_launch = true;   // SICP_HSEL=launches: the launch-per-phase form (A/B)
     bool hsel_dirty = false;
@@ -509,15 +512,13 @@ int reject_select(sicp_ctx *c, long Q, double *host_out, double seq, const IcpDe
     const size_t words = (reject_select_scratch_bytes() + 7) / 8;
     if (c->rj_keys.cap < words) {
         CHK(c->rj_keys.reserve(words));
-        HIPCHK(hipMemsetAsync(c->rj_keys.p, 0, words * 8, c->stream));      // the one-launch form keeps its state clean from here on
-        HIPCHK(hipMemsetAsync((char *)c->rj_keys.p + 8, 0xff, 16, c->stream));  // (HselAll::nxt[2] rests at ~0)
+        HIPCHK(hsel_state_init(c->stream, c->rj_keys.p));                    // the one-launch form keeps its state clean from here on
         c->hsel_bar = 0;
     }
     hipError_t e;
     if (c->hsel_one_launch) {
         if (c->hsel_dirty) {                                                 // the other form ran in between (tests): start clean
-            HIPCHK(hipMemsetAsync(c->rj_keys.p, 0, words * 8, c->stream));
-            HIPCHK(hipMemsetAsync((char *)c->rj_keys.p + 8, 0xff, 16, c->stream));
+            HIPCHK(hsel_state_init(c->stream, c->rj_keys.p));
             c->hsel_bar = 0; c->hsel_dirty = false;
         }
         e = reject_by_select_one_launch(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
@@ -1051,6 +1052,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_REJECT_SPLIT")) c->reject_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_COARSE_ITERS")) c->coarse_iters = std::atoi(e);
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
+    if (const char *e = std::getenv("SICP_LM")) c->lm_one_launch = std::strcmp(e, "launches") != 0;
     if (const char *e = std::getenv("SICP_HSEL")) c->hsel_one_launch = std::strcmp(e, "launches") != 0;
     if (const char *e = std::getenv("SICP_MATCH_EPILOGUE")) c->match_epilogue = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_XCHG_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) c->xchg_timeout_s = v; }
@@ -1082,7 +1084,7 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->hit_cnt.release(); c->hit_list.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
     c->resid.release(); c->flag.release(); c->keep.release(); c->small.release(); c->ne_partial.release();
-    c->ticket.release(); c->icp_dev.release(); c->lm_dev.release(); c->resid2.release();
+    c->lm_bar_buf.release(); c->ticket.release(); c->icp_dev.release(); c->lm_dev.release(); c->resid2.release();
     c->corr_pl.release();
     if (c->h_lm) (void)hipHostFree(c->h_lm);
     if (c->h_small) (void)hipHostFree(c->h_small);
@@ -1501,7 +1503,9 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                                            ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q);
                 // without an exchange the match is final when its kernel ends: the winning lanes leave the point-to-plane
                 // distance and the planarity verdict too (what k_postmatch would re-read 72 bytes per correspondence for)
-                post_done = !c->collective() && c->match_epilogue;
+                // (only in the one-wave-per-query flavour: with four queries per wave at the register limit the epilogue's late
+                // loads cost the search more than k_postmatch's launch -- match 693 -> 758 us at 1 M queries, measured)
+                post_done = !c->collective() && c->match_epilogue && cnt < c->nn16_min_q;
                 PostMatch pm = {c->normals.p, c->planarity.p, A.pl2, A.pl2_n, A.min_planarity, c->dist.p, c->flag.p};
                 if (cnt > 0)
                     launch_grid_nn_chained(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt,
@@ -1567,17 +1571,28 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                     if (shard) CHK(c->lm_gsum.reserve(64));
                     c->resid_sharded = shard;
                     Timed t(c, SICP_K_NORMALEQ);
-                    for (int e = 0; e < c->lm_evals; ++e) {
-                        launch_lm_eval(c->stream, qx, qy, qz, c->normals.p, c->m_p2.p, c->keep.p, Q, A, c->icp_dev.p, c->lm_dev.p,
-                                       c->small.p + 4, c->ne_partial.p, c->ticket.p, c->resid.p, c->resid2.p,
-                                       shard ? c->rank : 0, shard ? c->world : 1, shard ? c->lm_gsum.p : nullptr);
-                        if (shard) {
-                            CHK(all_reduce_sum_f64(c, c->lm_gsum.p, 64));
-                            launch_lm_advance(c->stream, A, c->icp_dev.p, c->lm_dev.p, c->small.p + 4, c->lm_gsum.p);
+                    if (c->lm_one_launch && !shard) {
+                        const size_t words = (lm_bar_bytes() + 7) / 8;
+                        if (c->lm_bar_buf.cap < words) {
+                            CHK(c->lm_bar_buf.reserve(words));
+                            HIPCHK(hipMemsetAsync(c->lm_bar_buf.p, 0, words * 8, c->stream));
+                            c->lm_bar = 0;
                         }
+                        launch_lm_all(c->stream, qx, qy, qz, c->normals.p, c->m_p2.p, c->keep.p, Q, A, c->icp_dev.p, c->lm_dev.p, c->small.p,
+                                      c->small.p + 4, c->ne_partial.p, c->lm_bar_buf.p, &c->lm_bar, c->resid.p, c->resid2.p, rec);
+                    } else {
+                        for (int e = 0; e < c->lm_evals; ++e) {
+                            launch_lm_eval(c->stream, qx, qy, qz, c->normals.p, c->m_p2.p, c->keep.p, Q, A, c->icp_dev.p, c->lm_dev.p,
+                                           c->small.p + 4, c->ne_partial.p, c->ticket.p, c->resid.p, c->resid2.p,
+                                           shard ? c->rank : 0, shard ? c->world : 1, shard ? c->lm_gsum.p : nullptr);
+                            if (shard) {
+                                CHK(all_reduce_sum_f64(c, c->lm_gsum.p, 64));
+                                launch_lm_advance(c->stream, A, c->icp_dev.p, c->lm_dev.p, c->small.p + 4, c->lm_gsum.p);
+                            }
+                        }
+                        launch_lm_finish(c->stream, qx, qy, qz, c->normals.p, c->m_p2.p, c->keep.p, Q, A, c->icp_dev.p, c->lm_dev.p,
+                                         c->small.p, c->small.p + 4, c->resid.p, c->resid2.p, rec);
                     }
-                    launch_lm_finish(c->stream, qx, qy, qz, c->normals.p, c->m_p2.p, c->keep.p, Q, A, c->icp_dev.p, c->lm_dev.p,
-                                     c->small.p, c->small.p + 4, c->resid.p, c->resid2.p, rec);
                 }
             }
             HIPCHK(hipGetLastError());

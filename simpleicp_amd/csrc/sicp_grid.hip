@@ -1136,32 +1136,12 @@ __global__ __launch_bounds__(256) void k_keep_stats(const double *__restrict__ d
 // ------------------------------------------------------------------------------------
 constexpr int HS_MAXB = 2 * HS_PASSES + 3;
 struct HselAll {
-    unsigned long long bar;        // grid-barrier arrivals, monotone over the life of the buffer
-    unsigned long long nxt[2];     // per statistic: smallest key above the prefix interval (~0 between launches; offset 8, see reject_select)
+    GridBar bar;                   // (sicp_lanes.h) all zero when the buffer is new
+    unsigned long long nxt[2];     // per statistic: smallest key above the prefix interval (~0 between launches; see hsel_state_init)
     unsigned ncand[2];             // per statistic: candidates appended (0 between launches)
-    unsigned error;                // a barrier timed out (sticky)
-    unsigned pad;
     unsigned hist[3][HS_BINS];     // all zero between launches
     unsigned long long cand[2][HS_CAP];
 };
-
-__device__ __forceinline__ void hs_barrier(HselAll *S, unsigned long long target)
-{
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(&S->bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        long spins = 0;
-        while (__hip_atomic_load(&S->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1L << 21)) { __hip_atomic_store(&S->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-}
 
 __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
                                                   HselAll *__restrict__ S, unsigned long long bar_base, uint8_t *__restrict__ keep,
@@ -1179,7 +1159,7 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
     const unsigned g = gridDim.x;
     int nb = 0;                                       // barriers this block has gone through
     if (st && st->stop) {                             // the run is over: leave, but leave the counter where the next launch expects it
-        if (tid == 0) __hip_atomic_fetch_add(&S->bar, (unsigned long long)HS_MAXB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        grid_barrier_leave(&S->bar, 0, HS_MAXB);
         return;
     }
     const long stride = (long)g * (256 * HS_UNROLL);
@@ -1226,7 +1206,7 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
             }
             __syncthreads();
             for (int i = tid; i < HS_BINS; i += 256) if (hist[i]) atomicAdd(&gh[i], hist[i]);
-            hs_barrier(S, bar_base + (unsigned long long)g * (unsigned long long)(++nb));
+            grid_barrier(&S->bar, bar_base + (unsigned long long)g * (unsigned long long)(++nb));
             // every block picks the bin itself: thread t owns bins 16t .. 16t+15 of the complete histogram
             unsigned h[16], mine = 0;
 #pragma unroll
@@ -1296,7 +1276,7 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
             for (int w = 1; w < 4; ++w) tn = pnx[w] < tn ? pnx[w] : tn;
             if (tn != ~0ull) atomicMin(&S->nxt[which], tn);
         }
-        hs_barrier(S, bar_base + (unsigned long long)g * (unsigned long long)(++nb));
+        grid_barrier(&S->bar, bar_base + (unsigned long long)g * (unsigned long long)(++nb));
         // every block ranks the survivors itself
         const unsigned long long above = __hip_atomic_load(&S->nxt[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < 2) pick[tid] = prefix;                  // (single-value interval: both middles are that value unless ...)
@@ -1351,7 +1331,7 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
     if (lane == 0) { red[wid][0] = n; red[wid][1] = s1; red[wid][2] = s2; }
     __syncthreads();
     if (tid < 3) partial[(long)tid * NE_MAX_GRID + blockIdx.x] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    hs_barrier(S, bar_base + (unsigned long long)g * (unsigned long long)(++nb));
+    grid_barrier(&S->bar, bar_base + (unsigned long long)g * (unsigned long long)(++nb));
     if (blockIdx.x == 0) {
         if (wid < 3) {
             double t = 0;
@@ -1361,7 +1341,7 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
         }
         __syncthreads();
         if (tid == 0) {
-            const bool bad = __hip_atomic_load(&S->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            const bool bad = __hip_atomic_load(&S->bar.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             const double cnt = bad ? 0.0 : red[0][0], mu = red[0][1] / cnt;
             const double var = red[0][2] / cnt - mu * mu;
             const double mean = med + mu, sd = sqrt(var > 0.0 ? var : 0.0);
@@ -1380,12 +1360,18 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
             __hip_atomic_store(&S->ncand[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    // top the counter up to this launch's fixed share
-    if (tid == 0 && nb < HS_MAXB)
-        __hip_atomic_fetch_add(&S->bar, (unsigned long long)(HS_MAXB - nb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    grid_barrier_leave(&S->bar, nb, HS_MAXB);      // top the counter up to this launch's fixed share
 }
 
 size_t reject_select_scratch_bytes() { return sizeof(HselAll) > sizeof(HselState) ? sizeof(HselAll) : sizeof(HselState); }
+
+// a new (or re-used) state buffer of the one-launch form: all zero, the two `nxt` words at ~0
+hipError_t hsel_state_init(hipStream_t s, void *state)
+{
+    hipError_t e = hipMemsetAsync(state, 0, reject_select_scratch_bytes(), s);
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(&((HselAll *)state)->nxt[0], 0xff, 2 * sizeof(unsigned long long), s);
+}
 
 // One-launch form.  `state` must have been zeroed (hipMemset) when it was allocated and is left clean by every launch;
 // *bar_total is the host's running count of what the launches on this buffer have added to its barrier counter.

@@ -86,6 +86,10 @@ int  lm_eval_grid(long Q);
 void launch_lm_eval(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
                     const uint8_t *keep, long Q, const TailArgs &A, const IcpDev *st, LmDev *L, const double *stats, double *partial,
                     unsigned *ticket, double *resid0, double *resid1, int rank = 0, int world = 1, double *gsum = nullptr);
+void launch_lm_all(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
+                   const uint8_t *keep, long Q, const TailArgs &A, IcpDev *st, LmDev *L, const double *rj4, const double *stats,
+                   double *partial, void *bar, unsigned long long *bar_total, double *resid0, double *resid1, double *rec);
+size_t lm_bar_bytes();
 void launch_lm_advance(hipStream_t s, const TailArgs &A, const IcpDev *st, LmDev *L, const double *stats, const double *gsum);
 void launch_lm_finish(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
                       const uint8_t *keep, long Q, const TailArgs &A, IcpDev *st, LmDev *L, const double *rj4, const double *stats,
@@ -121,6 +125,7 @@ void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const do
 void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec);
 void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, double *d2, int64_t *idx, double *p2);
 size_t reject_select_scratch_bytes();
+hipError_t hsel_state_init(hipStream_t s, void *state);
 hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
                                        double *out3, void *state, unsigned long long *bar_total, double *partial, double *host_out,
                                        double seq, const IcpDev *st);

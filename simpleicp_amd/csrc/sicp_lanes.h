@@ -81,6 +81,52 @@ __device__ __forceinline__ unsigned long long wsum_u64(unsigned long long v)
     return v;
 }
 
+
+// ---- grid barrier for kernels whose blocks are all resident at once (at most one block per CU is launched) -------------------
+// Arrivals are counted at one address, the release is published at another: the waiting blocks poll `gen` (a load nobody
+// writes until the barrier opens), so they do not queue up behind -- and slow down -- the arriving blocks' read-modify-writes on
+// `bar` (256 pollers on the counter itself made a phase 40 % slower than a kernel boundary).  The counter only ever grows: a
+// launch adds exactly gridDim.x * MAXB to it (blocks top their share up when they leave, grid_barrier_leave), the host hands
+// every launch the value it starts from, barrier k of a launch waits for  base + gridDim.x * (k + 1)  -- no reset between
+// launches.  Polling is bounded (about two seconds): a launch that cannot meet itself flags an error and goes on instead of
+// hanging the queue.
+struct GridBar {
+    unsigned long long bar;        // arrivals, monotone over the life of the buffer
+    unsigned long long pad0[7];
+    unsigned long long gen;        // the last barrier target reached
+    unsigned long long pad1[7];
+    unsigned error;                // a wait timed out (sticky)
+    unsigned pad2[15];
+};
+__device__ __forceinline__ void grid_barrier(GridBar *B, unsigned long long target)
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long mine = __hip_atomic_fetch_add(&B->bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+        if (mine >= target) {
+            // last to arrive: open (a later barrier's opener can only run after this one's waiters have left: gen never moves back)
+            __hip_atomic_store(&B->gen, target, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            long spins = 0;
+            while (__hip_atomic_load(&B->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1L << 21)) { __hip_atomic_store(&B->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+// a block that leaves after `done` of its launch's `budget` barriers
+__device__ __forceinline__ void grid_barrier_leave(GridBar *B, int done, int budget)
+{
+    if (threadIdx.x == 0 && done < budget)
+        __hip_atomic_fetch_add(&B->bar, (unsigned long long)(budget - done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace sicp
 
 #endif

@@ -284,14 +284,12 @@ __global__ __launch_bounds__(64) void k_lm_advance(TailArgs A, const IcpDev *__r
 }
 
 // One workgroup.  rj4: (m, median, mad, n_kept) of the rejection; stats: (n, mean, std) of the kept distances.
-__global__ __launch_bounds__(LB) void k_lm_finish(
-    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
-    const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep, long Q, TailArgs A,
+__device__ __forceinline__ void lm_finish_body(
+    LmShared &S, double *out /* LDS, 64 */, const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+    const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep, long Q, const TailArgs &A,
     IcpDev *__restrict__ st, LmDev *__restrict__ L, const double *__restrict__ rj4, const double *__restrict__ stats,
     double *__restrict__ resid0, double *__restrict__ resid1, double *__restrict__ rec)
 {
-    __shared__ LmShared S;
-    __shared__ double out[64];
     const int tid = threadIdx.x;
     if (tid < 64) out[tid] = 0.0;
     if (st->stop) {
@@ -395,6 +393,104 @@ __global__ __launch_bounds__(LB) void k_lm_finish(
     }
 }
 
+__global__ __launch_bounds__(LB) void k_lm_finish(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+    const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep, long Q, TailArgs A,
+    IcpDev *__restrict__ st, LmDev *__restrict__ L, const double *__restrict__ rj4, const double *__restrict__ stats,
+    double *__restrict__ resid0, double *__restrict__ resid1, double *__restrict__ rec)
+{
+    __shared__ LmShared S;
+    __shared__ double out[64];
+    lm_finish_body(S, out, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, resid0, resid1, rec);
+}
+
+// ------------------------------------------------------------------------------------
+// The whole minimisation of an iteration in ONE launch (default without a sharded reduction): evaluations are phases of a single
+// kernel separated by grid barriers (sicp_lanes.h), so exactly the evaluations the solver needs are run -- the
+// launch-per-evaluation form enqueues `lm_evals` of them plus the finish and the unused ones exit at ~4 us apiece.
+//   * one barrier per evaluation: blocks write their 8x8 partials (two alternating buffers), meet, and then EVERY block folds
+//     all partials in the same fixed order and advances its OWN copy of the solver state (LDS) -- same numbers, same decisions,
+//     no second meeting to broadcast the next trial;
+//   * after the last evaluation block 0 stores the solver state and does what k_lm_finish does (residual statistics,
+//     convergence test, record + ticket, next iteration's start; and the completion loop in the never-seen case that
+//     LM_MAXB evaluations were not enough).
+// Same arithmetic in the same order as the launch-per-evaluation form with the same grid: bit-identical results.
+// ------------------------------------------------------------------------------------
+constexpr int LM_MAXB = 24;
+__global__ __launch_bounds__(LB) void k_lm_all(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+    const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep, long Q, TailArgs A,
+    IcpDev *__restrict__ st, LmDev *__restrict__ L, const double *__restrict__ rj4, const double *__restrict__ stats,
+    double *__restrict__ partial /* [2][gridDim.x][64] */, GridBar *__restrict__ B, unsigned long long bar_base,
+    double *__restrict__ resid0, double *__restrict__ resid1, double *__restrict__ rec)
+{
+    __shared__ LmShared S;
+    __shared__ LmDev Ls;
+    __shared__ double out[64];
+    const int tid = threadIdx.x;
+    int nb = 0;
+    if (st->stop || stats[0] < 6.0) {
+        // run over, or too few correspondences: nothing to minimise -- block 0 still reports (as k_lm_finish does)
+        if (blockIdx.x == 0) lm_finish_body(S, out, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, resid0, resid1, rec);
+        grid_barrier_leave(B, 0, LM_MAXB);
+        return;
+    }
+    {   // every block starts from the same solver state
+        const double *src = reinterpret_cast<const double *>(L);
+        double *dst = reinterpret_cast<double *>(&Ls);
+        for (int i = tid; i < (int)(sizeof(LmDev) / sizeof(double)); i += LB) dst[i] = src[i];
+    }
+    __syncthreads();
+    const long nchunks = (Q + LB - 1) / LB;
+    const unsigned g = gridDim.x;
+    while (!Ls.done && nb < LM_MAXB) {
+        double x[6], sc[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { x[j] = Ls.xt[j]; sc[j] = Ls.sct[j]; }
+        const int slot = Ls.cur ^ 1;
+        const double shift = Ls.first ? stats[1] : Ls.shift;
+        block_gram(S, qx, qy, qz, normals, p2, keep, Q, x, sc, shift, blockIdx.x, g, nchunks, slot ? resid1 : resid0);
+        double *mypart = partial + ((long)(nb & 1) * g + blockIdx.x) * 64;
+        if (tid < 64) mypart[tid] = S.gb[tid];
+        ++nb;
+        grid_barrier(B, bar_base + (unsigned long long)g * (unsigned long long)nb);
+        // fold the block partials in the launch-per-evaluation form's order: the block's waves take eight partials each per step
+        {
+            const double *all = partial + (long)((nb - 1) & 1) * g * 64;
+            const int wid = tid >> 6, lane = tid & 63;
+            double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (unsigned b0 = 0; b0 < g; b0 += 8 * LW) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned b = b0 + (unsigned)(wid * 8 + k);
+                    if (b < g) s8[k] += all[(long)b * 64 + lane];
+                }
+            }
+            S.gp[wid][0][lane] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double gsum = 0.0;
+#pragma unroll
+            for (int w = 0; w < LW; ++w) gsum += S.gp[w][0][tid];
+            S.gb[tid] = gsum;
+            lm_advance(S, &Ls, A, stats, shift);
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        {   // the state the finish (and the next iteration) reads
+            double *dst = reinterpret_cast<double *>(L);
+            const double *src = reinterpret_cast<const double *>(&Ls);
+            for (int i = tid; i < (int)(sizeof(LmDev) / sizeof(double)); i += LB) dst[i] = src[i];
+        }
+        __threadfence();
+        __syncthreads();
+        lm_finish_body(S, out, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, resid0, resid1, rec);
+    }
+    grid_barrier_leave(B, nb, LM_MAXB);
+}
+
 int lm_eval_grid(long Q)
 {
     // (one block per CU: the per-block ticket atomics serialise, see reject_by_select in sicp_grid.hip)
@@ -417,6 +513,18 @@ void launch_lm_eval(hipStream_t s, const double *qx, const double *qy, const dou
     hipLaunchKernelGGL(k_lm_eval, dim3(lm_eval_grid(mine)), dim3(LB), 0, s, qx, qy, qz, normals, p2, keep, Q, A, st, L, stats,
                        partial, ticket, resid0, resid1, lo, hi, gsum);
 }
+
+// one launch for the whole minimisation; *bar_total: what the launches on `bar` have added to its counter so far
+void launch_lm_all(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
+                   const uint8_t *keep, long Q, const TailArgs &A, IcpDev *st, LmDev *L, const double *rj4, const double *stats,
+                   double *partial, void *bar, unsigned long long *bar_total, double *resid0, double *resid1, double *rec)
+{
+    const unsigned g = (unsigned)lm_eval_grid(Q);
+    hipLaunchKernelGGL(k_lm_all, dim3(g), dim3(LB), 0, s, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, partial,
+                       (GridBar *)bar, *bar_total, resid0, resid1, rec);
+    *bar_total += (unsigned long long)g * LM_MAXB;
+}
+size_t lm_bar_bytes() { return sizeof(GridBar); }
 
 void launch_lm_advance(hipStream_t s, const TailArgs &A, const IcpDev *st, LmDev *L, const double *stats, const double *gsum)
 {

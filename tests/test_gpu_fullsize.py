@@ -285,8 +285,9 @@ def test_large_q_iterations_equal_oracle_at_full_size(data, big_q):
     # the chained loop lands on the same estimates
     c.icp_setup(sel, nv, pl)
     whole = c.icp_run(z, z, z, 0.3, 1.0, max_iterations=3, min_change=0.0)
+    # (the chained loop carries sin / cos forward on the device, the iterate loop takes them from libm: equal to rounding)
     assert np.abs(np.array(whole[-1].x[:]) - x).max() < 1e-12
-    assert whole[-1].n_kept == R.n_kept and whole[-1].median == R.median and whole[-1].mad == R.mad
+    assert whole[-1].n_kept == R.n_kept and abs(whole[-1].median - R.median) < 1e-12 and abs(whole[-1].mad - R.mad) < 1e-12
 
 
 def test_mid_q_iteration_equals_oracle_at_full_size(data, big_q):
