@@ -15,3 +15,4 @@ if [ "${FULL:-1}" = "1" ]; then
   timeout 700 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -k "large_q or mid_q or dataframes" > "$OUT/fullsize.log" 2>&1; tail -3 "$OUT/fullsize.log"
 fi
 head -20 "$OUT"/q_sweep_*.txt
+SICP_SOLVE_TRACE=1 timeout 300 python scripts/trace_c4.py 2>&1 | grep "\[tail\]" | tail -22 > "$OUT/tail_trace.txt"; tail -3 "$OUT/tail_trace.txt"

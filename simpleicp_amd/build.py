@@ -20,7 +20,11 @@ HEADERS = [CSRC / "sicp_internal.h", CSRC / "sicp_lanes.h", CSRC / "sicp_solver.
 # -amdgpu-mfma-vgpr-form: MFMA results land in ordinary VGPRs (gfx950's register file is unified), so the VALU work
 # that consumes them (min trees of the matrix-pipe filter, Gram folds) needs no v_accvgpr_read per register
 COMPILE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-           "-fvisibility=hidden", "-Wall", "-pthread", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+           "-fvisibility=hidden", "-Wall", "-pthread", "-mllvm", "-amdgpu-mfma-vgpr-form",
+           # the first 16 dwords of a kernel's arguments (8 pointers) arrive in SGPRs with the wave instead of through a load
+           # every dependent access queues behind; hot kernels order their parameters accordingly (falls back by itself
+           # where the firmware does not preload)
+           "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 LINK = ["--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"]
 OBJ = PKG / "_obj"
 LIB_ASAN = OBJ / "libsimpleicp_hip_asan.so"

@@ -293,15 +293,18 @@ __device__ __forceinline__ void post_match(const PostMatch &post, const Xf &H, l
 // with v_readlane (uniform row index: no LDS crossbar), lane l takes point l of each row, and the four 32-byte
 // record loads are in flight together.  A pass costs two dependent memory round trips (offsets, records).
 template <bool XFORM, bool CHAINED>
+// (parameter order: the eight pointers the first instructions need come first -- preloaded into SGPRs at wave start,
+// -amdgpu-kernarg-preload-count=16, instead of a kernarg load every dependent load would queue behind)
 __global__ __launch_bounds__(256) void k_grid_nn(
-    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, long Q,
+    const IcpDev *__restrict__ st,
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
     const double *__restrict__ prev_p2 /* nullable: (Q,3) a cloud point per query (last match) -> its exact
                                           distance under H bounds the answer */,
-    GridGeom G, const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
-    Xf H, Xf Hinv, double rmax, double max_d2, int64_t idx_base,
-    double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
-    const IcpDev *__restrict__ st, unsigned long long *__restrict__ work /* nullable: [0] candidates, [1] rows, [2] launches */,
+    const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
     const uint32_t *__restrict__ order /* nullable: queries in cell order (grid size is a multiple of 8 then) */,
+    long Q, GridGeom G, Xf H, Xf Hinv, double rmax, double max_d2, int64_t idx_base,
+    double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
+    unsigned long long *__restrict__ work /* nullable: [0] candidates, [1] rows, [2] launches */,
     int tight /* prev_p2 is a bound to search in one go (the nearest point of a subsample), not an old match */,
     PostMatch post /* chained match of an ICP iteration: the winning lane also leaves the point-to-plane distance and the
                       planarity verdict (corrpts.py:139-163,195-211) -- it holds the matched point, the query and H already */)
@@ -529,12 +532,12 @@ __global__ __launch_bounds__(256) void k_grid_nn(
 // ------------------------------------------------------------------------------------
 template <bool XFORM, bool CHAINED>
 __global__ __launch_bounds__(256, 4) void k_grid_nn16(
-    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, long Q,
-    const double *__restrict__ prev_p2, GridGeom G, const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
+    const IcpDev *__restrict__ st, const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+    const double *__restrict__ prev_p2, const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
+    const uint32_t *__restrict__ order, long Q, GridGeom G,
     Xf H, Xf Hinv, double rmax, double max_d2, int64_t idx_base,
     double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
-    const IcpDev *__restrict__ st, unsigned long long *__restrict__ work, const uint32_t *__restrict__ order, int tight,
-    PostMatch post)
+    unsigned long long *__restrict__ work, int tight, PostMatch post)
 {
     const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48;
     long blk = blockIdx.x;
@@ -1121,10 +1124,9 @@ __global__ __launch_bounds__(256) void k_keep_stats(const double *__restrict__ d
 // two per statistic) and nothing is dispatched in between -- the launch-per-phase form above enqueues 6 + 1 + 6 + 1 + 1 kernels
 // of which 8 exit at once, ~4 us apiece: at 32 768 correspondences that was ALL of the 65 us this step took.
 //
-//   * every block is resident at once (at most one block per CU is asked for, 256 lanes, 16 KiB of LDS), so a barrier is a
-//     counter every block's lane 0 adds to and then polls.  The counter only ever grows: a launch adds exactly
-//     gridDim.x * HS_MAXB to it (blocks top their share up when they leave), the host hands every launch the value it starts
-//     from, barrier k of a launch waits for  base + gridDim.x * (k + 1).  No reset, no memset between launches;
+//   * every block is resident at once (at most one block per CU is asked for, 256 lanes, 16 KiB of LDS), so the phases can meet
+//     at the grid barrier of sicp_lanes.h (fence-free: everything blocks tell each other here travels in agent-scope atomics;
+//     barrier numbers grow over the life of the state buffer, the host hands every launch the number it starts from);
 //   * a pass needs ONE barrier: blocks add their local histograms to hist[p % 3], meet, and then EVERY block reads the complete
 //     histogram and picks the bin itself (same integers, same answer) -- no second meeting to broadcast the pick.  The buffer two
 //     passes ahead, hist[(p + 2) % 3], is wiped right after the barrier of pass p: it was last read before barrier p was entered
@@ -1159,7 +1161,6 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
     const unsigned g = gridDim.x;
     int nb = 0;                                       // barriers this block has gone through
     if (st && st->stop) {                             // the run is over: leave, but leave the counter where the next launch expects it
-        grid_barrier_leave(&S->bar, 0, HS_MAXB);
         return;
     }
     const long stride = (long)g * (256 * HS_UNROLL);
@@ -1206,11 +1207,11 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
             }
             __syncthreads();
             for (int i = tid; i < HS_BINS; i += 256) if (hist[i]) atomicAdd(&gh[i], hist[i]);
-            grid_barrier(&S->bar, bar_base + (unsigned long long)g * (unsigned long long)(++nb));
+            grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb));
             // every block picks the bin itself: thread t owns bins 16t .. 16t+15 of the complete histogram
             unsigned h[16], mine = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { h[j] = gh[16 * tid + j]; mine += h[j]; }
+            for (int j = 0; j < 16; ++j) { h[j] = __hip_atomic_load(&gh[16 * tid + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mine += h[j]; }
             const unsigned incl = wscan_u32(mine);
             if (lane == 63) scan[wid] = incl;
             __syncthreads();
@@ -1276,7 +1277,7 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
             for (int w = 1; w < 4; ++w) tn = pnx[w] < tn ? pnx[w] : tn;
             if (tn != ~0ull) atomicMin(&S->nxt[which], tn);
         }
-        grid_barrier(&S->bar, bar_base + (unsigned long long)g * (unsigned long long)(++nb));
+        grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb));
         // every block ranks the survivors itself
         const unsigned long long above = __hip_atomic_load(&S->nxt[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < 2) pick[tid] = prefix;                  // (single-value interval: both middles are that value unless ...)
@@ -1330,12 +1331,15 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
     n = wsum(n); s1 = wsum(s1); s2 = wsum(s2);
     if (lane == 0) { red[wid][0] = n; red[wid][1] = s1; red[wid][2] = s2; }
     __syncthreads();
-    if (tid < 3) partial[(long)tid * NE_MAX_GRID + blockIdx.x] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    grid_barrier(&S->bar, bar_base + (unsigned long long)g * (unsigned long long)(++nb));
+    if (tid < 3)
+        __hip_atomic_store(&partial[(long)tid * NE_MAX_GRID + blockIdx.x], (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb));
     if (blockIdx.x == 0) {
         if (wid < 3) {
             double t = 0;
-            for (unsigned blk = lane; blk < g; blk += 64) t += partial[(long)wid * NE_MAX_GRID + blk];
+            for (unsigned blk = lane; blk < g; blk += 64)
+                t += __hip_atomic_load(&partial[(long)wid * NE_MAX_GRID + blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             t = wsum(t);
             if (lane == 0) red[0][wid] = t;
         }
@@ -1360,7 +1364,6 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
             __hip_atomic_store(&S->ncand[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    grid_barrier_leave(&S->bar, nb, HS_MAXB);      // top the counter up to this launch's fixed share
 }
 
 size_t reject_select_scratch_bytes() { return sizeof(HselAll) > sizeof(HselState) ? sizeof(HselAll) : sizeof(HselState); }
@@ -1383,7 +1386,7 @@ hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const 
     const unsigned g = (unsigned)std::max<long>(1, std::min<long>(cap, (Q + 256 * HS_UNROLL - 1) / (256 * HS_UNROLL)));
     hipLaunchKernelGGL(k_hsel_all, dim3(g), dim3(256), 0, s, dist, flag, Q, (HselAll *)state, *bar_total, keep, partial, out4, out3,
                        host_out, seq, st);
-    *bar_total += (unsigned long long)g * HS_MAXB;
+    *bar_total += (unsigned long long)HS_MAXB;
     return hipGetLastError();
 }
 
@@ -1472,21 +1475,17 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
     if (four_per_wave) {
         const dim3 g16(cdiv(Q, 16));
         if (H)
-            hipLaunchKernelGGL((k_grid_nn16<true, false>), g16, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec,
-                               *H, *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work,
-                               (const uint32_t *)nullptr, 0, PostMatch{});
+            hipLaunchKernelGGL((k_grid_nn16<true, false>), g16, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, *H, *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{});
         else
-            hipLaunchKernelGGL((k_grid_nn16<false, false>), g16, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec,
-                               id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work,
-                               (const uint32_t *)nullptr, 0, PostMatch{});
+            hipLaunchKernelGGL((k_grid_nn16<false, false>), g16, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{});
         return;
     }
     if (H)
-        hipLaunchKernelGGL((k_grid_nn<true, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec, *H,
-                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work, (const uint32_t *)nullptr, 0, PostMatch{});
+        hipLaunchKernelGGL((k_grid_nn<true, false>), grid, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, *H,
+                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{});
     else
-        hipLaunchKernelGGL((k_grid_nn<false, false>), grid, block, 0, s, qx, qy, qz, Q, prev_p2, G, cell_start, (const double4 *)rec, id,
-                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, (const IcpDev *)nullptr, work, (const uint32_t *)nullptr, 0, PostMatch{});
+        hipLaunchKernelGGL((k_grid_nn<false, false>), grid, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, id,
+                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{});
 }
 
 // the match of a chained iteration: transform taken from the loop state on the device
@@ -1501,14 +1500,12 @@ void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, c
     if (four_per_wave) {
         unsigned g16 = cdiv(Q, 16);
         if (order) g16 = (g16 + 7u) & ~7u;
-        hipLaunchKernelGGL((k_grid_nn16<true, true>), dim3(g16), dim3(256), 0, s, qx, qy, qz, Q, prev_p2, G, cell_start,
-                           (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work, order, tight ? 1 : 0, pm);
+        hipLaunchKernelGGL((k_grid_nn16<true, true>), dim3(g16), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, tight ? 1 : 0, pm);
         return;
     }
     unsigned g = cdiv(Q, 4);
     if (order) g = (g + 7u) & ~7u;
-    hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(g), dim3(256), 0, s, qx, qy, qz, Q, prev_p2, G, cell_start,
-                       (const double4 *)rec, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, st, work, order, tight ? 1 : 0, pm);
+    hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, tight ? 1 : 0, pm);
 }
 
 void launch_stride_sample(hipStream_t s, const double *x, const double *y, const double *z, long n, long stride, long m, long mpad,

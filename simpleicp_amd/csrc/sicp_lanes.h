@@ -83,48 +83,57 @@ __device__ __forceinline__ unsigned long long wsum_u64(unsigned long long v)
 
 
 // ---- grid barrier for kernels whose blocks are all resident at once (at most one block per CU is launched) -------------------
-// Arrivals are counted at one address, the release is published at another: the waiting blocks poll `gen` (a load nobody
-// writes until the barrier opens), so they do not queue up behind -- and slow down -- the arriving blocks' read-modify-writes on
-// `bar` (256 pollers on the counter itself made a phase 40 % slower than a kernel boundary).  The counter only ever grows: a
-// launch adds exactly gridDim.x * MAXB to it (blocks top their share up when they leave, grid_barrier_leave), the host hands
-// every launch the value it starts from, barrier k of a launch waits for  base + gridDim.x * (k + 1)  -- no reset between
-// launches.  Polling is bounded (about two seconds): a launch that cannot meet itself flags an error and goes on instead of
-// hanging the queue.
+// What three measured versions taught (Q = 1 M, 256 blocks, a phase = one pass over 9 MB):
+//   * one counter that everybody adds to AND polls: the pollers queue up in front of the arrivals -- a phase cost 21 us against
+//     11 us for a kernel boundary;
+//   * release / acquire FENCES in the barrier (buffer_wbl2 / buffer_inv: every block writes its L2 back and drops it, 256 times
+//     per barrier) cost more than the barrier -- so there are none: blocks exchange data through agent-scope atomic loads and
+//     stores (performed at the coherence point), and whatever they read again in the next phase stays in their L2;
+//   * 256 same-address read-modify-writes serialise at ~20 ns apiece (5 us): arrivals are counted in 8 groups (blockIdx & 7, a
+//     line each) whose last member reports to a top counter -- 32 + 8 in a row instead of 256.
+// The last arriver of a counter resets it BEFORE it reports upwards, the last of all then publishes the barrier's number in
+// `gen`, the only word the waiting blocks poll.  Barrier numbers grow monotonically over the life of the buffer: the host hands
+// every launch the number it starts from (launch index * the kernel's barrier budget) -- nothing to reset between launches, and a
+// launch that leaves early leaves nothing behind.  Polling is bounded (about two seconds): a launch that cannot meet itself
+// flags an error and goes on instead of hanging the queue.
 struct GridBar {
-    unsigned long long bar;        // arrivals, monotone over the life of the buffer
-    unsigned long long pad0[7];
-    unsigned long long gen;        // the last barrier target reached
-    unsigned long long pad1[7];
+    struct Line { unsigned v; unsigned pad[31]; };
+    Line sub[8];                   // arrivals per group, 0 between barriers
+    Line top;                      // groups that are complete, 0 between barriers
+    unsigned long long gen;        // number of the last barrier every block reached
+    unsigned long long pad1[15];
     unsigned error;                // a wait timed out (sticky)
-    unsigned pad2[15];
+    unsigned pad2[31];
 };
-__device__ __forceinline__ void grid_barrier(GridBar *B, unsigned long long target)
+// all threads call it; every cross-block datum published before must have been written with agent-scope atomics
+__device__ __forceinline__ void grid_barrier(GridBar *B, unsigned long long number)
 {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long mine = __hip_atomic_fetch_add(&B->bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
-        if (mine >= target) {
-            // last to arrive: open (a later barrier's opener can only run after this one's waiters have left: gen never moves back)
-            __hip_atomic_store(&B->gen, target, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
+        const unsigned g = gridDim.x, c = blockIdx.x & 7u;
+        const unsigned n_c = (g + 7u - c) >> 3, groups = g < 8u ? g : 8u;
+        bool opener = false;
+        if (__hip_atomic_fetch_add(&B->sub[c].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_c - 1u) {
+            __hip_atomic_store(&B->sub[c].v, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (__hip_atomic_fetch_add(&B->top.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u) {
+                __hip_atomic_store(&B->top.v, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&B->gen, number, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                opener = true;
+            }
+        }
+        if (!opener) {
             long spins = 0;
-            while (__hip_atomic_load(&B->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(8);
+            while (__hip_atomic_load(&B->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < number) {
+                __builtin_amdgcn_s_sleep(4);
                 if (++spins > (1L << 21)) { __hip_atomic_store(&B->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    asm volatile("" ::: "memory");
     __syncthreads();
-}
-// a block that leaves after `done` of its launch's `budget` barriers
-__device__ __forceinline__ void grid_barrier_leave(GridBar *B, int done, int budget)
-{
-    if (threadIdx.x == 0 && done < budget)
-        __hip_atomic_fetch_add(&B->bar, (unsigned long long)(budget - done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace sicp

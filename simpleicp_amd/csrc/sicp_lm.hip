@@ -432,7 +432,6 @@ __global__ __launch_bounds__(LB) void k_lm_all(
     if (st->stop || stats[0] < 6.0) {
         // run over, or too few correspondences: nothing to minimise -- block 0 still reports (as k_lm_finish does)
         if (blockIdx.x == 0) lm_finish_body(S, out, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, resid0, resid1, rec);
-        grid_barrier_leave(B, 0, LM_MAXB);
         return;
     }
     {   // every block starts from the same solver state
@@ -451,9 +450,9 @@ __global__ __launch_bounds__(LB) void k_lm_all(
         const double shift = Ls.first ? stats[1] : Ls.shift;
         block_gram(S, qx, qy, qz, normals, p2, keep, Q, x, sc, shift, blockIdx.x, g, nchunks, slot ? resid1 : resid0);
         double *mypart = partial + ((long)(nb & 1) * g + blockIdx.x) * 64;
-        if (tid < 64) mypart[tid] = S.gb[tid];
+        if (tid < 64) __hip_atomic_store(&mypart[tid], S.gb[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ++nb;
-        grid_barrier(B, bar_base + (unsigned long long)g * (unsigned long long)nb);
+        grid_barrier(B, bar_base + (unsigned long long)nb);
         // fold the block partials in the launch-per-evaluation form's order: the block's waves take eight partials each per step
         {
             const double *all = partial + (long)((nb - 1) & 1) * g * 64;
@@ -463,7 +462,7 @@ __global__ __launch_bounds__(LB) void k_lm_all(
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const unsigned b = b0 + (unsigned)(wid * 8 + k);
-                    if (b < g) s8[k] += all[(long)b * 64 + lane];
+                    if (b < g) s8[k] += __hip_atomic_load(&all[(long)b * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             S.gp[wid][0][lane] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
@@ -488,7 +487,6 @@ __global__ __launch_bounds__(LB) void k_lm_all(
         __syncthreads();
         lm_finish_body(S, out, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, resid0, resid1, rec);
     }
-    grid_barrier_leave(B, nb, LM_MAXB);
 }
 
 int lm_eval_grid(long Q)
@@ -522,7 +520,7 @@ void launch_lm_all(hipStream_t s, const double *qx, const double *qy, const doub
     const unsigned g = (unsigned)lm_eval_grid(Q);
     hipLaunchKernelGGL(k_lm_all, dim3(g), dim3(LB), 0, s, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, partial,
                        (GridBar *)bar, *bar_total, resid0, resid1, rec);
-    *bar_total += (unsigned long long)g * LM_MAXB;
+    *bar_total += (unsigned long long)LM_MAXB;
 }
 size_t lm_bar_bytes() { return sizeof(GridBar); }
 

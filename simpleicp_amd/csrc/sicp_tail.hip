@@ -299,12 +299,14 @@ __device__ __forceinline__ void publish(double *rec, double seq)
 }  // namespace
 
 template <int EPT>
+// (parameter order: the eight pointers the first instructions need come first -- they are preloaded into SGPRs when the wave
+// starts, -amdgpu-kernarg-preload-count=16, instead of being fetched by a load the whole kernel would wait behind)
 __global__ __launch_bounds__(TB, 1) void k_icp_tail(
-    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
-    const float *__restrict__ normals, const double *__restrict__ p2, TailArgs A, IcpDev *__restrict__ st,
+    IcpDev *__restrict__ st,
     const double *__restrict__ dist /* point-to-plane distances and planarity verdicts of this iteration's matches: left by */,
     const uint8_t *__restrict__ flag /* the match kernel's winning lanes (or by k_postmatch behind a multi-GPU exchange)   */,
-    uint8_t *__restrict__ keep, double *__restrict__ resid, double *__restrict__ rec)
+    const double *__restrict__ p2, const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+    const float *__restrict__ normals, uint8_t *__restrict__ keep, double *__restrict__ resid, double *__restrict__ rec, TailArgs A)
 {
     __shared__ TailShared S;
     const int tid = threadIdx.x, wid = tid >> 6;
@@ -606,13 +608,13 @@ void launch_icp_tail(hipStream_t s, const double *qx, const double *qy, const do
 {
     // correspondences per lane: the register-resident copy is sized to the problem
     if (A.Q <= TB)
-        hipLaunchKernelGGL(k_icp_tail<1>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, p2, A, st, dist, flag, keep, resid, rec);
+        hipLaunchKernelGGL(k_icp_tail<1>, dim3(1), dim3(TB), 0, s, st, dist, flag, p2, qx, qy, qz, normals, keep, resid, rec, A);
     else if (A.Q <= 2 * TB)
-        hipLaunchKernelGGL(k_icp_tail<2>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, p2, A, st, dist, flag, keep, resid, rec);
+        hipLaunchKernelGGL(k_icp_tail<2>, dim3(1), dim3(TB), 0, s, st, dist, flag, p2, qx, qy, qz, normals, keep, resid, rec, A);
     else if (A.Q <= 4 * TB)
-        hipLaunchKernelGGL(k_icp_tail<4>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, p2, A, st, dist, flag, keep, resid, rec);
+        hipLaunchKernelGGL(k_icp_tail<4>, dim3(1), dim3(TB), 0, s, st, dist, flag, p2, qx, qy, qz, normals, keep, resid, rec, A);
     else
-        hipLaunchKernelGGL(k_icp_tail<8>, dim3(1), dim3(TB), 0, s, qx, qy, qz, normals, p2, A, st, dist, flag, keep, resid, rec);
+        hipLaunchKernelGGL(k_icp_tail<8>, dim3(1), dim3(TB), 0, s, st, dist, flag, p2, qx, qy, qz, normals, keep, resid, rec, A);
 }
 
 }  // namespace sicp
