@@ -336,6 +336,7 @@ def run(args):
     fused = nq <= 2048
     evals_per_it = ne_evals / args.steps
     bytes_bruteforce = n_local * 24 + nq * (24 + 16)        # read the searched cloud once + queries + (idx, d2)
+    # 72 B per kept correspondence and evaluation + the median / MAD passes (n * 8 B x 3) when they are in the launch
     bytes_solve = int(last.n_kept) * 72 * evals_per_it + (nq * 8 * 3 if fused else 0)
     pmc, pmc_src = load_pmc()
 
@@ -370,7 +371,7 @@ def run(args):
     else:
         r_match = roof(match_kernel, match_ms, bytes_bruteforce,
                        "brute-force Q x N scan: VALU-bound by construction (SURVEY 8d), cloud read once")
-    tail_kernel = "k_icp_tail" if fused else "k_lm_eval"
+    tail_kernel = "k_icp_tail" if fused else ("k_lm_eval" if exchange else "k_lm_all")
     r_solve = roof(tail_kernel, solve_ms, bytes_solve,
                    "everything after the match in ONE single-workgroup launch (distances, MAD rejection, LM with "
                    "device-side 6x6 solves): ~1000 correspondences = latency-bound on one CU by design, not bandwidth"
@@ -564,12 +565,13 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
                             "issue-bound", {"candidates_per_query": per["candidates"] / max(1, nq_local),
                                            "grid_rows_per_query": per["rows"] / max(1, nq_local),
                                            "pruning_ratio": (Nm * 24 + nq_local * 40) / max(1.0, bytes_match)}),
-           "roofline_solver": roof("k_lm_eval", avg["solve"], int(last.n_kept) * 72 * evals,
-                                   "the iteration's solver launches together (evaluations + finish): 72 B per kept correspondence and "
-                                   "evaluation, 8x8 Gram on the FP64 matrix pipe", {"evaluations_per_iteration": evals}),
-           "roofline_rejection": roof("k_hsel_pass" if nq > 16384 else "k_reject", avg["reject_select"], nq * 9 * (5 if nq > 16384 else 1),
-                                      "distances' median / MAD by digit selection + keep mask + statistics: 9 B per correspondence and pass "
-                                      "(two selection passes each for median and MAD, one keep / statistics pass)"),
+           "roofline_solver": roof("k_lm_eval" if exchange else "k_lm_all", avg["solve"], int(last.n_kept) * 72 * evals,
+                                   "the iteration's whole minimisation (one launch: evaluations as phases between grid barriers, then the "
+                                   "finish): 72 B per kept correspondence and evaluation, 8x8 Gram on the FP64 matrix pipe",
+                                   {"evaluations_per_iteration": evals}),
+           "roofline_rejection": roof("k_hsel_all" if nq > 16384 else "k_reject", avg["reject_select"], nq * 9 * (7 if nq > 16384 else 1),
+                                      "median / MAD by digit selection + keep mask + statistics in one launch: 9 B per correspondence and "
+                                      "sweep (two digit passes and one collecting sweep each for median and MAD, one keep / statistics sweep)"),
            "kernels_instrumented": {name: {"avg_ms": avg[name], "launches": timing[name]["launches"]} for name in timing},
            "setup": {"normals_ms": normals_ms},
            "solver": {"final_n_kept": int(last.n_kept), "final_res_std": last.res_std}}

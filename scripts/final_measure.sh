@@ -1,25 +1,46 @@
 #!/usr/bin/env bash
-# Everything the round's records are made of, in one GPU call:  scripts/final_measure.sh <tag>  -> gpurun_out/final_<tag>/ (+ prof_<tag>/)
+# Everything the round's records are made of, in one GPU call:  scripts/final_measure.sh <tag>  -> gpurun_out/final_<tag>/ (+ prof_<tag>*/)
+# Every step under its own timeout; partial results survive a cut-off call.  STEPS selects (default: all).
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/final_$TAG
+STEPS=${STEPS:-"bench configs exchange sweeps traces profiles c5"}
 mkdir -p "$OUT"
 cd "$REPO"
-for C in C4 C1 C2 C3; do
-  timeout 900 python bench.py --config $C --out "$OUT/bench_$C.json" > /dev/null 2> "$OUT/bench_$C.err"
-done
-timeout 600 python bench.py --force-exchange --partition cloud --no-cpu-baseline --no-end-to-end --no-bruteforce-leg --out "$OUT/bench_C4_exchange_cloud.json" > /dev/null 2> "$OUT/bench_x1.err"
-timeout 600 python bench.py --force-exchange --partition queries --no-cpu-baseline --no-end-to-end --no-bruteforce-leg --out "$OUT/bench_C4_exchange_queries.json" > /dev/null 2> "$OUT/bench_x2.err"
-timeout 900 python scripts/q_sweep.py 1e7 1000 2048 2049 10000 16384 32768 100000 1000000 > "$OUT/q_sweep.txt" 2>&1
-timeout 600 python scripts/datasets_run.py > "$OUT/datasets_run.txt" 2>&1
-timeout 600 python scripts/cold_match.py > "$OUT/cold_match.txt" 2>&1
-SICP_SOLVE_TRACE=1 timeout 600 python scripts/trace_c4.py 2>&1 | grep "\[tail\]" | tail -22 > "$OUT/tail_trace.txt"
-scripts/kernel_timeline.sh c4_$TAG scripts/trace_c4.py > "$OUT/kernel_timeline_c4.txt" 2>&1
-python scripts/iter_timeline.py gpurun_out/kt_c4_$TAG > "$OUT/iter_timeline.txt" 2>&1
-scripts/kernel_timeline.sh q1m_$TAG scripts/q_sweep.py 1e7 1000000 > "$OUT/kernel_timeline_q1m.txt" 2>&1
-timeout 900 python scripts/run_profile.py > "$OUT/run_profile.txt" 2>&1
-timeout 900 python scripts/run_profile.py 1e7 1000 1.0 > "$OUT/run_profile_overlap.txt" 2>&1
-scripts/gpu_profile.sh $TAG > "$OUT/gpu_profile.log" 2>&1
-timeout 1500 python bench.py --config C5size --repeats 5 --no-parity --no-cpu-baseline --no-end-to-end --no-bruteforce-leg --out "$OUT/bench_C5size.json" > /dev/null 2> "$OUT/bench_C5size.err"
-ls "$OUT"
+T0=$(date +%s)
+stamp() { echo "[$(( $(date +%s) - T0 )) s] $*" >> "$OUT/steps.log"; }
+has() { case " $STEPS " in *" $1 "*) return 0;; *) return 1;; esac; }
+if has bench; then
+  timeout 600 python bench.py --out "$OUT/bench_C4.json" > /dev/null 2> "$OUT/bench_C4.err"; stamp "bench C4 rc=$?"
+fi
+if has configs; then
+  for C in C1 C2 C3; do
+    timeout 600 python bench.py --config $C --out "$OUT/bench_$C.json" > /dev/null 2> "$OUT/bench_$C.err"; stamp "bench $C rc=$?"
+  done
+fi
+if has exchange; then
+  timeout 600 python bench.py --force-exchange --partition cloud --no-cpu-baseline --no-end-to-end --no-bruteforce-leg --throughput-q 100000 --out "$OUT/bench_C4_exchange_cloud.json" > /dev/null 2> "$OUT/bench_x1.err"; stamp "exchange cloud rc=$?"
+  timeout 600 python bench.py --force-exchange --partition queries --no-cpu-baseline --no-end-to-end --no-bruteforce-leg --throughput-q 0 --out "$OUT/bench_C4_exchange_queries.json" > /dev/null 2> "$OUT/bench_x2.err"; stamp "exchange queries rc=$?"
+fi
+if has sweeps; then
+  timeout 600 python scripts/q_sweep.py 1e7 1000 2048 2049 10000 16384 32768 100000 1000000 > "$OUT/q_sweep.txt" 2>&1; stamp "q_sweep rc=$?"
+  timeout 600 python scripts/datasets_run.py > "$OUT/datasets_run.txt" 2>&1; stamp "datasets rc=$?"
+  timeout 600 python scripts/cold_match.py > "$OUT/cold_match.txt" 2>&1; stamp "cold match rc=$?"
+fi
+if has traces; then
+  SICP_SOLVE_TRACE=1 timeout 600 python scripts/trace_c4.py 2>&1 | grep "\[tail\]" | tail -22 > "$OUT/tail_trace.txt"; stamp "tail trace"
+  scripts/kernel_timeline.sh c4_$TAG scripts/trace_c4.py > "$OUT/kernel_timeline_c4.txt" 2>&1
+  python scripts/iter_timeline.py gpurun_out/kt_c4_$TAG > "$OUT/iter_timeline.txt" 2>&1; stamp "iter timeline"
+  scripts/kernel_timeline.sh q1m_$TAG scripts/q_sweep.py 1e7 1000000 > "$OUT/kernel_timeline_q1m.txt" 2>&1; stamp "timeline q1m"
+  timeout 600 python scripts/run_profile.py > "$OUT/run_profile.txt" 2>&1; stamp "run profile rc=$?"
+fi
+if has profiles; then
+  scripts/gpu_profile.sh $TAG > "$OUT/gpu_profile.log" 2>&1; stamp "profile default"
+  PASSES="trace fetch write sq1" scripts/gpu_profile.sh ${TAG}_q1000000 --correspondences 1000000 >> "$OUT/gpu_profile.log" 2>&1; stamp "profile Q=1M"
+  PASSES="trace fetch write sq1" scripts/gpu_profile.sh ${TAG}_q100000 --correspondences 100000 >> "$OUT/gpu_profile.log" 2>&1; stamp "profile Q=100k"
+fi
+if has c5; then
+  timeout 1200 python bench.py --config C5size --repeats 5 --no-cpu-baseline --no-end-to-end --no-bruteforce-leg --throughput-q 0 --out "$OUT/bench_C5size.json" > /dev/null 2> "$OUT/bench_C5size.err"; stamp "C5size rc=$?"
+fi
+cat "$OUT/steps.log"; ls "$OUT"

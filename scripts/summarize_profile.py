@@ -20,7 +20,7 @@ ROOT = Path(__file__).resolve().parent.parent
 tag = sys.argv[1]
 dst = ROOT / "profiles" / tag
 dst.mkdir(parents=True, exist_ok=True)
-WATCH = ("grid_nn", "icp_tail", "knn1_f", "lm_eval", "lm_finish", "lm_advance", "k_reject", "k_scatter", "k_cell_ids", "k_cloud_stats",
+WATCH = ("grid_nn", "icp_tail", "knn1_f", "lm_eval", "lm_finish", "lm_advance", "lm_all", "k_reject", "k_scatter", "k_cell_ids", "k_cloud_stats",
          "hsel", "keep_stats", "postmatch", "grid_knn", "k_normals", "query_order", "pack_best", "lexmin")
 
 

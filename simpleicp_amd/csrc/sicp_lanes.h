@@ -111,8 +111,10 @@ __device__ __forceinline__ void grid_barrier(GridBar *B, unsigned long long numb
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned g = gridDim.x, c = blockIdx.x & 7u;
-        const unsigned n_c = (g + 7u - c) >> 3, groups = g < 8u ? g : 8u;
+        // (up to 64 blocks report to ONE group: the second level costs a dependent round trip that the serialisation of so few
+        // arrivals does not)
+        const unsigned g = gridDim.x, flat = g <= 64u ? 1u : 0u, c = flat ? 0u : (blockIdx.x & 7u);
+        const unsigned n_c = flat ? g : ((g + 7u - c) >> 3), groups = flat ? 1u : 8u;
         bool opener = false;
         if (__hip_atomic_fetch_add(&B->sub[c].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_c - 1u) {
             __hip_atomic_store(&B->sub[c].v, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
