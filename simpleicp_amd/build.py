@@ -76,6 +76,17 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defines, units=("sicp_tail",), verbose=False):
+    """An instrumented build for measurements (e.g. -DSICP_SEL_FINE_TRACE): `units` recompiled with `defines`, everything else
+    shared with the product build -> _obj/libsimpleicp_hip_<name>.so; load it with SICP_LIBRARY=<path>."""
+    build(verbose=verbose)
+    lib = OBJ / f"libsimpleicp_hip_{name}.so"
+    special = [s for s in SOURCES if s.stem in units]
+    objs = _objects(special, f".{name}", list(defines), True, verbose) + _objects([s for s in SOURCES if s.stem not in units], "", [], False, verbose)
+    _run([hipcc(), *LINK, "-o", str(lib), *map(str, objs)], verbose, f"linking {lib.name}")
+    return lib
+
+
 def build_asan(force=False, verbose=False):
     """The same library with its HOST translation units (C ABI + .xyz I/O) under AddressSanitizer and UBSan; the device
     objects are shared with the product build.  Host units go through g++ and GCC's sanitizer runtime: the one shipped with

@@ -106,9 +106,11 @@ __device__ __forceinline__ bool lm_step(const double *G, double w, const double 
     double inv[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
+        // v[k] = L[j][k] * D[k]: formed once per column, every product below is ONE fma
+        double v[6] = {0, 0, 0, 0, 0, 0};
         double d = M[j][j];
 #pragma unroll
-        for (int k = 0; k < j; ++k) d -= M[j][k] * M[j][k] * M[k][k];
+        for (int k = 0; k < j; ++k) { v[k] = M[j][k] * M[k][k]; d = fma(-M[j][k], v[k], d); }
         ok = ok && (d > 0.0) && (d < __builtin_inf());
         M[j][j] = d;
         double y = __builtin_amdgcn_rcp(d);
@@ -119,20 +121,20 @@ __device__ __forceinline__ bool lm_step(const double *G, double w, const double 
         for (int i = j + 1; i < 6; ++i) {
             double t = M[i][j];
 #pragma unroll
-            for (int k = 0; k < j; ++k) t -= M[i][k] * M[j][k] * M[k][k];
+            for (int k = 0; k < j; ++k) t = fma(-M[i][k], v[k], t);
             M[i][j] = t * y;
         }
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
 #pragma unroll
-        for (int k = 0; k < i; ++k) b[i] -= M[i][k] * b[k];
+        for (int k = 0; k < i; ++k) b[i] = fma(-M[i][k], b[k], b[i]);
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double t = b[i] * inv[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; ++k) t -= M[k][i] * dx[k];
+        for (int k = i + 1; k < 6; ++k) t = fma(-M[k][i], dx[k], t);
         dx[i] = t;
     }
     return ok;

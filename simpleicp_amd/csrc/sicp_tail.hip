@@ -63,6 +63,9 @@ struct TailShared {
     double red[2][NW][4];                  // block sums: one slot per call site, no reuse hazards
     double dmm[NW][2];                     // per-wave (min, -max) of the flagged distances
     unsigned long long wmin[NW];           // per-wave smallest member key above a selection's final interval
+#ifdef SICP_SEL_FINE_TRACE
+    long long selt[2][8]; int selw;        // cycle stamps inside the two selections (trace build only)
+#endif
     unsigned tot[256];                     // folded histogram of a selection round
     unsigned long long cand[CAND_MAX];
     unsigned ncand;
@@ -125,6 +128,12 @@ __device__ __forceinline__ void block_select(TailShared &S, unsigned *hc, const 
     unsigned cs = 0;                         // members inside [lo, hi] once the loop ends
     int sh = 0;
     unsigned *mycopy = hc + (lane & (HC - 1)) * 257;
+#ifdef SICP_SEL_FINE_TRACE
+#define SICP_ST(i) if (tid == 0) S.selt[S.selw][i] = clock64();
+#else
+#define SICP_ST(i)
+#endif
+    SICP_ST(0)
 #pragma unroll 1
     for (int round = 0; round < 10; ++round) {
         const unsigned long long range = hi - lo;
@@ -133,6 +142,7 @@ __device__ __forceinline__ void block_select(TailShared &S, unsigned *hc, const 
         for (int e = 0; e < EPT; ++e)
             if (k[e] != NOKEY && k[e] >= lo && k[e] <= hi) atomicAdd(&mycopy[(unsigned)((k[e] - lo) >> sh)], 1u);
         __syncthreads();
+        if (round == 0) { SICP_ST(1) }
         {   // lane t folds bin t over the copies and leaves them clean for the next round
             unsigned tot = 0;
 #pragma unroll
@@ -140,6 +150,7 @@ __device__ __forceinline__ void block_select(TailShared &S, unsigned *hc, const 
             S.tot[tid] = tot;
         }
         __syncthreads();
+        if (round == 0) { SICP_ST(2) }
         // every wave scans the 256 totals on its own (lane l owns bins 4l..4l+3)
         const uint4 h4 = *reinterpret_cast<const uint4 *>(&S.tot[4 * lane]);
         const unsigned mine = h4.x + h4.y + h4.z + h4.w;
@@ -159,18 +170,23 @@ __device__ __forceinline__ void block_select(TailShared &S, unsigned *hc, const 
         lo = lo + ((unsigned long long)s << sh);
         if (sh > 0) { const unsigned long long top = lo + ((1ull << sh) - 1ull); hi = top < hi ? top : hi; } else hi = lo;
         rounds_out = round + 1;
+        if (round == 0) { SICP_ST(3) }
         if (cs <= (unsigned)CAND_MAX || sh == 0) break;
     }
+    SICP_ST(4)
     const unsigned long long t = (unsigned long long)r - below;                 // rank inside the final interval
     const bool need_above = want2 && t + 1 >= cs;                                // the next rank lies above the final interval
     if (sh == 0 || lo == hi) {
         ka = lo; kb = lo;                                                         // one key value (cs copies of it)
     } else {
         // <= CAND_MAX members left: list them (at most 8 lanes touch the counter), then rank all pairs with one ballot
+        // (measured and not adopted: listing them per wave by ballot compaction, no atomics -- the gather got 100 cycles cheaper
+        // and the ranking 500 dearer, its lane-dependent LDS addresses are worth more than the atomics' return trip)
 #pragma unroll
         for (int e = 0; e < EPT; ++e)
             if (k[e] != NOKEY && k[e] >= lo && k[e] <= hi) { const unsigned slot = atomicAdd(&S.ncand, 1u); if (slot < (unsigned)CAND_MAX) S.cand[slot] = k[e]; }
         __syncthreads();
+        SICP_ST(5)
         if (tid == 0) S.ncand = 0u;             // (every gather atomic is behind the barrier; the next use is barriers away)
         const int ci = lane >> 3, cj = lane & 7;
         const unsigned long long vi = S.cand[ci], vj = S.cand[cj];
@@ -200,6 +216,7 @@ __device__ __forceinline__ void block_select(TailShared &S, unsigned *hc, const 
         for (int w = 1; w < NW; ++w) { const unsigned long long a = S.wmin[w]; b = a < b ? a : b; }
         kb = b;
     }
+    SICP_ST(6)
 }
 
 template <int EPT>
@@ -402,6 +419,10 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         }
         unsigned long long ka, kb;
         int nr = 0;
+#ifdef SICP_SEL_FINE_TRACE
+        if (tid == 0) S.selw = which;
+        __syncthreads();
+#endif
         block_select<EPT>(S, hc, key, (m - 1) / 2, (m & 1) == 0, klo, khi, ka, kb, nr);
         const double mid = (oval(ka) + oval(kb)) / 2.0;
         if (which == 0) { med = mid; rounds[0] = nr; } else { mad = mid; rounds[1] = nr; }
@@ -574,6 +595,11 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         for (int k = 0; k < 5; ++k) S.out[50 + k] = (double)(tk[k + 1] - tk[k]);
         S.out[59] = (double)t_eval; S.out[60] = (double)t_step; S.out[62] = (double)t_acc;
         S.out[55] = (double)(tsel - tk[1]); S.out[56] = rounds[0]; S.out[57] = (double)(tk[2] - tsel); S.out[58] = rounds[1];
+#ifdef SICP_SEL_FINE_TRACE
+        // (trace build: the splits of both selections overwrite the last twelve normal-equation sums of the record)
+        for (int wsel = 0; wsel < 2; ++wsel)
+            for (int i = 0; i < 6; ++i) S.out[38 + 6 * wsel + i] = (double)(S.selt[wsel][i + 1] - S.selt[wsel][i]);
+#endif
 
     }
     flush_out(S, rec, REC_TICKET);
