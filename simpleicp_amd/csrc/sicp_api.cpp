@@ -1637,6 +1637,8 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
         if (c->solve_trace && small_q && std::getenv("SICP_SEL_TRACE"))      // (a -DSICP_SEL_FINE_TRACE build: build.build_variant)
             std::fprintf(stderr, "[sel] median: atomics+barrier %.0f fold+barrier %.0f scan+pick %.0f (more rounds %.0f) gather+barrier %.0f rank %.0f | "
                                  "MAD: %.0f %.0f %.0f (%.0f) %.0f %.0f\n", o[38], o[39], o[40], o[41], o[42], o[43], o[44], o[45], o[46], o[47], o[48], o[49]);
+        if (c->solve_trace && small_q && std::getenv("SICP_EVAL_TRACE"))     // (a -DSICP_EVAL_FINE_TRACE build)
+            std::fprintf(stderr, "[eval] rows + LDS writes %.0f barrier %.0f MFMA Gram %.0f block write + barrier %.0f fold %.0f\n", o[38], o[39], o[40], o[41], o[42]);
         if (o[REC_CONVERGED] != 0.0) over = true;
     }
     return rc;

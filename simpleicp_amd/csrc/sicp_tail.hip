@@ -56,15 +56,25 @@ constexpr unsigned long long NOKEY = ~0ull;
 constexpr int ST_DOUBLES = sizeof(IcpDev) / sizeof(double);
 static_assert(sizeof(IcpDev) % sizeof(double) == 0 && ST_DOUBLES <= 64, "the loop state leaves the kernel as one 64-lane store");
 
+#ifdef SICP_EVAL_FINE_TRACE
+#define SICP_ET(i) if (threadIdx.x == 0) S.evt[i] = clock64();
+#else
+#define SICP_ET(i)
+#endif
+
 struct TailShared {
     double ja[SOLVE_MAX_Q][8];             // staged rows [a0..a5 | r | 1] of the kept correspondences (128 KiB at Q = 2048)
-    double gp[NW][2][64];                  // per-wave Gram blocks
+    double gp[NW][2][64];                  // per-wave Gram blocks (matrix-pipe form)
+    double gw[2][NW][32];                  // per-wave sums of an evaluation (two evaluations' worth)
     double gf[NW][2][64];                  // per-wave copies of the reduced Gram matrix: current estimate / trial
     double red[2][NW][4];                  // block sums: one slot per call site, no reuse hazards
     double dmm[NW][2];                     // per-wave (min, -max) of the flagged distances
     unsigned long long wmin[NW];           // per-wave smallest member key above a selection's final interval
 #ifdef SICP_SEL_FINE_TRACE
     long long selt[2][8]; int selw;        // cycle stamps inside the two selections (trace build only)
+#endif
+#ifdef SICP_EVAL_FINE_TRACE
+    long long evt[8];                      // cycle stamps inside the last evaluation (trace build only)
 #endif
     unsigned tot[256];                     // folded histogram of a selection round
     unsigned long long cand[CAND_MAX];
@@ -226,6 +236,129 @@ struct Corr {                                       // one lane's correspondence
     bool keep[EPT];
 };
 
+// ---- the 30 sums of an evaluation without the matrix pipe ------------------------------------------------------------
+// On gfx950 v_mfma_f64_16x16x4_f64 holds the pipe for 64 cycles (FP64 matrix peak = FP64 vector peak), and the Gram form wastes
+// half of every instruction on the two off-diagonal 8x8 blocks: 32 instructions = 2.3 k cycles per evaluation, plus the 64 bytes
+// per correspondence staged through LDS to transpose rows into operands (fine trace: rows + LDS writes 2.3 k, Gram 2.3 k of an
+// evaluation's 5.8 k).  Instead: every lane accumulates the 30 distinct sums (21 of J^T J, 6 of J^T r, sum r, sum r^2, n) of its own
+// correspondences with plain FMAs (28 per correspondence), and the wave adds them up with a HALVING butterfly -- at distance 32 a
+// lane pair splits the 30 values, each keeps 15 and receives the partner's share of those (v_permlane32_swap does the split, the
+// exchange and leaves two registers to add), then 8, 4, 2, 1: 15 + 8 + 4 + 2 + 1 + 1 = 31 additions instead of 30 x 6, and
+// lane l ends up owning ONE finished sum.  No rows in LDS, one barrier.
+__device__ __forceinline__ double swap_add32(double lo, double hi)
+{
+    // lanes 0..31 get lo(l) + lo(l + 32), lanes 32..63 get hi(l) + hi(l - 32)
+    const unsigned l0 = (unsigned)__double2loint(lo), l1 = (unsigned)__double2hiint(lo);
+    const unsigned h0 = (unsigned)__double2loint(hi), h1 = (unsigned)__double2hiint(hi);
+    const v2u_t a = __builtin_amdgcn_permlane32_swap(l0, h0, false, false), b = __builtin_amdgcn_permlane32_swap(l1, h1, false, false);
+    return __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
+}
+__device__ __forceinline__ double swap_add16(double lo, double hi)
+{
+    // lanes with (l & 16) == 0 get lo(l) + lo(l + 16), the others hi(l) + hi(l - 16)
+    const unsigned l0 = (unsigned)__double2loint(lo), l1 = (unsigned)__double2hiint(lo);
+    const unsigned h0 = (unsigned)__double2loint(hi), h1 = (unsigned)__double2hiint(hi);
+    const v2u_t a = __builtin_amdgcn_permlane16_swap(l0, h0, false, false), b = __builtin_amdgcn_permlane16_swap(l1, h1, false, false);
+    return __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
+}
+template <int J>
+__device__ __forceinline__ double split_add(double lo, double hi)
+{
+    // lanes with (l & J) == 0 get lo(l) + lo(l ^ J), the others hi(l) + hi(l ^ J)
+    if constexpr (J == 32) return swap_add32(lo, hi);
+    else if constexpr (J == 16) return swap_add16(lo, hi);
+    else {
+        const bool up = (threadIdx.x & J) != 0;
+        const double keep = up ? hi : lo, send = up ? lo : hi;
+        return keep + lane_xor_f64<J>(send);
+    }
+}
+// g[0..N) -> g[0..(N+1)/2): lanes with (l & J) == 0 keep the first half, the others the second (a missing last entry is 0)
+template <int N, int J>
+__device__ __forceinline__ void halve(double (&g)[30])
+{
+    constexpr int H = (N + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < H; ++i) g[i] = split_add<J>(g[i], i + H < N ? g[i + H] : 0.0);
+}
+// index (0..29) of the sum lane l owns after halve<30,32>, <15,16>, <8,8>, <4,4>, <2,2>, <1,1>; -1: none
+__device__ __forceinline__ int owned_sum(int lane)
+{
+    if (lane & 1) return -1;
+    const int low = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    if ((lane & 16) && low == 7) return -1;                 // the second half of 15 has only 7 entries
+    return ((lane >> 5) & 1) * 15 + ((lane >> 4) & 1) * 8 + low;
+}
+// position of G[u][v] in the list of 30: upper triangle of J^T J row by row (21), J^T r (6), sum r, sum r^2, n; -1: not kept
+// (G[k][7] = sum a_k, which nothing in this kernel reads)
+__device__ __forceinline__ int sum_index(int u, int v)
+{
+    if (u > v) { const int t = u; u = v; v = t; }
+    if (v < 6) return u * 6 - u * (u - 1) / 2 + (v - u);
+    if (v == 6) return u < 6 ? 21 + u : 28;
+    return u == 6 ? 27 : (u == 7 ? 29 : -1);
+}
+
+// Normal equations of the unweighted residuals at x over the kept correspondences, as the 8x8 matrix G of the rows
+// [a0..a5 | r | 1] (J^T J = G[0..5][0..5], J^T r = G[.][6], sum r = G[6][7], sum r^2 = G[6][6], n = G[7][7]; G[k][7] is not
+// formed), left in this wave's LDS slot S.gf[wave][slot].  `parity` alternates between consecutive evaluations (two buffers for
+// the waves' sums: a wave can be at most one evaluation ahead of another).
+template <int EPT>
+__device__ __forceinline__ void eval_ne(TailShared &S, const double (&x)[6], const double (&sc)[6], const Corr<EPT> &C,
+                                        double (&rr)[EPT], int slot, int parity)
+{
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    SICP_ET(0)
+    double H[12];
+    euler_H(x, sc, H);
+    const double s1 = sc[0], c1 = sc[1], s2 = sc[2], c2 = sc[3];
+    const double w3y = -s1 * c2, w3z = c1 * c2;
+    double g[30];
+#pragma unroll
+    for (int i = 0; i < 30; ++i) g[i] = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        double a[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (C.keep[e]) {
+            double X, Y, Z;
+            xfm(H, C.px[e], C.py[e], C.pz[e], X, Y, Z);
+            a[6] = pdist(X - C.qx[e], Y - C.qy[e], Z - C.qz[e], C.nx[e], C.ny[e], C.nz[e]);
+            const double nx = C.nx[e], ny = C.ny[e], nz = C.nz[e];
+            const double ux = X - x[3], uy = Y - x[4], uz = Z - x[5];          // R p
+            const double cx = uy * nz - uz * ny, cy = uz * nx - ux * nz, cz = ux * ny - uy * nx;   // (R p) x n
+            a[0] = cx;
+            a[1] = c1 * cy + s1 * cz;
+            a[2] = s2 * cx + w3y * cy + w3z * cz;
+            a[3] = nx; a[4] = ny; a[5] = nz;
+        }
+        rr[e] = a[6];
+        int t = 0;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int v = u; v < 6; ++v) { g[t] = fma(a[u], a[v], g[t]); ++t; }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) g[21 + u] = fma(a[u], a[6], g[21 + u]);
+        g[27] += a[6];
+        g[28] = fma(a[6], a[6], g[28]);
+        g[29] += C.keep[e] ? 1.0 : 0.0;
+    }
+    SICP_ET(1)
+    halve<30, 32>(g); halve<15, 16>(g); halve<8, 8>(g); halve<4, 4>(g); halve<2, 2>(g); halve<1, 1>(g);
+    SICP_ET(2)
+    const int mine = owned_sum(lane);
+    if (mine >= 0) S.gw[parity][wid][mine] = g[0];
+    SICP_ET(3)
+    __syncthreads();
+    SICP_ET(4)
+    // every wave adds the four waves' sums itself (fixed order) and parks the matrix in its own LDS slot
+    const int idx = sum_index(lane >> 3, lane & 7);
+    double v = 0.0;
+    if (idx >= 0) v = (S.gw[parity][0][idx] + S.gw[parity][1][idx]) + (S.gw[parity][2][idx] + S.gw[parity][3][idx]);
+    S.gf[wid][slot][lane] = v;
+    SICP_ET(5)
+}
+
 // Normal equations of the unweighted residuals at x over the kept correspondences as the 8x8 Gram matrix G of the
 // rows [a0..a5 | r | 1] (J^T J = G[0..5][0..5], J^T r = G[.][6], sum r = G[6][7], sum r^2 = G[6][6], n = G[7][7]),
 // left in this wave's LDS slot S.gf[wave][slot] -- the sums are uniform, registers are not spent on them.
@@ -233,10 +366,11 @@ struct Corr {                                       // one lane's correspondence
 // w1 = e_x, w2 = Rx e_y = (0, c1, s1), w3 = Rx Ry e_z = (s2, -s1 c2, c1 c2)  (R = Rx Ry Rz, mathutils.py:39-68):
 // a_k = w_k . ((R p) x n).
 template <int EPT>
-__device__ __forceinline__ void eval_ne(TailShared &S, const double (&x)[6], const double (&sc)[6], const Corr<EPT> &C,
-                                        double (&rr)[EPT], int slot)
+__device__ __forceinline__ void eval_ne_mfma(TailShared &S, const double (&x)[6], const double (&sc)[6], const Corr<EPT> &C,
+                                             double (&rr)[EPT], int slot)
 {
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    SICP_ET(0)
     double H[12];
     euler_H(x, sc, H);
     const double s1 = sc[0], c1 = sc[1], s2 = sc[2], c2 = sc[3];
@@ -262,7 +396,9 @@ __device__ __forceinline__ void eval_ne(TailShared &S, const double (&x)[6], con
         row[0] = make_double2(a[0], a[1]); row[1] = make_double2(a[2], a[3]);
         row[2] = make_double2(a[4], a[5]); row[3] = make_double2(a[6], a[7]);
     }
+    SICP_ET(1)
     __syncthreads();
+    SICP_ET(2)
     // Gram product on the FP64 matrix pipe.  v_mfma_f64_16x16x4_f64: A[m = lane&15][k = lane>>4], B[k][n = lane&15],
     // one f64 per lane each.  Lane l supplies component (l & 7) of correspondence  base + 8 j + 4 ((l >> 3) & 1) + (l >> 4)
     // as BOTH operands: rows / columns 0..7 of D accumulate the Gram block of four correspondences, rows / columns
@@ -271,14 +407,15 @@ __device__ __forceinline__ void eval_ne(TailShared &S, const double (&x)[6], con
     {
         const double *src = &S.ja[wid * (EPT * 64) + 4 * ((lane >> 3) & 1) + (lane >> 4)][lane & 7];
 #pragma unroll
-        for (int j = 0; j < EPT * 4; ++j) {                  // unrolled: the LDS reads of all steps are in flight together
-            const double v = src[0], u = src[64];            // 8 rows x 8 doubles further
+        for (int j = 0; j < EPT * 4; ++j) {                  // (reading the whole batch first was measured SLOWER: v_mfma_f64_16x16x4 holds
+            const double v = src[0], u = src[64];            //  the pipe for 64 cycles on gfx950, the interleaved LDS reads hide behind it)
             src += 128;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(u, u, acc2, 0, 0, 0);
         }
         acc += acc2;
     }
+    SICP_ET(3)
     // D: col = lane & 15, row = (lane >> 4) + 4 * reg
     {
         const int n = lane & 15;
@@ -289,12 +426,14 @@ __device__ __forceinline__ void eval_ne(TailShared &S, const double (&x)[6], con
         }
     }
     __syncthreads();
+    SICP_ET(4)
     // every wave folds the partial blocks itself and parks the result in its own LDS slot (a wave's LDS
     // operations are ordered: no barrier between this write and the reads that follow)
     double g = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) g += S.gp[w][0][lane] + S.gp[w][1][lane];
     S.gf[wid][slot][lane] = g;
+    SICP_ET(5)
 }
 
 // wave 0: the words parked in S.out leave in ONE store instruction; for the record the completion ticket
@@ -483,6 +622,7 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
     for (int j = 0; j < 6; ++j) { xn[j] = x[j]; scn[j] = sc[j]; }
     int steps = 0, evals = 0, cur = 1, tries = 0;
     bool first = true;
+    double d0n = 1.0, d0s1 = 0.0, d0s2 = 0.0;
     double cost = 0.0, lambda = 0.0, dxmax = 0.0;
     // finer split of the solver loop (-DSICP_TAIL_FINE_TRACE: each reading drains the LDS queue, ~100 cycles -- off by default;
     // measured at C4: evaluation 5.35 k cycles, acceptance 1.05 k, 6x6 solve 2.3 k, trial angles + loop 2.2 k per round)
@@ -495,14 +635,18 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
 #pragma unroll 1
     for (;;) {
         SICP_FT(const long long te0 = clock64();)
-        eval_ne<EPT>(S, xn, scn, C, rrn, cur ^ 1); ++evals;      // (its first barrier orders it after the last one's LDS reads)
+#ifdef SICP_TAIL_MFMA_GRAM
+        eval_ne_mfma<EPT>(S, xn, scn, C, rrn, cur ^ 1); ++evals;      // (its first barrier orders it after the last one's LDS reads)
+#else
+        eval_ne<EPT>(S, xn, scn, C, rrn, cur ^ 1, evals & 1); ++evals;
+#endif
         SICP_FT(const long long te1 = clock64(); t_eval += te1 - te0;)
         const double costn = objective(S.gf[wid][cur ^ 1], w, xn, A);
-        if (first && !need_w && tid == 0) {
-            // r = d at the start estimate: sum r, sum r^2, n of this evaluation ARE the kept distances' statistics
+        if (first) {
+            // r = d at the start estimate: sum r, sum r^2, n of this evaluation ARE the kept distances' statistics (turned into
+            // mean / std where the record is written: two divisions and a root are not on the solver's path)
             const double *G0 = S.gf[wid][cur ^ 1];
-            const double n0 = G0[7 * 8 + 7], mean0 = G0[6 * 8 + 7] / n0, var0 = G0[6 * 8 + 6] / n0 - mean0 * mean0;
-            S.out[4] = mean0; S.out[5] = sqrt(var0 > 0.0 ? var0 : 0.0);
+            d0n = G0[7 * 8 + 7]; d0s1 = G0[6 * 8 + 7]; d0s2 = G0[6 * 8 + 6];
         }
         if (first || costn <= cost * (1 + 1e-12) || dxmax < 1e-15) {          // 1e-12: rounding noise of the sums
 #pragma unroll
@@ -585,6 +729,10 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         S.out[20 + tid] = G[u * 8 + v];
     }
     if (tid == 0) {
+        if (!need_w) {
+            const double mean0 = d0s1 / d0n, var0 = d0s2 / d0n - mean0 * mean0;
+            S.out[4] = mean0; S.out[5] = sqrt(var0 > 0.0 ? var0 : 0.0);
+        }
         S.out[6] = w; S.out[7] = cost; S.out[8] = steps; S.out[9] = evals;
 #pragma unroll
         for (int j = 0; j < 6; ++j) S.out[10 + j] = x[j];
@@ -595,6 +743,9 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         for (int k = 0; k < 5; ++k) S.out[50 + k] = (double)(tk[k + 1] - tk[k]);
         S.out[59] = (double)t_eval; S.out[60] = (double)t_step; S.out[62] = (double)t_acc;
         S.out[55] = (double)(tsel - tk[1]); S.out[56] = rounds[0]; S.out[57] = (double)(tk[2] - tsel); S.out[58] = rounds[1];
+#ifdef SICP_EVAL_FINE_TRACE
+        for (int i = 0; i < 5; ++i) S.out[38 + i] = (double)(S.evt[i + 1] - S.evt[i]);
+#endif
 #ifdef SICP_SEL_FINE_TRACE
         // (trace build: the splits of both selections overwrite the last twelve normal-equation sums of the record)
         for (int wsel = 0; wsel < 2; ++wsel)
