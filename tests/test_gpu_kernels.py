@@ -562,3 +562,48 @@ def test_rejection_with_massive_duplicate_distances(ctx, Q, layers):
     assert R.median == o["median"] and R.mad == o["mad"] and R.n_kept == o["n"]
     assert np.array_equal(keep, o["keep"])
     assert np.array_equal(np.array(R.x[:]), z6)
+
+
+@pytest.mark.parametrize("Q", [16_385, 40_000])
+@pytest.mark.parametrize("quantised", [False, True])
+def test_one_launch_forms_equal_launch_per_phase_forms(Q, quantised):
+    """The large-Q rejection (k_hsel_all) and minimisation (k_lm_all) as ONE launch each, phases meeting at grid barriers,
+    against their launch-per-phase forms (SICP_HSEL=launches: k_hsel_pass / k_hsel_finish / k_keep_stats; SICP_LM=launches:
+    k_lm_eval x E + k_lm_finish): the same integers and the same sums in the same order -- median, MAD, keep mask, kept
+    statistics, estimate and residuals bit for bit, over three chained iterations and through sicp_icp_run."""
+    import os
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(Q + 17)
+    n = 70_000
+    P = _surface(n, 43)
+    x_true = np.array([0.002, -0.001, 0.003, 0.05, -0.03, 0.02])
+    Xm = orc.transform(np.linalg.inv(orc.params_to_H(x_true)), P + rng.normal(0, 0.01, P.shape))
+    if quantised:
+        P, Xm = np.round(P, 2), np.round(Xm, 2)                 # thousands of exactly equal distances
+    sel = np.sort(rng.choice(n, Q, replace=False))
+    z = np.zeros(6)
+    out = {}
+    for form in ("one", "launches"):
+        if form == "launches":
+            os.environ["SICP_HSEL"] = "launches"; os.environ["SICP_LM"] = "launches"
+        try:
+            c = _lib.Context(0)
+        finally:
+            os.environ.pop("SICP_HSEL", None); os.environ.pop("SICP_LM", None)
+        with c:
+            c.upload(_lib.FIX, P); c.upload(_lib.MOV, Xm)
+            nv, pl = c.estimate_normals(_lib.FIX, sel, 10)
+            c.icp_setup(sel, nv, pl)
+            x, rec = z.copy(), []
+            for it in range(3):
+                R = c.icp_iterate(x, z, z, 0.3, 1.0)
+                idx, dist, keep, resid = c.icp_state()
+                rec.append((np.array(R.x[:]), R.n_kept, R.median, R.mad, R.dist_mean, R.dist_std, R.res_mean, R.res_std, keep, resid, R.ne_evals))
+                x = np.array(R.x[:])
+            c.icp_setup(sel, nv, pl)
+            whole = c.icp_run(z, z, z, 0.3, 1.0, max_iterations=4, min_change=0.0)
+            rec.append(tuple(np.array(w.x[:]) for w in whole))
+        out[form] = rec
+    for a, b in zip(out["one"][:3], out["launches"][:3]):
+        assert np.array_equal(a[0], b[0]) and a[1:8] == b[1:8] and np.array_equal(a[8], b[8]) and np.array_equal(a[9], b[9]) and a[10] == b[10]
+    assert all(np.array_equal(p, q) for p, q in zip(out["one"][3], out["launches"][3]))
