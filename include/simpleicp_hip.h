@@ -271,7 +271,7 @@ int sicp_device_memory(sicp_ctx *ctx, int64_t *free_out, int64_t *total_out);
  *   SICP_PART_CLOUD   (default) every rank holds a contiguous index range of the searched cloud and all Q queries; one
  *                     all-gather of per-query winners + lexicographic minimum per iteration;
  *   SICP_PART_QUERIES every rank holds the WHOLE searched cloud (index_base 0) and matches Q / world of the queries;
- *                     one all-gather of the slices per iteration, no reduction.  Pays off when the match dominates
+ *                     one all-gather of the slices' matched indices per iteration (8 bytes per query), no reduction.  Pays off when the match dominates
  *                     (Q >= ~1e5); needs the default grid search.  sicp_knn / sicp_select_in_range are then local. */
 #define SICP_PART_CLOUD   0
 #define SICP_PART_QUERIES 1

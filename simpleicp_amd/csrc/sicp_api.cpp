@@ -475,17 +475,22 @@ long query_slice(const sicp_ctx *c, long Q, long *lo)
     *lo = std::min<long>(Q, per * c->rank);
     return std::min<long>(Q, *lo + per) - *lo;
 }
-int exchange_query_slices(sicp_ctx *c, double *d2, int64_t *idx, double *p2, long Q)
+// ... gathered slim: 8 bytes per query (the matched index) instead of the 40-byte (d2, idx, xyz) record -- the cloud is replicated,
+// so every rank looks the coordinates up itself and forms distance + verdict in the same pass (k_postmatch's work)
+int exchange_query_slices_idx(sicp_ctx *c, const TailArgs &A, long Q)
 {
+    const Cloud &cl = c->cloud[SICP_MOV];
     const long per = (Q + c->world - 1) / c->world;
     long lo; const long cnt = query_slice(c, Q, &lo);
     Timed t(c, SICP_K_XCHG);
-    CHK(c->x_send.reserve((size_t)5 * per));
-    CHK(c->x_recv.reserve((size_t)5 * per * c->world));
-    if (cnt > 0) launch_pack_best(c->stream, d2 + lo, idx + lo, p2 + 3 * lo, cnt, c->x_send.p);
+    CHK(c->x_send.reserve((size_t)per));
+    CHK(c->x_recv.reserve((size_t)per * c->world));
+    launch_pack_idx(c->stream, c->m_idx.p + lo, cnt, per, c->x_send.p);
     HIPCHK(hipGetLastError());
-    CHK(all_gather_f64(c, c->x_send.p, c->x_recv.p, 5 * per));
-    launch_lexmin_gathered(c->stream, c->x_recv.p, 1, Q, d2, idx, p2);     // world = 1: a plain unpack of the Q records
+    CHK(all_gather_f64(c, c->x_send.p, c->x_recv.p, per));
+    launch_unpack_idx_postmatch(c->stream, c->x_recv.p, Q, cl.x(), cl.y(), cl.z(), cl.idx_base, cl.n, c->q.p, c->q.p + c->qpad,
+                                c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, A.min_planarity, A.pl2, A.pl2_n, c->icp_dev.p,
+                                c->m_idx.p, c->m_p2.p, c->dist.p, c->flag.p);
     HIPCHK(hipGetLastError());
     return SICP_OK;
 }
@@ -1524,7 +1529,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
             }
             HIPCHK(hipGetLastError());
             c->have_prev_match = true;          // (after an exchange: the job-wide winner's coordinates -- still a valid bound)
-            if (qshard) CHK(exchange_query_slices(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
+            if (qshard) { CHK(exchange_query_slices_idx(c, A, Q)); post_done = true; }      // (distances + verdicts formed by the unpack)
             else CHK(exchange_best(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
             A.seq = (double)(++c->solve_seq);
             seqs[launched % REC_RING] = A.seq;

@@ -123,6 +123,11 @@ void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const do
                      const uint32_t *cell_start, const void *rec, double rmax, int64_t idx_base, double *d2_out, int64_t *idx_out);
 
 void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec);
+void launch_pack_idx(hipStream_t s, const int64_t *idx, long cnt, long per, double *out);
+void launch_unpack_idx_postmatch(hipStream_t s, const double *gathered, long Q, const double *cx, const double *cy, const double *cz,
+                                 int64_t idx_base, long n, const double *qx, const double *qy, const double *qz, const float *normals,
+                                 const float *planarity, float min_planarity, const float *pl2, long pl2_n, const IcpDev *st,
+                                 int64_t *idx, double *p2, double *dist, uint8_t *flag);
 void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, double *d2, int64_t *idx, double *p2);
 size_t reject_select_scratch_bytes();
 hipError_t hsel_state_init(hipStream_t s, void *state);

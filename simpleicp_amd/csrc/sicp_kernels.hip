@@ -1362,6 +1362,41 @@ __global__ void k_lexmin_gathered(const double *__restrict__ g, int world, long 
     if (p2) { p2[3 * q] = bx; p2[3 * q + 1] = by; p2[3 * q + 2] = bz; }
 }
 
+// ---- query shards (every rank holds the WHOLE searched cloud): the exchange carries nothing but the matched index ----
+// 8 bytes per query instead of the 40-byte (d2, idx, xyz) record: the coordinates are this rank's own to look up, the squared
+// distance is not used after the match, and the point-to-plane distance is formed from the looked-up point anyway.
+__global__ void k_pack_idx(const int64_t *__restrict__ idx, long cnt, long per, double *__restrict__ out)
+{
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < per) out[j] = __longlong_as_double(j < cnt ? (long long)idx[j] : -1ll);
+}
+// gathered[q] = bits of query q's matched global index (slices in rank order = query order).  Writes the index, looks the
+// point up in the cloud, and does k_postmatch's work on it (distance under the chained run's H, planarity verdict).
+__global__ void k_unpack_idx_postmatch(const double *__restrict__ gathered, long Q, const double *__restrict__ cx,
+                                       const double *__restrict__ cy, const double *__restrict__ cz, int64_t idx_base, long n,
+                                       const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+                                       const float *__restrict__ normals, const float *__restrict__ planarity, float min_planarity,
+                                       const float *__restrict__ pl2, long pl2_n, const IcpDev *__restrict__ st,
+                                       int64_t *__restrict__ idx, double *__restrict__ p2, double *__restrict__ dist,
+                                       uint8_t *__restrict__ flag)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (st->stop || q >= Q) return;
+    const int64_t m = (int64_t)__double_as_longlong(gathered[q]);
+    const long row = (long)(m - idx_base);
+    const bool ok = m >= 0 && row >= 0 && row < n;
+    const double px = ok ? cx[row] : 0.0, py = ok ? cy[row] : 0.0, pz = ok ? cz[row] : 0.0;
+    idx[q] = ok ? m : (int64_t)-1;
+    p2[3 * q] = px; p2[3 * q + 1] = py; p2[3 * q + 2] = pz;
+    const Xf H = st->H;
+    double X, Y, Z;
+    xform(H, px, py, pz, X, Y, Z);
+    dist[q] = plane_dist(X - qx[q], Y - qy[q], Z - qz[q], normals[3 * q], normals[3 * q + 1], normals[3 * q + 2]);
+    bool f = ok && planarity[q] >= min_planarity;
+    if (f && pl2) f = m < pl2_n && pl2[m] >= min_planarity;          // corrpts.py:158-163 (NaN fails)
+    flag[q] = f ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------------------
@@ -1370,6 +1405,18 @@ static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b)
 void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec)
 {
     hipLaunchKernelGGL(k_pack_best, dim3(cdiv(Q, 256)), dim3(256), 0, s, d2, idx, p2, Q, rec);
+}
+void launch_pack_idx(hipStream_t s, const int64_t *idx, long cnt, long per, double *out)
+{
+    if (per > 0) hipLaunchKernelGGL(k_pack_idx, dim3(cdiv(per, 256)), dim3(256), 0, s, idx, cnt, per, out);
+}
+void launch_unpack_idx_postmatch(hipStream_t s, const double *gathered, long Q, const double *cx, const double *cy, const double *cz,
+                                 int64_t idx_base, long n, const double *qx, const double *qy, const double *qz, const float *normals,
+                                 const float *planarity, float min_planarity, const float *pl2, long pl2_n, const IcpDev *st,
+                                 int64_t *idx, double *p2, double *dist, uint8_t *flag)
+{
+    hipLaunchKernelGGL(k_unpack_idx_postmatch, dim3(cdiv(Q, 256)), dim3(256), 0, s, gathered, Q, cx, cy, cz, idx_base, n, qx, qy, qz,
+                       normals, planarity, min_planarity, pl2, pl2_n, st, idx, p2, dist, flag);
 }
 void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, double *d2, int64_t *idx, double *p2)
 {
