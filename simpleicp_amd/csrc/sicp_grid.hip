@@ -1383,7 +1383,15 @@ hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const 
                                        double seq, const IcpDev *st)
 {
     static const long cap = [] { const char *e = std::getenv("SICP_HS_GRID"); const long v = e ? std::atol(e) : 0; return v > 0 && v <= 256 ? v : 256L; }();
-    const unsigned g = (unsigned)std::max<long>(1, std::min<long>(cap, (Q + 256 * HS_UNROLL - 1) / (256 * HS_UNROLL)));
+    // every block must be resident at once (grid barrier): never more blocks than the device can hold (a partitioned device has
+    // far fewer CUs than 256)
+    static const long resident = [] {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_hsel_all, 256, 0) != hipSuccess || cus < 1 || per_cu < 1) return 1L;
+        return (long)cus * per_cu;
+    }();
+    const unsigned g = (unsigned)std::max<long>(1, std::min<long>(std::min<long>(cap, resident), (Q + 256 * HS_UNROLL - 1) / (256 * HS_UNROLL)));
     hipLaunchKernelGGL(k_hsel_all, dim3(g), dim3(256), 0, s, dist, flag, Q, (HselAll *)state, *bar_total, keep, partial, out4, out3,
                        host_out, seq, st);
     *bar_total += (unsigned long long)HS_MAXB;

@@ -517,7 +517,14 @@ void launch_lm_all(hipStream_t s, const double *qx, const double *qy, const doub
                    const uint8_t *keep, long Q, const TailArgs &A, IcpDev *st, LmDev *L, const double *rj4, const double *stats,
                    double *partial, void *bar, unsigned long long *bar_total, double *resid0, double *resid1, double *rec)
 {
-    const unsigned g = (unsigned)lm_eval_grid(Q);
+    // every block must be resident at once (grid barrier): never more blocks than the device can hold
+    static const long resident = [] {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lm_all, LB, 0) != hipSuccess || cus < 1 || per_cu < 1) return 1L;
+        return (long)cus * per_cu;
+    }();
+    const unsigned g = (unsigned)std::min<long>(lm_eval_grid(Q), resident);
     hipLaunchKernelGGL(k_lm_all, dim3(g), dim3(LB), 0, s, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, partial,
                        (GridBar *)bar, *bar_total, resid0, resid1, rec);
     *bar_total += (unsigned long long)LM_MAXB;
