@@ -207,6 +207,14 @@ def _worker_attach(rank, world, port, tmp):
         os.environ["SICP_XCHG"] = "callback"
         c = _FakeCtx(rank, fail_on=None)
         assert dist.attach(c) == "callback" and not any(x[0] == "comm_init" for x in c.calls)
+        # the queries partition replicates the cloud: taken only when EVERY rank has room for it (one rank short -> all say no)
+        class _Mem:
+            def __init__(self, free): self.free = free
+            def device_memory(self): return self.free, 288 << 30
+        roomy, tight = _Mem(200 << 30), _Mem(1 << 30)
+        assert dist.queries_partition_fits(roomy, 100_000_000) and not dist.queries_partition_fits(tight, 100_000_000)
+        assert dist.agree(dist.queries_partition_fits(roomy, 100_000_000)) is True
+        assert dist.agree(dist.queries_partition_fits(roomy if rank == 0 else tight, 100_000_000)) is False
         Path(tmp, f"at{rank}").write_text("ok")
     finally:
         os.environ.pop("SICP_XCHG", None)

@@ -258,3 +258,34 @@ def test_every_export_refuses_null_arguments():
             assert rc == 0
         else:
             assert rc == _lib.ERR_INVALID and msg, (name, rc, msg)
+
+
+def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
+    """SICP_LIBRARY makes it easy to point the binding at a stale build: load() compares sicp_abi_version() with the version
+    this binding was written for and refuses instead of calling entry points with the wrong arguments."""
+    from simpleicp_amd import _lib
+    _lib.load()                                                   # (the real library is fine)
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", 99)
+    with pytest.raises(_lib.BackendError, match="ABI version"):
+        _lib.load()
+
+
+def test_bench_withholds_stale_pmc_traffic(tmp_path, monkeypatch):
+    """profiles/latest_pmc.json is quoted as `traffic` only when it was measured on THESE kernel sources (bench.csrc_hash)."""
+    import json
+    import bench
+    pmc, src = bench.load_pmc()
+    committed = json.loads((ROOT / "profiles" / "latest_pmc.json").read_text())
+    if committed.get("_csrc_hash") == bench.csrc_hash():
+        assert pmc.get("k_icp_tail", 0) > 0 and "NOT collected in this run" in src
+    else:
+        assert pmc == {} and "stale" in src
+    # a file stamped with another hash is refused whatever it holds
+    fake = tmp_path / "profiles"
+    fake.mkdir()
+    (fake / "latest_pmc.json").write_text(json.dumps({"_csrc_hash": "0" * 16, "k_icp_tail": 1.0}))
+    (tmp_path / "simpleicp_amd").symlink_to(ROOT / "simpleicp_amd")
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    pmc, src = bench.load_pmc()
+    assert pmc == {} and "stale" in src and bench.csrc_hash() in src
