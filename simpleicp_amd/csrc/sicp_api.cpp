@@ -313,6 +313,7 @@ struct sicp_ctx {
     unsigned long long hsel_bar = 0;   // what the one-launch rejection's launches have added to its barrier counter so far
     bool hsel_one_launch = true;   // SICP_HSEL=launches: the launch-per-phase form (A/B)
     bool hsel_dirty = false;
+    int nn_group = 0;              // SICP_NN_GROUP=8|16: lanes per query of the many-queries search (0: chosen per launch)
     bool match_epilogue = true;    // SICP_MATCH_EPILOGUE=0: distances + verdicts by k_postmatch even without an exchange (A/B)
     int chain_depth = 4;           // iterations enqueued ahead of the last record read (SICP_CHAIN_DEPTH)
     // exchange: an RCCL communicator of the library's own (sicp_comm_init) or a host callback (sicp_set_exchange)
@@ -1059,6 +1060,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
     if (const char *e = std::getenv("SICP_LM")) c->lm_one_launch = std::strcmp(e, "launches") != 0;
     if (const char *e = std::getenv("SICP_HSEL")) c->hsel_one_launch = std::strcmp(e, "launches") != 0;
+    if (const char *e = std::getenv("SICP_NN_GROUP")) { const int v = std::atoi(e); if (v == 8 || v == 16) c->nn_group = v; }
     if (const char *e = std::getenv("SICP_MATCH_EPILOGUE")) c->match_epilogue = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_XCHG_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) c->xchg_timeout_s = v; }
     if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
@@ -1511,13 +1513,18 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 // (only in the one-wave-per-query flavour: with four queries per wave at the register limit the epilogue's late
                 // loads cost the search more than k_postmatch's launch -- match 693 -> 758 us at 1 M queries, measured)
                 post_done = !c->collective() && c->match_epilogue && cnt < c->nn16_min_q;
+                // EIGHT queries per wave (8 lanes each) once the query set is large and cells are small: twice the independent
+                // requests per wave in flight (0.69 -> 0.62 ms per 1 M queries on 10 M points); not with long rows (C5 sizes: the cell
+                // table's limit leaves 25 points per cell, 8 lanes need twice the steps: 2.07 -> 2.53 ms per step) nor below ~200 k
+                // queries (too few waves to fill the machine)
+                const bool eight = c->nn_group ? c->nn_group == 8 : (cnt >= 196608 && cl.grid.avg_per_cell <= 20.0);
                 PostMatch pm = {c->normals.p, c->planarity.p, A.pl2, A.pl2_n, A.min_planarity, c->dist.p, c->flag.p};
                 if (cnt > 0)
                     launch_grid_nn_chained(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt,
                                            coarse ? c->bound_p2.p + 3 * lo : (prev ? prev + 3 * lo : nullptr), cl.grid.g,
                                            cl.grid.cell_start.p, cl.grid.rec.p, c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p + lo,
                                            c->m_idx.p + lo, c->m_p2.p + 3 * lo, c->count_work ? c->match_work.p : nullptr,
-                                           ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q, coarse, post_done ? &pm : nullptr);
+                                           ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q, coarse, post_done ? &pm : nullptr, eight);
             } else if (qshard) {
                 return fail(SICP_ERR_INVALID, "query shards need the grid search (SICP_KNN1 forces another kernel)");
             } else {

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
 // are one DPP row, so the lexicographic minimum stays a register butterfly; row ranges travel inside the group by
 // ds_bpermute (per-group source lane: no uniform readlane).  Groups of a wave run in lock step and idle once done.
 // ------------------------------------------------------------------------------------
-template <bool XFORM, bool CHAINED>
+template <bool XFORM, bool CHAINED, int GS /* lanes per query: 16 (four queries per wave) or 8 (eight) */>
 __global__ __launch_bounds__(256, 4) void k_grid_nn16(
     const IcpDev *__restrict__ st, const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
     const double *__restrict__ prev_p2, const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
@@ -539,10 +539,12 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
     double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
     unsigned long long *__restrict__ work, int tight, PostMatch post)
 {
-    const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48;
+    constexpr int GPW = 64 / GS;                       // queries per wave
+    constexpr unsigned GMASK = GS == 16 ? 0xffffu : 0xffu;
+    const int lane = threadIdx.x & 63, gl = lane & (GS - 1), gbase = lane & (64 - GS);
     long blk = blockIdx.x;
     if (order) blk = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);     // one contiguous eighth per XCD
-    const long slot = (blk * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const long slot = (blk * 4 + (threadIdx.x >> 6)) * GPW + lane / GS;
     const bool active = slot < Q;
     if (!__any(active)) return;
     const long q = active ? (order ? (long)order[slot] : slot) : 0;
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
         // candidates of up to two rows per group: lane gl of a group takes record gl (+ 16, ...) of each of its rows
         auto scan_rows = [&](const uint32_t (&rbv)[2], const uint32_t (&rlv)[2]) {
             const uint32_t longest = rlv[0] > rlv[1] ? rlv[0] : rlv[1];
-            for (uint32_t o = 0; __any(o < longest); o += 16) {
+            for (uint32_t o = 0; __any(o < longest); o += GS) {
                 double4 P[2];
                 bool ok[2];
 #pragma unroll
@@ -644,11 +646,11 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
                 len = cell_start[row + xh + 1] - b;
             }
         };
-        for (long rb = 0; __any(rb < nrows); rb += 16) {
+        for (long rb = 0; __any(rb < nrows); rb += GS) {
             uint32_t b = 0, len = 0;
             double lb2 = __builtin_inf();
             if (rb + gl < nrows) row_range(rb + gl, b, len, lb2);
-            unsigned todo = (unsigned)(__ballot(len > 0) >> gbase) & 0xffffu;      // this group's rows that hold points
+            unsigned todo = (unsigned)(__ballot(len > 0) >> gbase) & GMASK;      // this group's rows that hold points
             if (work && len > 0) n_rows += 1;
             const bool many = __popc(todo) > 4;
             if (__any(many)) {
@@ -656,9 +658,9 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
                 // x ranges to the hit's ball (one more look at the cell offsets, a fraction of the candidates)
                 unsigned long long key = len > 0 ? (unsigned long long)__double_as_longlong(lb2) : ~0ull, mk = key;
                 { unsigned long long o;
-                  o = lane_xor64<8>(mk);  mk = o < mk ? o : mk;  o = lane_xor64<4>(mk);  mk = o < mk ? o : mk;
+                  if constexpr (GS == 16) { o = lane_xor64<8>(mk);  mk = o < mk ? o : mk; }  o = lane_xor64<4>(mk);  mk = o < mk ? o : mk;
                   o = lane_xor64<2>(mk);  mk = o < mk ? o : mk;  o = lane_xor64<1>(mk);  mk = o < mk ? o : mk; }
-                const unsigned geq = (unsigned)(__ballot(len > 0 && key == mk) >> gbase) & 0xffffu;
+                const unsigned geq = (unsigned)(__ballot(len > 0 && key == mk) >> gbase) & GMASK;
                 const int j = (many && geq) ? __ffs((int)geq) - 1 : 0;
                 const uint32_t vb = (uint32_t)__shfl((int)b, gbase + j), vl = (uint32_t)__shfl((int)len, gbase + j);
                 const uint32_t rbv[2] = {many ? vb : 0u, 0u};
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
                 scan_rows(rbv, rlv);
                 double gb = best;
                 { double o;
-                  o = lane_xor_f64<8>(gb);  gb = o < gb ? o : gb;  o = lane_xor_f64<4>(gb);  gb = o < gb ? o : gb;
+                  if constexpr (GS == 16) { o = lane_xor_f64<8>(gb);  gb = o < gb ? o : gb; }  o = lane_xor_f64<4>(gb);  gb = o < gb ? o : gb;
                   o = lane_xor_f64<2>(gb);  gb = o < gb ? o : gb;  o = lane_xor_f64<1>(gb);  gb = o < gb ? o : gb; }
                 if (many && gb < __builtin_inf()) {
                     const double rbnd = sqrt(gb) * (1.0 + 1e-12) + slack;
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
                         if (((todo >> gl) & 1u) && rb + gl < nrows) row_range(rb + gl, b, len, lb2);
                     }
                 }
-                todo &= (unsigned)(__ballot(len > 0 && lb2 <= cull2) >> gbase) & 0xffffu;
+                todo &= (unsigned)(__ballot(len > 0 && lb2 <= cull2) >> gbase) & GMASK;
             }
             while (__any(todo != 0u)) {
                 uint32_t rbv[2], rlv[2];
@@ -700,7 +702,8 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
             const uint32_t oi = lane_xor32<J>(bidx);                                              \
             if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; }                 \
         }
-        SICP_LEXMIN_STEP(8) SICP_LEXMIN_STEP(4) SICP_LEXMIN_STEP(2) SICP_LEXMIN_STEP(1)
+        if constexpr (GS == 16) SICP_LEXMIN_STEP(8)
+        SICP_LEXMIN_STEP(4) SICP_LEXMIN_STEP(2) SICP_LEXMIN_STEP(1)
 #undef SICP_LEXMIN_STEP
         if (!done) {
             const bool found = bidx != 0xffffffffu;
@@ -1483,9 +1486,9 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
     if (four_per_wave) {
         const dim3 g16(cdiv(Q, 16));
         if (H)
-            hipLaunchKernelGGL((k_grid_nn16<true, false>), g16, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, *H, *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{});
+            hipLaunchKernelGGL((k_grid_nn16<true, false, 16>), g16, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, *H, *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{});
         else
-            hipLaunchKernelGGL((k_grid_nn16<false, false>), g16, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{});
+            hipLaunchKernelGGL((k_grid_nn16<false, false, 16>), g16, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{});
         return;
     }
     if (H)
@@ -1500,7 +1503,7 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
 void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                             const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
                             int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
-                            const uint32_t *order, bool four_per_wave, bool tight, const PostMatch *post)
+                            const uint32_t *order, bool four_per_wave, bool tight, const PostMatch *post, bool eight_per_wave)
 {
     Xf id = {};
     PostMatch pm = {};
@@ -1508,7 +1511,13 @@ void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, c
     if (four_per_wave) {
         unsigned g16 = cdiv(Q, 16);
         if (order) g16 = (g16 + 7u) & ~7u;
-        hipLaunchKernelGGL((k_grid_nn16<true, true>), dim3(g16), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, tight ? 1 : 0, pm);
+        if (eight_per_wave) {
+            unsigned g8 = cdiv(Q, 32);
+            if (order) g8 = (g8 + 7u) & ~7u;
+            hipLaunchKernelGGL((k_grid_nn16<true, true, 8>), dim3(g8), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, tight ? 1 : 0, pm);
+            return;
+        }
+        hipLaunchKernelGGL((k_grid_nn16<true, true, 16>), dim3(g16), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, tight ? 1 : 0, pm);
         return;
     }
     unsigned g = cdiv(Q, 4);

@@ -115,7 +115,8 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
 void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                             const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
                             int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
-                            const uint32_t *order, bool four_per_wave, bool tight = false, const PostMatch *post = nullptr);
+                            const uint32_t *order, bool four_per_wave, bool tight = false, const PostMatch *post = nullptr,
+                            bool eight_per_wave = false);
 void launch_stride_sample(hipStream_t s, const double *x, const double *y, const double *z, long n, long stride, long m, long mpad,
                           double *out);
 void launch_scatter_order(hipStream_t s, const uint32_t *ids, long n, uint32_t *cursor, uint32_t *order);

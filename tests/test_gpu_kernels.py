@@ -607,3 +607,45 @@ def test_one_launch_forms_equal_launch_per_phase_forms(Q, quantised):
     for a, b in zip(out["one"][:3], out["launches"][:3]):
         assert np.array_equal(a[0], b[0]) and a[1:8] == b[1:8] and np.array_equal(a[8], b[8]) and np.array_equal(a[9], b[9]) and a[10] == b[10]
     assert all(np.array_equal(p, q) for p, q in zip(out["one"][3], out["launches"][3]))
+
+
+@pytest.mark.parametrize("quantised", [False, True])
+def test_eight_queries_per_wave_equals_four(quantised):
+    """The many-queries search with 8 lanes per query (chosen for very large query sets on finely binned clouds) against the
+    16-lane form and the oracle: same indices, same distances, bit for bit, over chained iterations (cold, loosely and
+    tightly bounded searches), on a cloud with exact ties."""
+    import os
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(99)
+    n, Q = 90_000, 40_000
+    P = _surface(n, 47)
+    x_true = np.array([0.004, -0.003, 0.006, 0.25, -0.15, 0.1])       # far enough off that early searches are wide
+    Xm = orc.transform(np.linalg.inv(orc.params_to_H(x_true)), P + rng.normal(0, 0.01, P.shape))
+    if quantised:
+        P, Xm = np.round(P, 2), np.round(Xm, 2)
+    sel = np.sort(rng.choice(n, Q, replace=False))
+    z = np.zeros(6)
+    out = {}
+    for gs in ("16", "8"):
+        os.environ["SICP_NN_GROUP"] = gs
+        try:
+            c = _lib.Context(0)
+        finally:
+            os.environ.pop("SICP_NN_GROUP", None)
+        with c:
+            c.upload(_lib.FIX, P); c.upload(_lib.MOV, Xm)
+            nv, pl = c.estimate_normals(_lib.FIX, sel, 10)
+            c.icp_setup(sel, nv, pl)
+            x, rec = z.copy(), []
+            for it in range(4):
+                R = c.icp_iterate(x, z, z, 0.3, 1.0)
+                assert c.last_match_kernel() == "k_grid_nn16"
+                idx, dist, keep, _ = c.icp_state(residual=False)
+                rec.append((x.copy(), idx, dist, keep, np.array(R.x[:])))
+                x = np.array(R.x[:])
+        out[gs] = rec
+    for a, b in zip(out["16"], out["8"]):
+        assert all(np.array_equal(u, v) for u, v in zip(a, b))
+    for x, idx, dist, keep, xn in out["8"][:2]:
+        nn, _ = orc.knn(Xm, P[sel], k=1, H=orc.params_to_H(x))
+        assert np.array_equal(idx, nn[:, 0])
