@@ -94,6 +94,7 @@ struct Grid {
     GridGeom g;
     long ncells = 0;
     double avg_per_cell = 0;
+    bool cap_limited = false;        // the cell table's size limit, not the points-per-cell target, set the cell size
     DevBuf<uint32_t> cell_start;     // ncells + 1
     DevBuf<double> rec;              // the cloud in cell order: packed 32-byte records (x, y, z, local row as int64 bits)
 };
@@ -597,6 +598,7 @@ int subsample_build(sicp_ctx *c, int slot)
 int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const double *Y, const double *Z, long n, Grid &gr)
 {
     if (gr.valid) return SICP_OK;
+    gr.cap_limited = false;
     double mn[3], ex[3], vol = 1.0; int deff = 0;
     for (int a = 0; a < 3; ++a) {
         mn[a] = cl.bb_lo[a];
@@ -670,6 +672,7 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
             }
             if (ncells <= cap) break;
             h *= std::cbrt((double)ncells / (double)cap) * 1.02;
+            gr.cap_limited = true;                       // cells are coarser than the target asked for
         }
         for (int a = 0; a < 3; ++a) G.mn[a] = mn[a];
         G.h = h; G.inv_h = 1.0 / h;
@@ -1517,7 +1520,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 // requests per wave in flight (0.69 -> 0.62 ms per 1 M queries on 10 M points); not with long rows (C5 sizes: the cell
                 // table's limit leaves 25 points per cell, 8 lanes need twice the steps: 2.07 -> 2.53 ms per step) nor below ~200 k
                 // queries (too few waves to fill the machine)
-                const bool eight = c->nn_group ? c->nn_group == 8 : (cnt >= 196608 && cl.grid.avg_per_cell <= 20.0);
+                const bool eight = c->nn_group ? c->nn_group == 8 : (cnt >= 196608 && !cl.grid.cap_limited && cl.grid.avg_per_cell <= 20.0);
                 PostMatch pm = {c->normals.p, c->planarity.p, A.pl2, A.pl2_n, A.min_planarity, c->dist.p, c->flag.p};
                 if (cnt > 0)
                     launch_grid_nn_chained(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt,
