@@ -150,6 +150,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-bruteforce-leg", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-work-pass", action="store_true",
+                    help="skip the pass in which the grid search tallies its own candidates / rows (in-kernel atomics: a kernel "
+                         "trace taken with it averages slower launches in) -- the match's roofline then falls back to PMC traffic")
     ap.add_argument("--cpu-iterations", type=int, default=2)
     ap.add_argument("--partition", choices=["auto", "cloud", "queries"], default="auto",
                     help="N > 1: shard the movable cloud (north-star scheme, default below 1e5 correspondences) or the "
@@ -298,7 +301,7 @@ def run(args):
     match_kernel = ctx.last_match_kernel()
     # ... and one more with the grid search tallying the candidates / rows it touches (the bytes its roofline is priced on)
     work = None
-    if match_kernel in ("k_grid_nn", "k_grid_nn16"):
+    if match_kernel in ("k_grid_nn", "k_grid_nn16") and not args.no_work_pass:
         ctx.timing_enable(True, count_work=True)
         ctx.timing_reset()
         cold()

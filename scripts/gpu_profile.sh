@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --steps 20 --warmup 3 --repeats 5 --no-cpu-baseline --no-parity --no-end-to-end --throughput-q 0 $*"
 for P in $PASSES; do
   case $P in
-    trace) rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err" ;;
+    trace) rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --no-work-pass > "$OUT/bench_trace.json" 2> "$OUT/trace.err" ;;
     fetch) rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --no-bruteforce-leg > "$OUT/bench_pmc_fetch.json" 2> "$OUT/pmc_fetch.err" ;;
     write) rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH --no-bruteforce-leg > "$OUT/bench_pmc_write.json" 2> "$OUT/pmc_write.err" ;;
     sq1)   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/pmc_sq1" -- $BENCH --no-bruteforce-leg > "$OUT/bench_pmc_sq1.json" 2> "$OUT/pmc_sq1.err" ;;
