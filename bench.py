@@ -345,8 +345,10 @@ def run(args):
 
     def roof(kernel, ms, bytes_alg, note, extra=None):
         ach = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        # counters are keyed by kernel for the default line and "<kernel>@<config>" for the other configurations' own passes
+        traffic = pmc.get(f"{kernel}@{args.config}") if args.config != "C4" else pmc.get(kernel)
         d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-             "traffic": pmc.get(kernel), "traffic_source": pmc_src if (pmc.get(kernel) is not None or not pmc) else None,
+             "traffic": traffic, "traffic_source": pmc_src if (traffic is not None or not pmc) else None,
              "kernel": kernel, "avg_ms": ms, "bytes_alg_per_launch": int(bytes_alg), "note": note}
         if extra:
             d.update(extra)

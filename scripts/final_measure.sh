@@ -39,6 +39,8 @@ if has profiles; then
   scripts/gpu_profile.sh $TAG > "$OUT/gpu_profile.log" 2>&1; stamp "profile default"
   PASSES="trace fetch write sq1" scripts/gpu_profile.sh ${TAG}_q1000000 --correspondences 1000000 >> "$OUT/gpu_profile.log" 2>&1; stamp "profile Q=1M"
   PASSES="trace fetch write sq1" scripts/gpu_profile.sh ${TAG}_q100000 --correspondences 100000 >> "$OUT/gpu_profile.log" 2>&1; stamp "profile Q=100k"
+  PASSES="trace fetch write" scripts/gpu_profile.sh ${TAG}_C3 --config C3 >> "$OUT/gpu_profile.log" 2>&1; stamp "profile C3"
+  PASSES="trace fetch write" scripts/gpu_profile.sh ${TAG}_C5size --config C5size --repeats 2 >> "$OUT/gpu_profile.log" 2>&1; stamp "profile C5size"
 fi
 if has c5; then
   timeout 1200 python bench.py --config C5size --repeats 5 --no-cpu-baseline --no-end-to-end --no-bruteforce-leg --throughput-q 0 --out "$OUT/bench_C5size.json" > /dev/null 2> "$OUT/bench_C5size.err"; stamp "C5size rc=$?"

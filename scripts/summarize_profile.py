@@ -2,7 +2,7 @@
 """Turn gpurun_out/prof_<tag>[_q<Q>]/ (scripts/gpu_profile.sh) into the committed summaries under profiles/<tag>/ and
 profiles/latest_pmc.json (per-kernel HBM bytes per launch, read by bench.py).
 
-    python scripts/summarize_profile.py r3            # prof_r3 (default line) + every prof_r3_q<Q> (large-Q legs)
+    python scripts/summarize_profile.py r3            # prof_r3 (default line) + every prof_r3_q<Q> (large-Q legs) + prof_r3_C<config>
 
 HBM bytes per launch = FETCH_SIZE * cal + WRITE_SIZE  (both counters are in KiB).  On gfx950 FETCH_SIZE under-reports wide
 coalesced reads by 2x (MI355X_MICROARCH.md, HBM section); `cal` is measured in the same run on k_aos_to_soa, whose read volume
@@ -98,12 +98,13 @@ out = {}
 base = ROOT / "gpurun_out" / f"prof_{tag}"
 hashes = set()
 notes = []
-for src in [base] + sorted(ROOT.glob(f"gpurun_out/prof_{tag}_q*")):
+for src in [base] + sorted(ROOT.glob(f"gpurun_out/prof_{tag}_q*")) + sorted(ROOT.glob(f"gpurun_out/prof_{tag}_C*")):
     if not src.exists():
         continue
     suffix = src.name[len(f"prof_{tag}"):].lstrip("_")
     per, cal = one(src, suffix)
-    key = f"@Q{suffix[1:]}" if suffix else ""
+    # "q<n>": the default clouds with n correspondences -> "<kernel>@Q<n>";  "C<k>...": another configuration -> "<kernel>@<config>"
+    key = "" if not suffix else (f"@Q{suffix[1:]}" if suffix.startswith("q") else f"@{suffix}")
     for k, v in per.items():
         out[k + key] = v
     notes.append(f"{src.name}: cal {cal:.3f}")
