@@ -547,6 +547,9 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
     bytes_match = per["candidates"] * 32 + per["rows"] * 8 + nq_local * (24 + 24 + 48)
     pmc, pmc_src = load_pmc()
     tag = f"@Q{Qt}"
+    if args.config != "C4" or args.points:
+        pmc = {}                  # (the per-leg counters were collected on the default line's 10 M-point clouds only)
+        pmc_src = "no counter pass for this leg on these clouds"
 
     def roof(kernel, ms, bytes_alg, note, extra=None):
         ach = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
