@@ -163,7 +163,8 @@ def parse_args(argv=None):
                     help="correspondence counts of the `throughput_point` legs (synthetic configs; same clouds, same K steps "
                          "from cold; N > 1: under query shards); 0 = none")
     ap.add_argument("--throughput-repeats", type=int, default=7)
-    ap.add_argument("--out", type=str, default=None, help="also write the JSON line to this file")
+    ap.add_argument("--out", type=str, default=None, help="also write the UNABRIDGED record to this file")
+    ap.add_argument("--verbose-line", action="store_true", help="print the unabridged record on stdout as well")
     return ap.parse_args(argv)
 
 
@@ -459,11 +460,53 @@ def run(args):
     except Exception:  # noqa: BLE001
         pass
     sys.stdout.flush()
-    line = json.dumps(out)
+    full = json.dumps(out)
     if args.out:
         Path(args.out).parent.mkdir(parents=True, exist_ok=True)
-        Path(args.out).write_text(line + "\n")
-    print(line, flush=True)
+        Path(args.out).write_text(full + "\n")
+    # stdout carries ONE line of a size a log tail holds whole (the round-2 line was 6 KB): every field of the contract and every
+    # number, without the explanatory strings; the unabridged record goes to --out (profiles/r3/bench_*.json are such files)
+    print(json.dumps(out if args.verbose_line else compact_line(out)), flush=True)
+
+
+def compact_line(out):
+    """The stdout line: same objects, explanatory strings and second-order detail dropped."""
+    drop = {"note", "traffic_source", "timed_region", "scope", "oracle", "source", "measured_on", "bytes_alg_source", "repeat_stats",
+            "kernels_instrumented", "solver", "setup", "transport_chosen_by_attach"}
+
+    def strip(v, depth=0):
+        if isinstance(v, dict):
+            return {k: strip(x, depth + 1) for k, x in v.items() if not (depth > 0 and k in drop)}
+        if isinstance(v, float):
+            return float(f"{v:.6g}")
+        return v
+    line = strip(out)
+    line["repeat_stats"] = {k: out["repeat_stats"][k] for k in ("repeats", "ms_per_step_p10", "ms_per_step_p90")}
+    line["kernels_instrumented"] = {k: round(v["avg_ms"], 6) for k, v in out["kernels_instrumented"].items() if v["launches"]}
+    line["setup"] = {k: round(v, 3) for k, v in out["setup"].items() if isinstance(v, float)}
+    line["solver"] = out["solver"]
+    for k in list(line):
+        if k.startswith("throughput_point"):
+            t = out[k]
+            line[k] = {"correspondences": t["correspondences"], "n_gpus": t["n_gpus"], "ms_per_step": float(f"{t['ms_per_step']:.6g}"),
+                       "iterations_per_s": float(f"{t['iterations_per_s']:.6g}"),
+                       "correspondences_per_s": float(f"{t['correspondences_per_s']:.6g}"), "parallelism": t["parallelism"],
+                       "roofline": strip(t["roofline"], 1),
+                       "kernel_ms": {n: round(v["avg_ms"], 6) for n, v in t["kernels_instrumented"].items() if v["launches"]},
+                       "evaluations_per_iteration": t["roofline_solver"].get("evaluations_per_iteration")}
+            if "parity" in t:
+                p0 = t["parity"].get("iteration_0", {})
+                line[k]["parity"] = {"ok": t["parity"]["ok"], "queries_sampled": p0.get("queries_sampled"),
+                                     "max_abs_dx": p0.get("max_abs_dx")}
+            if "comm" in t:
+                line[k]["comm"] = strip(t["comm"], 1)
+    if "cpu_baseline" in line:
+        line["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:120]
+    if "cpu_reference" in line:
+        line["cpu_reference"]["sample"] = out["cpu_reference"]["sample"][:100]
+    line["config"]["workload"] = out["config"]["workload"]
+    line["detail"] = "unabridged record: --out FILE (committed examples: profiles/r3/bench_*.json)"
+    return line
 
 
 def comm_record(ctx, exchange, transport, qshard, world, shard_rows, nq, timing, steps):
