@@ -28,13 +28,17 @@ steps (HIP events on the library's own stream).
 N > 1: STRONG scaling -- the same movable cloud is sharded by index range over the ranks (one process per GPU),
 one all-gather exchange per iteration.
 
-One JSON line on stdout (rank 0).  Extra objects on the same line:
+One JSON line on stdout (rank 0) -- compact (about 5 KB: every field and number, no explanatory strings); the unabridged record
+goes to --out FILE (profiles/r3/bench_*.json are such files).  Extra objects on the same line:
   roofline             the kernel with the largest share of the step's GPU time; `achieved` = algorithmic bytes per
                        launch / average launch duration
   roofline_match       the 1-NN kernel of the default path (pruned grid search), priced on the bytes the pruned
                        search itself needs (candidates x 32-byte records + cell offsets + queries), with `pruning_ratio`
   roofline_bruteforce  the north-star brute-force scan, measured in a short extra leg on the same inputs
-  parity               one more iteration after the timed region, checked against the CPU oracle
+  throughput_point     the same clouds with 100 000 correspondences (SURVEY 8d's throughput point) and, _q1000000, with 1 M: K steps
+                       from cold, kernel split, the search's roofline on its own tallied bytes, an oracle leg (N > 1: query shards)
+  comm                 (when an exchange ran) backend, rank count as RCCL counts it, partition, shard rows, exchange us per iteration
+  parity               two more iterations after the timed region, checked against the CPU oracle
   setup                upload / grid build / normals, each once per run() -- outside `value`, reported
   run_end_to_end       a real run(): cold, min_change = 1, setup included
   cpu_baseline         the reference's algorithm (oracle/ref_port.py) on this box's host cores, bounded sample
