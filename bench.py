@@ -106,6 +106,8 @@ def load_workload(name, points=None, correspondences=None):
     n = points or cfg["n"]
     Xf, Xm, H_true = synthetic_pair(n)
     desc = f"{name} synthetic {n}-vs-{n} surface (SURVEY 8d generator)"
+    if name == "C3":
+        desc += " -- a STAND-IN: the airborne_lidar1/2.xyz files the config names are missing upstream (.MISSING_LARGE_BLOBS)"
     return Xf, Xm, H_true, Q, cfg["k"], cfg["kwargs"], desc
 
 
