@@ -38,8 +38,8 @@ extern "C" {
 
 /* 1: round 1.  2: + sicp_corr_*, sicp_estimate_parameters, sicp_comm_*, sicp_set_partition, sicp_cloud_set_planarity,
  * sicp_cloud_download_columns, sicp_match_work; sicp_timing_enable(ctx, 2); every upload resets the slot's planarity
- * column.  3: + sicp_comm_activate, sicp_comm_info, sicp_device_memory; SICP_K_XCHG; sicp_comm_init bounded + handshake.  A binding checks sicp_abi_version() against the header it was written for. */
-#define SICP_ABI_VERSION 3
+ * column.  3: + sicp_comm_activate, sicp_comm_info, sicp_device_memory; SICP_K_XCHG; sicp_comm_init bounded + handshake.  4: + sicp_knn_work; sicp_estimate_normals runs the one-sweep k-NN + covariance kernel.  A binding checks sicp_abi_version() against the header it was written for. */
+#define SICP_ABI_VERSION 4
 
 #define SICP_OK               0
 #define SICP_ERR_INVALID     -1   /* bad argument / wrong call order                         */
@@ -314,6 +314,10 @@ int sicp_timing_reset(sicp_ctx *ctx);
  * sicp_timing_enable(ctx, 2) is in force: out3[0] candidates evaluated (one 32-byte record read each), out3[1] non-empty grid rows
  * visited (two 4-byte offsets each), out3[2] launches -- the bytes the bench prices the search's roofline on. */
 int sicp_match_work(sicp_ctx *ctx, uint64_t out3[3]);
+/* Work the one-sweep k-NN (sicp_estimate_normals, sicp_knn with k > 1 on a binned cloud) did since sicp_timing_reset, under
+ * sicp_timing_enable(ctx, 2): out4[0] candidates read (one 32-byte record each), out4[1] sweeps (a query needs one when its first
+ * ball holds k points), out4[2] queries that took the k-round extraction instead, out4[3] candidates inside their query's ball. */
+int sicp_knn_work(sicp_ctx *ctx, uint64_t out4[4]);
 int sicp_timing_get(sicp_ctx *ctx, int kernel, double *total_ms_out, int64_t *launches_out);
 
 #ifdef __cplusplus

@@ -264,12 +264,15 @@ struct sicp_ctx {
     DevBuf<uint32_t> hit_cnt, hit_list;
     int knn1_mode = 0;             // SICP_KNN1 = exact | filter | grid: force one 1-NN flavour (A/B + tests); 0 = auto
     DevBuf<uint32_t> g_ids, g_counts, g_cursor, g_blk;    // grid build scratch: cell ids, histogram, scatter cursors, scan partials
-    DevBuf<unsigned long long> match_work;                // [0] candidates evaluated, [1] grid rows visited, [2] launches (instrumented runs)
+    DevBuf<unsigned long long> match_work;                // [0] candidates evaluated, [1] grid rows visited, [2] launches (instrumented runs); [4..7] the k-NN sweep's tallies
     DevBuf<unsigned long long> rj_keys;   // large-Q rejection scratch: Q keys + the selection state
     bool have_prev_match = false;  // m_p2 holds last iteration's winners (bound source)
     DevBuf<uint32_t> q_order;      // large query sets: the queries [q_order_lo, +q_order_cnt) in cell order (search locality)
     long q_order_lo = -1, q_order_cnt = 0;
     long order_min_q = 32768;      // SICP_ORDER_MIN_Q: from this many queries per launch on (0: never)
+    DevBuf<uint32_t> k_order;      // the queries of a k-NN / normals call in cell order
+    long knn_batch = 0;            // SICP_KNN_BATCH: queries a wave of the one-sweep k-NN works through (0: chosen per launch)
+    bool knn_sweep = true;         // SICP_KNN_SWEEP=0: k extraction rounds (k_grid_knn) + k_normals instead of the one-sweep kernel
     DevBuf<double> bound_p2, bound_d2;   // cold search: nearest subsample point per query (coordinates = the bound) + scratch
     DevBuf<int64_t> bound_idx;
     bool reject_split = true;      // SICP_REJECT_SPLIT=0: mid-Q distances inside the single-workgroup rejection kernel
@@ -705,13 +708,12 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
     return SICP_OK;
 }
 
-// Permutation of the queries [lo, lo + cnt) by cell of a grid over their own bounding box (cell size: the cloud grid's, the
-// two frames differ by a near-rigid H), once per setup.  Only the ORDER in which waves take the queries changes -- every
-// result still lands at the query's own index -- so neighbouring waves walk the same rows of the cloud's grid.
-int query_order_build(sicp_ctx *c, long lo, long cnt, double h)
+// Permutation of `cnt` points (columns qx, qy, qz) by cell of a grid over their own bounding box (cell size h, grown until the
+// table has at most max_cells cells): order[slot] = point.  Only the ORDER in which waves take the queries changes -- every
+// result still lands at the query's own index -- so neighbouring waves walk the same rows of the searched cloud's grid.
+int points_order_build(sicp_ctx *c, const double *qx, const double *qy, const double *qz, long cnt, double h, long max_cells,
+                       DevBuf<uint32_t> &order)
 {
-    if (c->q_order_lo == lo && c->q_order_cnt == cnt) return SICP_OK;
-    const double *qx = c->q.p + lo, *qy = c->q.p + c->qpad + lo, *qz = c->q.p + 2 * c->qpad + lo;
     unsigned long long *d_st = (unsigned long long *)(c->small.p + 40);       // 7 u64
     unsigned long long h_init[7] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull, 0ull};
     HIPCHK(hipMemcpyAsync(d_st, h_init, sizeof h_init, hipMemcpyHostToDevice, c->stream));
@@ -734,7 +736,7 @@ int query_order_build(sicp_ctx *c, long lo, long cnt, double h)
             G.dim[a] = (int)d; ncells *= (long)G.dim[a];
             if (ncells > (1L << 40)) ncells = 1L << 40;
         }
-        if (ncells <= (1L << 25)) break;
+        if (ncells <= max_cells) break;
         h *= 1.3;
     }
     G.h = h; G.inv_h = 1.0 / h;
@@ -742,12 +744,20 @@ int query_order_build(sicp_ctx *c, long lo, long cnt, double h)
     CHK(c->g_counts.reserve((size_t)ncells + 1));
     CHK(c->g_cursor.reserve((size_t)ncells + 1));
     CHK(c->g_blk.reserve((size_t)grid_scan_blocks(ncells) + 1));
-    CHK(c->q_order.reserve(cnt));
+    CHK(order.reserve(cnt));
     HIPCHK(hipMemsetAsync(c->g_counts.p, 0, ((size_t)ncells + 1) * sizeof(uint32_t), c->stream));
     launch_cell_ids(c->stream, qx, qy, qz, cnt, G, c->g_ids.p, c->g_counts.p, nullptr);
     launch_grid_scan(c->stream, c->g_counts.p, ncells, c->g_blk.p, nullptr, c->g_cursor.p);
-    launch_scatter_order(c->stream, c->g_ids.p, cnt, c->g_cursor.p, c->q_order.p);
+    launch_scatter_order(c->stream, c->g_ids.p, cnt, c->g_cursor.p, order.p);
     HIPCHK(hipGetLastError());
+    return SICP_OK;
+}
+
+// the ICP queries [lo, lo + cnt) in cell order (cell size: the cloud grid's, the two frames differ by a near-rigid H), once per setup
+int query_order_build(sicp_ctx *c, long lo, long cnt, double h)
+{
+    if (c->q_order_lo == lo && c->q_order_cnt == cnt) return SICP_OK;
+    CHK(points_order_build(c, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt, h, 1L << 25, c->q_order));
     c->q_order_lo = lo; c->q_order_cnt = cnt;
     return SICP_OK;
 }
@@ -921,16 +931,37 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
     return SICP_OK;
 }
 
-// k-NN (k >= 2, or k == 1 without transform) of SoA queries; (Q,k) device outputs
-int knnk_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, int k, double *d2_out, int64_t *idx_out)
+// does the k-NN of Q queries in this cloud go through the grid?  (the grid build hands 32-bit item counts to its scans)
+bool knnk_uses_grid(const sicp_ctx *c, const Cloud &cl, long Q)
 {
-    Cloud &cl = c->cloud[slot];
-    // the grid build hands 32-bit item counts to the device sort/scan primitives
     const bool big = (cl.n > 65536 || (double)cl.n * (double)Q > 1.0e9) && cl.n < (1LL << 31);
-    if (c->knn1_mode == 3 || (c->knn1_mode == 0 && big)) {     // pruned search on the slot's grid
+    return c->knn1_mode == 3 || (c->knn1_mode == 0 && big);
+}
+
+// k-NN (k >= 2, or k == 1 without transform) of SoA queries; (Q,k) device outputs.  With normals_out / planarity_out the grid
+// path's one-sweep kernel also forms covariance + normal + planarity of every query's neighbourhood (pointcloud.py:188-203) and
+// sets *fused; d2_out / idx_out may then be null (nothing but the normals leaves the kernel).  Otherwise *fused stays false and
+// the caller runs k_normals on the indices.
+int knnk_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, int k, double *d2_out, int64_t *idx_out,
+                float *normals_out = nullptr, float *planarity_out = nullptr, bool *fused = nullptr)
+{
+    if (fused) *fused = false;
+    Cloud &cl = c->cloud[slot];
+    if (knnk_uses_grid(c, cl, Q)) {                            // pruned search on the slot's grid
         CHK(grid_build(c, slot));
         Grid &gr = cl.grid;
-        {
+        if (c->knn_sweep && grid_knn_sweep_handles(k)) {       // one sweep per query (k <= 128)
+            const uint32_t *order = nullptr;
+            if (c->order_min_q > 0 && Q >= c->order_min_q) {
+                CHK(points_order_build(c, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, 2.0 * gr.g.h, 1L << 22, c->k_order));
+                order = c->k_order.p;
+            }
+            Timed t(c, SICP_K_KNNK);
+            launch_grid_knn_sweep(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, order, Q, k, gr.g, gr.avg_per_cell, gr.cell_start.p,
+                                  gr.rec.p, cl.rmax, cl.idx_base, d2_out, idx_out, normals_out, planarity_out,
+                                  c->count_work ? c->match_work.p + 4 : nullptr, c->knn_batch);
+            if (fused) *fused = normals_out != nullptr;
+        } else {
             Timed t(c, SICP_K_KNNK);
             launch_grid_knn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, k, gr.g, gr.cell_start.p, gr.rec.p, cl.rmax,
                             cl.idx_base, d2_out, idx_out);
@@ -1048,8 +1079,8 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (rc == SICP_OK) rc = c->icp_dev.reserve(1);
     if (rc == SICP_OK) rc = c->lm_dev.reserve(1);
     if (rc == SICP_OK && hipHostMalloc((void **)&c->h_lm, sizeof(LmDev), hipHostMallocDefault) != hipSuccess) rc = SICP_ERR_HIP;
-    if (rc == SICP_OK) rc = c->match_work.reserve(4);
-    if (rc == SICP_OK && hipMemsetAsync(c->match_work.p, 0, 4 * sizeof(unsigned long long), c->stream) != hipSuccess) rc = SICP_ERR_HIP;
+    if (rc == SICP_OK) rc = c->match_work.reserve(8);
+    if (rc == SICP_OK && hipMemsetAsync(c->match_work.p, 0, 8 * sizeof(unsigned long long), c->stream) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc == SICP_OK && hipHostMalloc((void **)&c->h_rec, (size_t)REC_RING * REC_DOUBLES * sizeof(double), hipHostMallocMapped) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc == SICP_OK && hipHostMalloc((void **)&c->h_state, sizeof(IcpDev), hipHostMallocDefault) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc == SICP_OK) std::memset(c->h_rec, 0, (size_t)REC_RING * REC_DOUBLES * sizeof(double));
@@ -1057,6 +1088,8 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
     if (const char *e = std::getenv("SICP_LM_EVALS")) { const int d = std::atoi(e); if (d >= 0 && d <= 32) c->lm_evals = d; }
     if (const char *e = std::getenv("SICP_ORDER_MIN_Q")) c->order_min_q = std::atol(e);
+    if (const char *e = std::getenv("SICP_KNN_SWEEP")) c->knn_sweep = std::atoi(e) != 0;
+    if (const char *e = std::getenv("SICP_KNN_BATCH")) c->knn_batch = std::atol(e);
     if (const char *e = std::getenv("SICP_NN16_MIN_Q")) c->nn16_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_REJECT_SPLIT")) c->reject_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_COARSE_ITERS")) c->coarse_iters = std::atoi(e);
@@ -1089,12 +1122,12 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     for (auto &p : c->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &cl : c->cloud) { cl.xyz.release(); cl.pl.release(); cl.grid.cell_start.release(); cl.grid.rec.release();
                                  cl.sub_xyz.release(); cl.sub_grid.cell_start.release(); cl.sub_grid.rec.release(); }
-    c->bound_p2.release(); c->bound_d2.release(); c->bound_idx.release(); c->q_order.release(); c->g_ids.release(); c->g_counts.release(); c->g_cursor.release(); c->g_blk.release(); c->match_work.release(); c->rj_keys.release();
+    c->bound_p2.release(); c->bound_d2.release(); c->bound_idx.release(); c->q_order.release(); c->k_order.release(); c->g_ids.release(); c->g_counts.release(); c->g_cursor.release(); c->g_blk.release(); c->match_work.release(); c->rj_keys.release();
     c->stage.release(); c->part_d2.release(); c->part_idx.release(); c->kq.release(); c->k_d2.release();
     c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->hit_cnt.release(); c->hit_list.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
     c->resid.release(); c->flag.release(); c->keep.release(); c->small.release(); c->ne_partial.release();
-    c->lm_bar_buf.release(); c->ticket.release(); c->icp_dev.release(); c->lm_dev.release(); c->resid2.release();
+    c->lm_bar_buf.release(); c->lm_gsum.release(); c->ticket.release(); c->icp_dev.release(); c->lm_dev.release(); c->resid2.release();
     c->corr_pl.release();
     if (c->h_lm) (void)hipHostFree(c->h_lm);
     if (c->h_small) (void)hipHostFree(c->h_small);
@@ -1349,9 +1382,10 @@ SICP_EXPORT int sicp_estimate_normals(sicp_ctx *c, int slot, const int64_t *sel_
     HIPCHK(hipSetDevice(c->device));
     const long qpad = round_up(Q, QPAD);
     CHK(c->kq.reserve((size_t)3 * qpad));
-    CHK(c->k_d2.reserve((size_t)Q * k));
-    CHK(c->k_idx.reserve((size_t)Q * k));
-    // selected rows -> device (reuse m_idx-sized scratch in k_idx tail? keep it simple: own buffer)
+    // the one-sweep kernel keeps the neighbours on chip: the (Q, k) index / distance arrays exist only when the caller wants them
+    const bool sweep = c->knn_sweep && knnk_uses_grid(c, cl, Q) && grid_knn_sweep_handles(k);
+    const bool want_lists = !sweep || nn_idx_out;
+    if (want_lists) { CHK(c->k_d2.reserve((size_t)Q * k)); CHK(c->k_idx.reserve((size_t)Q * k)); }
     DevBuf<int64_t> sel; DevBuf<float> nv, pl;
     int rc = sel.reserve(Q);
     if (rc == SICP_OK) rc = nv.reserve((size_t)3 * Q);
@@ -1359,8 +1393,10 @@ SICP_EXPORT int sicp_estimate_normals(sicp_ctx *c, int slot, const int64_t *sel_
     auto body = [&]() -> int {
         HIPCHK(hipMemcpyAsync(sel.p, sel_idx, (size_t)Q * sizeof(int64_t), hipMemcpyDefault, c->stream));
         launch_gather_queries(c->stream, cl.x(), cl.y(), cl.z(), sel.p, Q, qpad, c->kq.p, c->kq.p + qpad, c->kq.p + 2 * qpad);
-        CHK(knnk_device(c, slot, c->kq.p, Q, qpad, k, c->k_d2.p, c->k_idx.p));
-        launch_normals(c->stream, cl.x(), cl.y(), cl.z(), c->k_idx.p, Q, k, cl.idx_base, nv.p, pl.p);
+        bool fused = false;
+        CHK(knnk_device(c, slot, c->kq.p, Q, qpad, k, want_lists ? c->k_d2.p : nullptr, want_lists ? c->k_idx.p : nullptr, nv.p, pl.p,
+                        &fused));
+        if (!fused) launch_normals(c->stream, cl.x(), cl.y(), cl.z(), c->k_idx.p, Q, k, cl.idx_base, nv.p, pl.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(normals_out, nv.p, (size_t)3 * Q * sizeof(float), hipMemcpyDefault, c->stream));
         HIPCHK(hipMemcpyAsync(planarity_out, pl.p, (size_t)Q * sizeof(float), hipMemcpyDefault, c->stream));
@@ -1846,7 +1882,7 @@ SICP_EXPORT int sicp_icp_get_state(sicp_ctx *c, int64_t *pc2_idx, double *dist, 
         // the sharded reduction left only this rank's slice of the residuals current: one pass over all of them at the estimate
         double ne[30];
         CHK(normal_eq_host(c, c->last_x, true, false, ne));
-        c->resid_slot = 0; c->resid_sharded = false; c->resid_sharded = false;
+        c->resid_slot = 0; c->resid_sharded = false;
     }
     if (residual) HIPCHK(hipMemcpyAsync(residual, c->resid_slot ? c->resid2.p : c->resid.p, Q * sizeof(double), hipMemcpyDefault, c->stream));
     return sync(c);
@@ -2252,11 +2288,18 @@ SICP_EXPORT int sicp_match_work(sicp_ctx *c, uint64_t out3[3])
     HIPCHK(hipMemcpyAsync(out3, c->match_work.p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     return sync(c);
 }
+SICP_EXPORT int sicp_knn_work(sicp_ctx *c, uint64_t out4[4])
+{
+    if (!c || !out4) return fail(SICP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(out4, c->match_work.p + 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    return sync(c);
+}
 SICP_EXPORT int sicp_timing_reset(sicp_ctx *c)
 {
     if (!c) return fail(SICP_ERR_INVALID, "null ctx");
     if (!c->pending.empty()) CHK(sync(c));
-    HIPCHK(hipMemsetAsync(c->match_work.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->match_work.p, 0, 8 * sizeof(unsigned long long), c->stream));
     for (int i = 0; i < SICP_K_COUNT; ++i) { c->t_ms[i] = 0; c->t_n[i] = 0; }
     return SICP_OK;
 }

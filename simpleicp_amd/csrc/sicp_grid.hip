@@ -19,11 +19,13 @@
 // (corrpts.py:131, simpleicp.py:188-202).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cmath>
 #include <algorithm>
 #include <stdint.h>
 
 #include "sicp_internal.h"
 #include "sicp_lanes.h"
+#include "sicp_normals.h"
 
 namespace sicp {
 
@@ -836,6 +838,301 @@ __global__ __launch_bounds__(256) void k_grid_knn(
 }
 
 // ------------------------------------------------------------------------------------
+// k nearest neighbours in ONE sweep, covariance and eigen-decomposition in the same launch (estimate_normals,
+// pointcloud.py:185-203).  k_grid_knn above walks its candidate cells 2 x k times and hands (Q, k) indices to k_normals,
+// which gathers every neighbour again from the coordinate columns: 17.9 GB of HBM traffic per 1 M queries for 0.36 GB of
+// algorithmic bytes (round 3).  Here:
+//   * a wave takes one query at a time and sweeps the cells of a ball around it ONCE (rows culled to the ball as in
+//     k_grid_nn, four rows' records in flight together); candidates within the pass's radius -- the only ones that can be
+//     among the k nearest IF the ball holds k points -- are compacted into LDS with their coordinates (ballot + mbcnt);
+//   * ball holds >= k survivors: every survivor counts the survivors lexicographically below it on (d2, original index)
+//     -- its rank, exact and unique -- and the k smallest leave in rank order; fewer: the radius grows towards ~1.8 k
+//     expected points and the sweep repeats; more than the LDS holds: the radius shrinks, and data that defeats that
+//     (thousands of coincident points) takes the k-round extraction of k_grid_knn over the same cells;
+//   * the neighbours' coordinates are still in LDS: six lanes form the mean and the six covariance sums in the oracle's
+//     operation order (orc_normals: sequential in rank order), nothing is gathered again and no index goes to memory unless
+//     the caller asked for it;
+//   * a wave works through `batch` queries that are neighbours in space (the caller hands the queries in cell order) -- the
+//     k-th distance of one is the next one's starting radius, their cells are in L1/L2 -- and parks query b's covariance in
+//     lane b; when the batch is through, the lanes run the Jacobi eigen-solver side by side (one lane at a time it would
+//     cost more than the search).
+// Same answers as k_grid_knn + k_normals, bit for bit (tests run both).
+// ------------------------------------------------------------------------------------
+struct KnnKey { double d2; uint32_t idx; uint32_t pad; };
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS operations of one wave execute in order: only the compiler has to be kept from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int KS_MAXK = 128;                // largest k of the sweep kernel (above: k_grid_knn + k_normals)
+__host__ __device__ constexpr int ks_wave_doubles(int cap) { return 5 * cap + KS_MAXK / 4; }    // keys 2, xyz 3 per slot; perm u16[128]
+
+template <int NS /* survivor slots per lane: the LDS of a wave holds 64 * NS */>
+__global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+    const uint32_t *__restrict__ order /* nullable: queries in cell order (grid size is a multiple of 8 then) */,
+    const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
+    long Q, int k, int batch, GridGeom G, double rmax, double r_first, int64_t idx_base,
+    double *__restrict__ d2_out /* nullable */, int64_t *__restrict__ idx_out /* nullable */,
+    float *__restrict__ normals /* nullable: no covariance / eigen step */, float *__restrict__ planarity,
+    unsigned long long *__restrict__ work /* nullable: [0] candidates read, [1] sweeps, [2] queries on the k-round path, [3] survivors */)
+{
+    constexpr int CAP = 64 * NS;
+    extern __shared__ double ks_lds[];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *wbase = ks_lds + (size_t)wid * ks_wave_doubles(CAP);
+    KnnKey *keys = (KnnKey *)wbase;
+    double *xyz = wbase + 2 * CAP;
+    uint16_t *perm = (uint16_t *)(wbase + 5 * CAP);
+
+    long blk = blockIdx.x;
+    if (order) blk = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);       // one contiguous eighth per XCD
+    const long slot0 = (blk * 4 + wid) * (long)batch;
+    if (slot0 >= Q) return;
+    const int nb = (int)((Q - slot0 < (long)batch) ? (Q - slot0) : (long)batch);
+    uint32_t my_q = 0;
+    if (lane < nb) my_q = order ? order[slot0 + lane] : (uint32_t)(slot0 + lane);
+    double cov[6] = {0, 0, 0, 0, 0, 0};
+    bool my_ok = false;
+    unsigned long long n_cand = 0, n_sweeps = 0, n_slow = 0, n_surv = 0;
+    const double etol = 1e-6 * G.h;
+    double r_carry = r_first;
+
+    for (int b = 0; b < nb; ++b) {
+        const long q = (long)(uint32_t)__builtin_amdgcn_readlane((int)my_q, b);
+        const double ax = qx[q], ay = qy[q], az = qz[q];
+        const double scale = rmax + sqrt(fma(az, az, fma(ay, ay, ax * ax))) + 1.0;
+        const double slack = 1e-12 * scale;
+        const double c3[3] = {ax, ay, az};
+        double r = r_carry;
+        int shrinks = 0;
+        int kk = 0;                                   // neighbours found (k, or every point of the cloud if it holds fewer)
+        for (int pass = 0; pass < 4096; ++pass) {
+            int lo[3], hi[3];
+            bool all = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double fl = floor((c3[a] - r - G.mn[a]) * G.inv_h - 1e-6);
+                const double fh = floor((c3[a] + r - G.mn[a]) * G.inv_h + 1e-6);
+                lo[a] = fl < 0.0 ? 0 : (fl > (double)(G.dim[a] - 1) ? G.dim[a] - 1 : (int)fl);
+                hi[a] = fh < 0.0 ? 0 : (fh > (double)(G.dim[a] - 1) ? G.dim[a] - 1 : (int)fh);
+                all = all && (fl <= 0.0) && (fh >= (double)(G.dim[a] - 1));
+            }
+            const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
+            const long nrows = (long)ny * nz;
+            // a candidate at d2 <= thr lies inside the ball with room for every rounding: no point of a culled cell ties or beats it
+            const double r_eff = (r - slack) / (1.0 + 1e-12);
+            const double thr = all ? __builtin_inf() : (r_eff > 0.0 ? r_eff * r_eff : -1.0);
+            const double r2 = r * r;
+            unsigned ns = 0;                          // survivors so far (wave-uniform)
+            n_sweeps += 1;
+            for (long rb = 0; rb < nrows; rb += 64) {
+                uint32_t rbeg = 0, rlen = 0;
+                if (rb + lane < nrows) {
+                    const long rr = rb + lane;
+                    const int cy = lo[1] + (int)(rr % ny), cz = lo[2] + (int)(rr / ny);
+                    const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
+                    int xl = lo[0], xh = hi[0];
+                    if (!all) {
+                        const double yl = G.mn[1] + (double)cy * G.h, zl = G.mn[2] + (double)cz * G.h;
+                        const double dy = fmax(fmax(yl - etol - ay, ay - (yl + G.h + etol)), 0.0);
+                        const double dz = fmax(fmax(zl - etol - az, az - (zl + G.h + etol)), 0.0);
+                        const double rem = r2 - fma(dy, dy, dz * dz);
+                        if (rem >= 0.0) {
+                            const double hw = (rem < 1e-30 ? 1e-15 : (double)(sqrtf((float)rem) * 1.000001f)) + etol;
+                            const double fl = floor((ax - hw - G.mn[0]) * G.inv_h - 1e-6);
+                            const double fh = floor((ax + hw - G.mn[0]) * G.inv_h + 1e-6);
+                            const int tl = fl < 0.0 ? 0 : (fl > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fl);
+                            const int th = fh < 0.0 ? 0 : (fh > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fh);
+                            xl = tl > xl ? tl : xl; xh = th < xh ? th : xh;
+                        } else {
+                            xh = xl - 1;
+                        }
+                    }
+                    if (xh >= xl) {
+                        rbeg = cell_start[row + xl];
+                        rlen = cell_start[row + xh + 1] - rbeg;
+                    }
+                }
+                unsigned long long todo = __ballot(rlen > 0);
+                while (todo) {
+                    uint32_t rbv[4], rlv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        rbv[u] = 0; rlv[u] = 0;
+                        if (todo) {
+                            const int j = __ffsll((long long)todo) - 1;
+                            todo &= todo - 1ull;
+                            rbv[u] = (uint32_t)__builtin_amdgcn_readlane((int)rbeg, j);
+                            rlv[u] = (uint32_t)__builtin_amdgcn_readlane((int)rlen, j);
+                        }
+                    }
+                    uint32_t longest = rlv[0] > rlv[1] ? rlv[0] : rlv[1];
+                    { const uint32_t t2 = rlv[2] > rlv[3] ? rlv[2] : rlv[3]; longest = longest > t2 ? longest : t2; }
+                    for (uint32_t o = 0; o < longest; o += 64) {
+                        double4 P[4];
+                        bool ok[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            ok[u] = o + (uint32_t)lane < rlv[u];
+                            P[u] = rec[ok[u] ? rbv[u] + o + (uint32_t)lane : 0u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double dx = P[u].x - ax, dy = P[u].y - ay, dz = P[u].z - az;
+                            const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                            const bool sv = ok[u] && d2 <= thr;
+                            const unsigned long long m = __ballot(sv);
+                            if (m) {
+                                const unsigned pos = ns + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                if (sv && pos < (unsigned)CAP) {
+                                    keys[pos].d2 = d2; keys[pos].idx = (uint32_t)__double_as_longlong(P[u].w);
+                                    xyz[3 * pos] = P[u].x; xyz[3 * pos + 1] = P[u].y; xyz[3 * pos + 2] = P[u].z;
+                                }
+                                ns += (unsigned)__popcll((long long)m);
+                            }
+                            if (work) n_cand += ok[u] ? 1 : 0;
+                        }
+                    }
+                }
+            }
+            if (ns > (unsigned)CAP && !all && shrinks < 3) {
+                // far more than k points in the ball: aim at ~2 k of them (a count that grows like r^2 is the slow case)
+                double f = sqrt(2.0 * (double)k / (double)ns);
+                r *= f < 0.3 ? 0.3 : (f > 0.8 ? 0.8 : f);
+                ++shrinks;
+                continue;
+            }
+            if (ns < (unsigned)k && !all) {
+                // too few: aim at ~1.8 k (count ~ r^2 on a surface), at least a quarter more, at most twice the radius
+                double f = ns ? sqrt(1.8 * (double)k / (double)ns) : 2.0;
+                r *= f < 1.25 ? 1.25 : (f > 2.0 ? 2.0 : f);
+                continue;
+            }
+            n_surv += ns;
+            kk = ns < (unsigned)k ? (int)ns : k;
+            if (ns <= (unsigned)CAP) {
+                // ---- rank by counting: survivor e's rank = number of survivors below it on (d2, index) ----
+                wave_lds_sync();
+                double md[NS]; uint32_t mi[NS]; unsigned rk[NS];
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    const unsigned e = (unsigned)lane + 64u * t;
+                    const bool has = e < ns;
+                    md[t] = has ? keys[e].d2 : __builtin_inf();
+                    mi[t] = has ? keys[e].idx : 0xffffffffu;
+                    rk[t] = 0;
+                }
+                for (unsigned j = 0; j < ns; ++j) {
+                    const double od = keys[j].d2; const uint32_t oi = keys[j].idx;        // (same address in every lane: a broadcast)
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) rk[t] += (od < md[t] || (od == md[t] && oi < mi[t])) ? 1u : 0u;
+                }
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    const unsigned e = (unsigned)lane + 64u * t;
+                    if (e < ns && rk[t] < (unsigned)k) {
+                        perm[rk[t]] = (uint16_t)e;
+                        if (idx_out) idx_out[q * k + rk[t]] = idx_base + (int64_t)mi[t];
+                        if (d2_out) d2_out[q * k + rk[t]] = md[t];
+                    }
+                }
+            } else {
+                // ---- the ball holds more than the LDS does and would not shrink (coincident points), or the whole grid was
+                // asked for: k extraction rounds over the pass's cells (k_grid_knn's search); final, the ball holds k points ----
+                n_slow += 1;
+                double fd = -1.0; uint32_t fi = 0;
+                bool first = true;
+                kk = 0;
+                for (int j = 0; j < k; ++j) {
+                    double best = __builtin_inf(); uint32_t bidx = 0xffffffffu, bpos = 0;
+                    for (long rr = 0; rr < nrows; ++rr) {
+                        const int cy = lo[1] + (int)(rr % ny), cz = lo[2] + (int)(rr / ny);
+                        const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
+                        const uint32_t bb = cell_start[row + lo[0]], ee = cell_start[row + hi[0] + 1];
+                        for (uint32_t i = bb + lane; i < ee; i += 64) {
+                            const double4 P = rec[i];
+                            const double dx = P.x - ax, dy = P.y - ay, dz = P.z - az;
+                            const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                            const uint32_t oi = (uint32_t)__double_as_longlong(P.w);
+                            const bool above = first || d2 > fd || (d2 == fd && oi > fi);
+                            if (above && (d2 < best || (d2 == best && oi < bidx))) { best = d2; bidx = oi; bpos = i; }
+                        }
+                    }
+#define SICP_LEXMIN_STEP(J)                                                                       \
+                    {                                                                             \
+                        const double od = lane_xor_f64<J>(best);                                  \
+                        const uint32_t oi = lane_xor32<J>(bidx), op = lane_xor32<J>(bpos);        \
+                        if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; bpos = op; } \
+                    }
+                    SICP_LEXMIN_STEP(32) SICP_LEXMIN_STEP(16) SICP_LEXMIN_STEP(8) SICP_LEXMIN_STEP(4) SICP_LEXMIN_STEP(2) SICP_LEXMIN_STEP(1)
+#undef SICP_LEXMIN_STEP
+                    if (bidx == 0xffffffffu) break;         // the cloud holds fewer than k points
+                    const double4 W = rec[bpos];
+                    if (lane == 0) {
+                        if (idx_out) idx_out[q * k + j] = idx_base + (int64_t)bidx;
+                        if (d2_out) d2_out[q * k + j] = best;
+                        keys[j].d2 = best; keys[j].idx = bidx;
+                        xyz[3 * j] = W.x; xyz[3 * j + 1] = W.y; xyz[3 * j + 2] = W.z;
+                        perm[j] = (uint16_t)j;
+                    }
+                    fd = best; fi = bidx; first = false; kk = j + 1;
+                }
+            }
+            break;
+        }
+        // a cloud with fewer than k points: the missing neighbours read -1 / inf
+        for (int j = kk + lane; j < k; j += 64) {
+            if (idx_out) idx_out[q * k + j] = (int64_t)-1;
+            if (d2_out) d2_out[q * k + j] = __builtin_inf();
+        }
+        wave_lds_sync();
+        // the next query of the batch is a neighbour in space: start from this one's k-th distance
+        if (kk == k) {
+            const double dk = keys[perm[k - 1]].d2;
+            const double rn = 1.35 * sqrt(dk) + slack;
+            r_carry = rn > 0.25 * r_first ? rn : 0.25 * r_first;
+        }
+        if (normals) {
+            // mean and covariance sums in rank order, one sum per lane (orc_normals' operation order: pointcloud.py:188-190)
+            double cv = 0.0;
+            if (lane < 6 && kk == k) {
+                const int a = lane < 3 ? 0 : (lane < 5 ? 1 : 2);
+                const int c = lane < 3 ? lane : (lane < 5 ? lane - 2 : 2);
+                double ma = 0.0, mc = 0.0;
+                for (int s = 0; s < k; ++s) { const int e = perm[s]; ma += xyz[3 * e + a]; mc += xyz[3 * e + c]; }
+                ma /= (double)k; mc /= (double)k;
+                for (int s = 0; s < k; ++s) { const int e = perm[s]; cv = fma(xyz[3 * e + a] - ma, xyz[3 * e + c] - mc, cv); }
+                cv *= 1.0 / (double)(k - 1);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(cv);
+                const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, i);
+                const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), i);
+                if (lane == b) cov[i] = __longlong_as_double((long long)(((unsigned long long)hi32 << 32) | lo32));
+            }
+            if (lane == b) my_ok = kk == k;
+        }
+        wave_lds_sync();                              // (the next sweep overwrites the survivors)
+    }
+    if (normals && lane < nb) {
+        float nrm[3] = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")}, pl = __builtin_nanf("");
+        if (my_ok) normal_from_cov(cov, nrm, &pl);
+        normals[3 * (long)my_q] = nrm[0]; normals[3 * (long)my_q + 1] = nrm[1]; normals[3 * (long)my_q + 2] = nrm[2];
+        planarity[my_q] = pl;
+    }
+    if (work) {
+        n_cand = wsum_u64(n_cand);
+        if (lane == 0) { atomicAdd(work, n_cand); atomicAdd(work + 1, n_sweeps); atomicAdd(work + 2, n_slow); atomicAdd(work + 3, n_surv); }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // median / raw-MAD rejection for LARGE Q (corrpts.py:165-188): exact order statistics by digit SELECTION over many
 // workgroups on the order-preserving uint64 image of the distances -- keys are formed on the fly from (dist, flag),
 // nothing is sorted, nothing but ~35 KB of state is written -- everything chained on the stream without a host
@@ -1541,6 +1838,33 @@ void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const do
 {
     hipLaunchKernelGGL(k_grid_knn, dim3(cdiv(Q, 4)), dim3(256), 0, s, qx, qy, qz, Q, k, G, cell_start, (const double4 *)rec,
                        rmax, idx_base, d2_out, idx_out);
+}
+
+bool grid_knn_sweep_handles(int k) { return k >= 1 && k <= KS_MAXK; }
+
+// the one-sweep k-NN (k <= KS_MAXK), with covariance + eigen-decomposition when `normals` is given.  avg_per_cell: points per
+// occupied cell of the grid (sets the first radius: a ball that is expected to hold ~1.8 k points of a surface)
+void launch_grid_knn_sweep(hipStream_t s, const double *qx, const double *qy, const double *qz, const uint32_t *order, long Q, int k,
+                           const GridGeom &G, double avg_per_cell, const uint32_t *cell_start, const void *rec, double rmax,
+                           int64_t idx_base, double *d2_out, int64_t *idx_out, float *normals, float *planarity,
+                           unsigned long long *work, long batch_override)
+{
+    // enough waves to fill the machine several times over before a wave takes more than one query (8192 waves: 8 per SIMD)
+    long batch = batch_override > 0 ? batch_override : Q / 8192;
+    batch = batch < 1 ? 1 : (batch > 64 ? 64 : batch);
+    const double ppc = avg_per_cell >= 1.0 ? avg_per_cell : 1.0;
+    double r_first = 1.35 * G.h * std::sqrt((double)k / (3.141592653589793 * ppc));
+    if (!(r_first > 0.0) || !std::isfinite(r_first)) r_first = G.h;
+    unsigned g = cdiv(Q, 4 * batch);
+    if (order) g = (g + 7u) & ~7u;
+#define SICP_KS_LAUNCH(NS)                                                                                                     \
+    hipLaunchKernelGGL((k_grid_knn_sweep<NS>), dim3(g), dim3(256), 4 * ks_wave_doubles(64 * NS) * sizeof(double), s, qx, qy, qz, order, \
+                       cell_start, (const double4 *)rec, Q, k, (int)batch, G, rmax, r_first, idx_base, d2_out, idx_out, normals,  \
+                       planarity, work)
+    if (k <= 32) SICP_KS_LAUNCH(2);
+    else if (k <= 64) SICP_KS_LAUNCH(4);
+    else SICP_KS_LAUNCH(8);
+#undef SICP_KS_LAUNCH
 }
 
 }  // namespace sicp

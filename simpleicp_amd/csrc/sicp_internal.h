@@ -123,6 +123,12 @@ void launch_scatter_order(hipStream_t s, const uint32_t *ids, long n, uint32_t *
 void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int k, const GridGeom &G,
                      const uint32_t *cell_start, const void *rec, double rmax, int64_t idx_base, double *d2_out, int64_t *idx_out);
 
+bool grid_knn_sweep_handles(int k);
+void launch_grid_knn_sweep(hipStream_t s, const double *qx, const double *qy, const double *qz, const uint32_t *order, long Q, int k,
+                           const GridGeom &G, double avg_per_cell, const uint32_t *cell_start, const void *rec, double rmax,
+                           int64_t idx_base, double *d2_out, int64_t *idx_out, float *normals, float *planarity,
+                           unsigned long long *work, long batch_override = 0);
+
 void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec);
 void launch_pack_idx(hipStream_t s, const int64_t *idx, long cnt, long per, double *out);
 void launch_unpack_idx_postmatch(hipStream_t s, const double *gathered, long Q, const double *cx, const double *cy, const double *cz,

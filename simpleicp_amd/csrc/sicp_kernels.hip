@@ -16,6 +16,7 @@
 
 #include "sicp_internal.h"
 #include "sicp_lanes.h"
+#include "sicp_normals.h"
 
 namespace sicp {
 
@@ -729,39 +730,6 @@ __global__ void k_knnk_merge(const double *__restrict__ part_d2, const uint32_t 
 // K3: covariance + symmetric 3x3 eigen-decomposition     pointcloud.py:188-198
 // one query per lane, fp64, same operation order as oracle/sicp_oracle.c:orc_normals.
 // ------------------------------------------------------------------------------------
-__device__ void jacobi3(double a[3][3], double v[3][3])
-{
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 64; ++sweep) {
-        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
-        if (off == 0.0) break;
-#pragma unroll
-        for (int pq = 0; pq < 3; ++pq) {
-            const int p = (pq == 2) ? 1 : 0;
-            const int q = (pq == 0) ? 1 : 2;
-            const int r = 3 - p - q;
-            if (a[p][q] == 0.0) continue;
-            const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-            const double apq = a[p][q];
-            a[p][p] -= t * apq; a[q][q] += t * apq; a[p][q] = 0.0; a[q][p] = 0.0;
-            const double arp = a[r][p], arq = a[r][q];
-            a[r][p] = c * arp - s * arq; a[p][r] = a[r][p];
-            a[r][q] = s * arp + c * arq; a[q][r] = a[r][q];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const double vip = v[i][p], viq = v[i][q];
-                v[i][p] = c * vip - s * viq;
-                v[i][q] = s * vip + c * viq;
-            }
-        }
-    }
-}
-
 __global__ void k_normals(const double *__restrict__ px, const double *__restrict__ py,
                           const double *__restrict__ pz, const int64_t *__restrict__ nn, long Q, int k,
                           int64_t idx_base, float *__restrict__ normals, float *__restrict__ planarity)
@@ -783,30 +751,11 @@ __global__ void k_normals(const double *__restrict__ px, const double *__restric
         C[1][1] = fma(d1, d1, C[1][1]); C[1][2] = fma(d1, d2, C[1][2]); C[2][2] = fma(d2, d2, C[2][2]);
     }
     const double inv = 1.0 / (double)(k - 1);
-    C[0][0] *= inv; C[0][1] *= inv; C[0][2] *= inv; C[1][1] *= inv; C[1][2] *= inv; C[2][2] *= inv;
-    C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
-    double V[3][3];
-    jacobi3(C, V);
-    const double w[3] = {C[0][0], C[1][1], C[2][2]};
-    int lo = 0, hi = 0;
-#pragma unroll
-    for (int c = 1; c < 3; ++c) { if (w[c] < w[lo]) lo = c; if (w[c] > w[hi]) hi = c; }
-    if (lo == hi) { lo = 2; hi = 0; }
-    const int mid = 3 - lo - hi;
-    double wl = 0, wm = 0, wh = 0, n0 = 0, n1 = 0, n2 = 0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if (c == lo) { wl = w[c]; n0 = V[0][c]; n1 = V[1][c]; n2 = V[2][c]; }
-        if (c == mid) wm = w[c];
-        if (c == hi) wh = w[c];
-    }
-    int big = 0; double bigv = fabs(n0);
-    if (fabs(n1) > bigv) { big = 1; bigv = fabs(n1); }
-    if (fabs(n2) > bigv) { big = 2; }
-    const double lead = (big == 0) ? n0 : (big == 1) ? n1 : n2;
-    if (lead < 0) { n0 = -n0; n1 = -n1; n2 = -n2; }
-    normals[3 * q] = (float)n0; normals[3 * q + 1] = (float)n1; normals[3 * q + 2] = (float)n2;
-    planarity[q] = (float)((wm - wl) / wh);
+    const double c6[6] = {C[0][0] * inv, C[0][1] * inv, C[0][2] * inv, C[1][1] * inv, C[1][2] * inv, C[2][2] * inv};
+    float nrm[3], pl;
+    normal_from_cov(c6, nrm, &pl);
+    normals[3 * q] = nrm[0]; normals[3 * q + 1] = nrm[1]; normals[3 * q + 2] = nrm[2];
+    planarity[q] = pl;
 }
 
 // ------------------------------------------------------------------------------------

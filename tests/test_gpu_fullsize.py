@@ -290,6 +290,31 @@ def test_large_q_iterations_equal_oracle_at_full_size(data, big_q):
     assert whole[-1].n_kept == R.n_kept and abs(whole[-1].median - R.median) < 1e-12 and abs(whole[-1].mad - R.mad) < 1e-12
 
 
+def test_normals_at_one_million_queries_equal_oracle(data, big_q):
+    """estimate_normals at Q = 1 M on 10 M points (pointcloud.py:173-203; C5-class Q): the one-sweep k-NN + covariance kernel with
+    64 cell-ordered queries per wave.  A 3 000-query sample against the oracle's brute-force k-NN over the whole cloud -- indices
+    bit for bit incl. their (d2, idx) order -- and the normals / planarity the kernel formed WITHOUT writing those lists
+    against the oracle's covariance + eigen step on them (float32 store, 1 ulp of a unit vector's component)."""
+    from simpleicp_amd import _lib
+    from oracle import orc
+    Xf, _, _, _ = data
+    c, sel, nv, pl = big_q
+    pick = np.unique(np.round(np.linspace(0, len(sel) - 1, 3000)).astype(np.int64))
+    onn, _ = orc.knn(Xf, Xf[sel[pick]], k=10)
+    onv, opl = orc.normals(Xf, onn)
+    assert np.abs(nv[pick] - onv).max() <= 2e-7 and np.abs(pl[pick] - opl).max() <= 2e-6
+    assert np.isfinite(nv).all() and np.isfinite(pl).all()
+    # the same call with the index lists asked for: same normals, and the lists are the oracle's
+    c.timing_enable(True, count_work=True); c.timing_reset()
+    nv2, pl2, nn = c.estimate_normals(_lib.FIX, sel, 10, want_nn=True)
+    work = c.knn_work()
+    c.timing_enable(False)
+    assert np.array_equal(nv2, nv) and np.array_equal(pl2, pl)
+    assert np.array_equal(nn[pick], onn) and np.array_equal(nn[:, 0], sel)
+    assert work["sweeps"] >= len(sel) and work["slow_queries"] == 0, work
+    assert work["candidates"] <= 200 * len(sel), work              # (round 3's k-round search read ~20 x that)
+
+
 def test_mid_q_iteration_equals_oracle_at_full_size(data, big_q):
     """... and Q = 100 000 (SURVEY 8d's throughput point) on the same resident clouds."""
     Xf, Xm, H_true, _ = data

@@ -649,3 +649,76 @@ def test_eight_queries_per_wave_equals_four(quantised):
     for x, idx, dist, keep, xn in out["8"][:2]:
         nn, _ = orc.knn(Xm, P[sel], k=1, H=orc.params_to_H(x))
         assert np.array_equal(idx, nn[:, 0])
+
+
+# ---- the one-sweep k-NN + covariance kernel (k_grid_knn_sweep) == k extraction rounds + k_normals == oracle ----
+def _knn_cases():
+    rng = np.random.default_rng(2024)
+    surf = _surface(60_000, 5)
+    line = np.zeros((4000, 3)); line[:, 0] = np.round(rng.uniform(0, 50, 4000), 3)
+    clustered = np.concatenate([rng.normal(c, 0.05, (3000, 3)) for c in rng.uniform(-20, 20, (6, 3))] + [rng.uniform(-30, 30, (2000, 3))])
+    dup = np.concatenate((np.tile(np.array([[1.0, 2.0, 3.0]]), (3000, 1)), rng.uniform(-1, 5, (3000, 3))))       # 3000 coincident points
+    return {
+        "surface": (surf, 10), "surface_k40": (surf, 40), "surface_k128": (surf[:20_000], 128), "surface_k129": (surf[:20_000], 129),
+        "quantised_ties": (np.round(rng.uniform(-5, 5, (20_000, 3)), 1), 10),
+        "line": (line, 10), "clustered": (clustered, 16), "coincident": (dup, 10), "coincident_k70": (dup, 70),
+        "utm_offset": (surf[:30_000] + np.array([4.3e5, 5.2e6, 300.0]), 10),
+        "fewer_points_than_k": (rng.uniform(0, 1, (7, 3)), 10),
+        "volume": (rng.uniform(0, 30, (50_000, 3)), 12),
+    }
+
+
+@pytest.mark.parametrize("case", list(_knn_cases()))
+@pytest.mark.parametrize("batch,ordered", [("0", False), ("64", True), ("5", True)])
+def test_knn_sweep_equals_rounds_and_oracle(case, batch, ordered):
+    """sicp_knn(k > 1) and sicp_estimate_normals through the one-sweep kernel -- one query per wave, and batches of 5 / 64 queries in
+    cell order whose starting radius is the previous query's k-th distance -- against the k-round search + k_normals
+    (SICP_KNN_SWEEP=0) and the oracle: indices and squared distances bit for bit, normals / planarity bit for bit against the
+    other kernel pair and to 1 ulp(f32) against the oracle (pointcloud.py:185-203)."""
+    import os
+    from simpleicp_amd import _lib
+    P, k = _knn_cases()[case]
+    n = len(P)
+    rng = np.random.default_rng(k + n)
+    sel = np.sort(rng.choice(n, min(n, 700), replace=False))
+    out = {}
+    for sweep in ("1", "0"):
+        env = {"SICP_KNN1": "grid", "SICP_KNN_SWEEP": sweep, "SICP_KNN_BATCH": batch, "SICP_ORDER_MIN_Q": "1" if ordered else "0"}
+        os.environ.update(env)
+        try:
+            c = _lib.Context(0)
+        finally:
+            for key in env:
+                del os.environ[key]
+        with c:
+            c.upload(_lib.FIX, P)
+            c.timing_enable(True, count_work=True); c.timing_reset()
+            idx, d2 = c.knn(_lib.FIX, P[sel], k=k)
+            if k <= n:
+                nv, pl, nn = c.estimate_normals(_lib.FIX, sel, k, want_nn=True)
+                nv2, pl2 = c.estimate_normals(_lib.FIX, sel, k)           # (no index lists leave the kernel)
+                assert np.array_equal(nv, nv2, equal_nan=True) and np.array_equal(pl, pl2, equal_nan=True)
+            else:
+                nv = pl = nn = None
+            out[sweep] = (idx, d2, nv, pl, nn, c.knn_work())
+    ridx, rd2 = orc.knn(P, P[sel], k=k)
+    for key in ("1", "0"):
+        idx, d2, nv, pl, nn, work = out[key]
+        assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+        if nn is not None:
+            assert np.array_equal(nn, ridx)
+    w = out["1"][5]
+    if k <= 128:
+        assert w["sweeps"] >= len(sel) and w["candidates"] > 0, w           # the sweep kernel ran ...
+        if case.startswith("coincident"):
+            assert w["slow_queries"] > 0, w                                    # ... and its k-round path where the LDS cannot hold the ball
+    else:
+        assert w["sweeps"] == 0, w                                            # k > 128: the k-round kernel
+    assert out["0"][5]["sweeps"] == 0
+    if k <= n:
+        a, b = out["1"], out["0"]
+        assert np.array_equal(a[2], b[2], equal_nan=True) and np.array_equal(a[3], b[3], equal_nan=True)
+        rnv, rpl = orc.normals(P, ridx)
+        ok = np.isfinite(rpl)
+        assert np.abs(a[2] - rnv)[np.isfinite(rnv)].max() <= 2e-7
+        assert np.abs(a[3] - rpl)[ok].max() <= 2e-6 * max(1.0, np.abs(rpl[ok]).max())

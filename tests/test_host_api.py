@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/simpleicp_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert L.sicp_abi_version() == _lib.ABI_VERSION == 3
+    assert L.sicp_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_params_to_H_matches_reference_convention():
