@@ -442,6 +442,8 @@ def run(args):
             # sampled oracle leg, 1e10 pairs (the full-size legs of tests/test_gpu_fullsize.py check 3 000 queries per iteration)
             rec_t, sel_t, nv_t, pl_t, obs_t, ow_t = tp.pop("_parity_args")
             tp["parity"] = parity_oracle(rec_t, Xf, Xm, sel_t, nv_t, pl_t, obs_t, ow_t, pair_cap=1e10)
+        if "_normals_parity_args" in tp:
+            tp["roofline_normals"]["parity"] = normals_parity(Xf, *tp.pop("_normals_parity_args"))
         out["throughput_point" if i == 0 else f"throughput_point_q{tp['correspondences']}"] = tp
     if world == 1 and not args.no_end_to_end:
         out["run_end_to_end"] = end_to_end(Xf, Xm, Q, k, kw)
@@ -498,6 +500,7 @@ def compact_line(out):
                        "iterations_per_s": float(f"{t['iterations_per_s']:.6g}"),
                        "correspondences_per_s": float(f"{t['correspondences_per_s']:.6g}"), "parallelism": t["parallelism"],
                        "roofline": strip(t["roofline"], 1),
+                       "roofline_normals": {kk: vv for kk, vv in strip(t["roofline_normals"], 1).items() if kk != "kernel_ms_all"},
                        "kernel_ms": {n: round(v["avg_ms"], 6) for n, v in t["kernels_instrumented"].items() if v["launches"]},
                        "evaluations_per_iteration": t["roofline_solver"].get("evaluations_per_iteration")}
             if "parity" in t:
@@ -511,7 +514,7 @@ def compact_line(out):
     if "cpu_reference" in line:
         line["cpu_reference"]["sample"] = out["cpu_reference"]["sample"][:100]
     line["config"]["workload"] = out["config"]["workload"]
-    line["detail"] = "unabridged record: --out FILE (committed examples: profiles/r3/bench_*.json)"
+    line["detail"] = "unabridged record: --out FILE (committed examples: profiles/r4/bench_*.json)"
     return line
 
 
@@ -588,6 +591,19 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
     ctx.timing_enable(False)
     rec = None if args.no_parity else parity_device(ctx, sel, normals, planarity, obs, ow, iterations=1)
     comm = comm_record(ctx, exchange, transport, True, world, Nm, nq, timing, args.steps)
+    # the one-off before the loop at this Q: estimate_normals again (grid resident), its kernels under HIP events, then once more
+    # with the sweep tallying its candidates
+    ctx.timing_enable(True)
+    nrm_ms = []
+    for _ in range(3):
+        ctx.timing_reset()
+        ctx.estimate_normals(_lib.FIX, sel, k)
+        nrm_ms.append(ctx.timing()["knnk_scan"]["ms"])
+    ctx.timing_enable(True, count_work=True)
+    ctx.timing_reset()
+    ctx.estimate_normals(_lib.FIX, sel, k)
+    knn_work = ctx.knn_work()
+    ctx.timing_enable(False)
     if rank != 0:
         return None
     avg = {name: v["ms"] / max(1, v["launches"]) for name, v in timing.items()}
@@ -632,12 +648,41 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
            "kernels_instrumented": {name: {"avg_ms": avg[name], "launches": timing[name]["launches"]} for name in timing},
            "setup": {"normals_ms": normals_ms},
            "solver": {"final_n_kept": int(last.n_kept), "final_res_std": last.res_std}}
+    # SURVEY 8(d), normals (one-off): bytes_alg = N_f * 3 * 8 + Q * (3 * 8 + k * 8 + 16); reported as Q * k neighbours / s as well
+    nms = float(np.median(nrm_ms))
+    rn = roof("k_grid_knn_sweep", nms, Nf * 24 + nq * (24 + k * 8 + 16),
+              "estimate_normals' kernels (k_grid_knn_sweep: one sweep over the ball's cells per query, survivors ranked in LDS, mean + "
+              "covariance from the coordinates it holds; k_cov_normals: Jacobi eigen-solver, one lane per query) on the resident grid; "
+              "bytes_alg is SURVEY 8(d)'s brute-force figure (the whole cloud once + per-query terms) -- the pruned search reads "
+              "`bytes_read_tallied` instead; VALU-issue-bound (~690 vector instructions per query)",
+              {"neighbours_per_s": nq * k / (nms * 1e-3) if nms > 0 else None,
+               "candidates_per_query": knn_work["candidates"] / nq, "sweeps_per_query": knn_work["sweeps"] / nq,
+               "queries_on_k_round_path": knn_work["slow_queries"],
+               "bytes_read_tallied": int(knn_work["candidates"] * 32 + nq * (24 + 48 + 16)), "kernel_ms_all": nrm_ms})
+    if rn["traffic"] is not None and pmc.get("k_cov_normals" + tag) is not None:
+        rn["traffic"] += pmc["k_cov_normals" + tag]               # both kernels of the call
+    if rn["traffic"] is not None and nms > 0:
+        rn["frac_on_pmc_traffic"] = rn["traffic"] / (nms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    out["roofline_normals"] = rn
+    if rec is not None:
+        out["_normals_parity_args"] = (sel, normals, planarity, k)
     if comm is not None:
         out["comm"] = comm
     if rec is not None:
         # the oracle leg runs on the host after every GPU leg is over (the other ranks must not wait in a collective for it)
         out["_parity_args"] = (rec, sel, normals, planarity, obs, ow)
     return out
+
+
+def normals_parity(Xf, sel, normals, planarity, k, sample=300):
+    """The device's normals on a sample of the queries against the oracle's brute-force k-NN + covariance + eigen step
+    (pointcloud.py:185-203): 1 ulp(f32) of a unit vector's component."""
+    from oracle import orc
+    pick = np.unique(np.round(np.linspace(0, len(sel) - 1, sample)).astype(np.int64))
+    onn, _ = orc.knn(Xf, Xf[sel[pick]], k=k)
+    onv, opl = orc.normals(Xf, onn)
+    dn, dp = float(np.abs(normals[pick] - onv).max()), float(np.abs(planarity[pick] - opl).max())
+    return {"ok": bool(dn <= 2e-7 and dp <= 2e-6), "queries_sampled": int(len(pick)), "max_abs_dnormal": dn, "max_abs_dplanarity": dp}
 
 
 def parity_device(ctx, sel, normals, planarity, obs, ow, iterations=2):

@@ -21,10 +21,13 @@ VARIANTS = {
     "rounds": {"SICP_KNN_SWEEP": "0"},
     "sweep": {},
     "sweep_b1": {"SICP_KNN_BATCH": "1"},
+    "sweep_b2": {"SICP_KNN_BATCH": "2"},
+    "sweep_b4": {"SICP_KNN_BATCH": "4"},
     "sweep_b8": {"SICP_KNN_BATCH": "8"},
     "sweep_b16": {"SICP_KNN_BATCH": "16"},
     "sweep_b32": {"SICP_KNN_BATCH": "32"},
     "sweep_unordered": {"SICP_ORDER_MIN_Q": "0"},
+    "sweep_unordered_b1": {"SICP_ORDER_MIN_Q": "0", "SICP_KNN_BATCH": "1"},
     "sweep_target8": {"SICP_GRID_TARGET": "8"},
     "sweep_target32": {"SICP_GRID_TARGET": "32"},
 }

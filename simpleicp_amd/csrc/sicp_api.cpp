@@ -271,6 +271,9 @@ struct sicp_ctx {
     long q_order_lo = -1, q_order_cnt = 0;
     long order_min_q = 32768;      // SICP_ORDER_MIN_Q: from this many queries per launch on (0: never)
     DevBuf<uint32_t> k_order;      // the queries of a k-NN / normals call in cell order
+    DevBuf<int64_t> k_sel;         // sicp_estimate_normals: selected rows, normals and planarity before they leave
+    DevBuf<float> k_nv, k_pl;
+    DevBuf<double> k_cov;          // (Q, 6) covariances between the k-NN sweep and the eigen step
     long knn_batch = 0;            // SICP_KNN_BATCH: queries a wave of the one-sweep k-NN works through (0: chosen per launch)
     bool knn_sweep = true;         // SICP_KNN_SWEEP=0: k extraction rounds (k_grid_knn) + k_normals instead of the one-sweep kernel
     DevBuf<double> bound_p2, bound_d2;   // cold search: nearest subsample point per query (coordinates = the bound) + scratch
@@ -733,7 +736,9 @@ int points_order_build(sicp_ctx *c, const double *qx, const double *qy, const do
             double d = std::floor(ex[a] / h) + 1.0;
             if (!(d >= 1.0)) d = 1.0;
             if (d > 1.0e6) d = 1.0e6;
-            G.dim[a] = (int)d; ncells *= (long)G.dim[a];
+            G.dim[a] = (int)d;
+            if (a < 2) G.dim[a] = (G.dim[a] + 7) & ~7;        // cells are numbered in 8 x 8 (x, y) tiles: k_cell_ids_tiled
+            ncells *= (long)G.dim[a];
             if (ncells > (1L << 40)) ncells = 1L << 40;
         }
         if (ncells <= max_cells) break;
@@ -746,7 +751,7 @@ int points_order_build(sicp_ctx *c, const double *qx, const double *qy, const do
     CHK(c->g_blk.reserve((size_t)grid_scan_blocks(ncells) + 1));
     CHK(order.reserve(cnt));
     HIPCHK(hipMemsetAsync(c->g_counts.p, 0, ((size_t)ncells + 1) * sizeof(uint32_t), c->stream));
-    launch_cell_ids(c->stream, qx, qy, qz, cnt, G, c->g_ids.p, c->g_counts.p, nullptr);
+    launch_cell_ids_tiled(c->stream, qx, qy, qz, cnt, G, c->g_ids.p, c->g_counts.p);
     launch_grid_scan(c->stream, c->g_counts.p, ncells, c->g_blk.p, nullptr, c->g_cursor.p);
     launch_scatter_order(c->stream, c->g_ids.p, cnt, c->g_cursor.p, order.p);
     HIPCHK(hipGetLastError());
@@ -956,9 +961,10 @@ int knnk_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, in
                 CHK(points_order_build(c, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, 2.0 * gr.g.h, 1L << 22, c->k_order));
                 order = c->k_order.p;
             }
+            if (normals_out) CHK(c->k_cov.reserve((size_t)6 * Q));
             Timed t(c, SICP_K_KNNK);
             launch_grid_knn_sweep(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, order, Q, k, gr.g, gr.avg_per_cell, gr.cell_start.p,
-                                  gr.rec.p, cl.rmax, cl.idx_base, d2_out, idx_out, normals_out, planarity_out,
+                                  gr.rec.p, cl.rmax, cl.idx_base, d2_out, idx_out, c->k_cov.p, normals_out, planarity_out,
                                   c->count_work ? c->match_work.p + 4 : nullptr, c->knn_batch);
             if (fused) *fused = normals_out != nullptr;
         } else {
@@ -1122,7 +1128,7 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     for (auto &p : c->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &cl : c->cloud) { cl.xyz.release(); cl.pl.release(); cl.grid.cell_start.release(); cl.grid.rec.release();
                                  cl.sub_xyz.release(); cl.sub_grid.cell_start.release(); cl.sub_grid.rec.release(); }
-    c->bound_p2.release(); c->bound_d2.release(); c->bound_idx.release(); c->q_order.release(); c->k_order.release(); c->g_ids.release(); c->g_counts.release(); c->g_cursor.release(); c->g_blk.release(); c->match_work.release(); c->rj_keys.release();
+    c->bound_p2.release(); c->bound_d2.release(); c->bound_idx.release(); c->q_order.release(); c->k_order.release(); c->k_sel.release(); c->k_nv.release(); c->k_pl.release(); c->k_cov.release(); c->g_ids.release(); c->g_counts.release(); c->g_cursor.release(); c->g_blk.release(); c->match_work.release(); c->rj_keys.release();
     c->stage.release(); c->part_d2.release(); c->part_idx.release(); c->kq.release(); c->k_d2.release();
     c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->hit_cnt.release(); c->hit_list.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();
@@ -1386,7 +1392,8 @@ SICP_EXPORT int sicp_estimate_normals(sicp_ctx *c, int slot, const int64_t *sel_
     const bool sweep = c->knn_sweep && knnk_uses_grid(c, cl, Q) && grid_knn_sweep_handles(k);
     const bool want_lists = !sweep || nn_idx_out;
     if (want_lists) { CHK(c->k_d2.reserve((size_t)Q * k)); CHK(c->k_idx.reserve((size_t)Q * k)); }
-    DevBuf<int64_t> sel; DevBuf<float> nv, pl;
+    // (scratch kept with the ctx: a hipMalloc / hipFree pair per call costs more than the kernels at Q = 1000)
+    DevBuf<int64_t> &sel = c->k_sel; DevBuf<float> &nv = c->k_nv, &pl = c->k_pl;
     int rc = sel.reserve(Q);
     if (rc == SICP_OK) rc = nv.reserve((size_t)3 * Q);
     if (rc == SICP_OK) rc = pl.reserve(Q);
@@ -1404,8 +1411,7 @@ SICP_EXPORT int sicp_estimate_normals(sicp_ctx *c, int slot, const int64_t *sel_
         return sync(c);
     };
     if (rc == SICP_OK) rc = body();
-    (void)hipStreamSynchronize(c->stream);
-    sel.release(); nv.release(); pl.release();
+    if (rc != SICP_OK) (void)hipStreamSynchronize(c->stream);
     return rc;
 }
 

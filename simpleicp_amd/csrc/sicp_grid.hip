@@ -134,6 +134,25 @@ __global__ __launch_bounds__(256) void k_cell_ids(const double *__restrict__ x, 
     }
 }
 
+// Cell ids for ORDERING queries (points_order_build): cells are numbered tile by tile -- 8 x 8 cells in (x, y) -- instead of row by
+// row, so that consecutive slots of the order cover a compact patch and not a strip one cell wide: the waves an XCD runs side by
+// side then share the rows their balls reach into (the halo of a 64-cell square is a sixth of it, of a strip more than half).
+// G.dim[0], G.dim[1] are multiples of 8 here.
+__global__ __launch_bounds__(256) void k_cell_ids_tiled(const double *__restrict__ x, const double *__restrict__ y,
+                                                        const double *__restrict__ z, long n, GridGeom G,
+                                                        uint32_t *__restrict__ ids, uint32_t *__restrict__ counts)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int cx = cell_coord(x[i], G.mn[0], G.inv_h, G.dim[0]);
+    const int cy = cell_coord(y[i], G.mn[1], G.inv_h, G.dim[1]);
+    const int cz = cell_coord(z[i], G.mn[2], G.inv_h, G.dim[2]);
+    const uint32_t tile = ((uint32_t)cz * (uint32_t)(G.dim[1] >> 3) + (uint32_t)(cy >> 3)) * (uint32_t)(G.dim[0] >> 3) + (uint32_t)(cx >> 3);
+    const uint32_t id = tile * 64u + (uint32_t)((cy & 7) * 8 + (cx & 7));
+    ids[i] = id;
+    atomicAdd(counts + id, 1u);
+}
+
 // Occupancy probe for the cell-size choice: histogram of the points of a SAMPLE (every `every`-th 1024-point chunk of
 // the cloud: coalesced, a fraction of the traffic) that fall inside a small window of the bounding box (G describes
 // the window's own grid); out[0] += sampled points inside, out[1] += cells that got a first point
@@ -852,10 +871,13 @@ __global__ __launch_bounds__(256) void k_grid_knn(
 //   * the neighbours' coordinates are still in LDS: six lanes form the mean and the six covariance sums in the oracle's
 //     operation order (orc_normals: sequential in rank order), nothing is gathered again and no index goes to memory unless
 //     the caller asked for it;
-//   * a wave works through `batch` queries that are neighbours in space (the caller hands the queries in cell order) -- the
-//     k-th distance of one is the next one's starting radius, their cells are in L1/L2 -- and parks query b's covariance in
-//     lane b; when the batch is through, the lanes run the Jacobi eigen-solver side by side (one lane at a time it would
-//     cost more than the search).
+//   * a wave works through `batch` queries that are neighbours in space (the caller hands the queries in cell order, tile by
+//     tile): their cells are in L1 / L2, and the k-th distances met so far (smoothed) set the next starting radius, so a cloud
+//     whose density varies does not pay shrinking or growing sweeps at every query;
+//   * the six covariance sums go to memory (48 B per query) and k_cov_normals runs the Jacobi eigen-solver with one lane per
+//     query: done by the one lane of the wave that holds a query's sums it would cost more than the search (measured: 3.4 ms per
+//     1 M queries against 1.8 ms for everything else), and batching it inside this kernel ties the batch size to it -- 64 queries
+//     per wave put 8 x the distinct cells in flight per XCD and doubled the HBM traffic (1.84 GB against 0.9 GB).
 // Same answers as k_grid_knn + k_normals, bit for bit (tests run both).
 // ------------------------------------------------------------------------------------
 struct KnnKey { double d2; uint32_t idx; uint32_t pad; };
@@ -869,7 +891,14 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 constexpr int KS_MAXK = 128;                // largest k of the sweep kernel (above: k_grid_knn + k_normals)
-__host__ __device__ constexpr int ks_wave_doubles(int cap) { return 5 * cap + KS_MAXK / 4; }    // keys 2, xyz 3 per slot; perm u16[128]
+// LDS of a wave, in doubles: keys 2 + coordinates 3 per survivor slot | the k winners' coordinates in rank order | the k-th distance
+__host__ __device__ constexpr int ks_wave_doubles(int cap, int kpad) { return 5 * cap + 3 * kpad + 2; }
+__device__ __forceinline__ double rdlane_f64(double v, int l)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 template <int NS /* survivor slots per lane: the LDS of a wave holds 64 * NS */>
 __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
@@ -878,16 +907,18 @@ __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
     const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
     long Q, int k, int batch, GridGeom G, double rmax, double r_first, int64_t idx_base,
     double *__restrict__ d2_out /* nullable */, int64_t *__restrict__ idx_out /* nullable */,
-    float *__restrict__ normals /* nullable: no covariance / eigen step */, float *__restrict__ planarity,
+    double *__restrict__ cov_out /* nullable: (Q, 6) by SLOT: upper triangle of every neighbourhood's sample covariance (NaN: fewer than k points) */,
     unsigned long long *__restrict__ work /* nullable: [0] candidates read, [1] sweeps, [2] queries on the k-round path, [3] survivors */)
 {
     constexpr int CAP = 64 * NS;
     extern __shared__ double ks_lds[];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double *wbase = ks_lds + (size_t)wid * ks_wave_doubles(CAP);
+    const int kpad = (k + 7) & ~7;
+    double *wbase = ks_lds + (size_t)wid * ks_wave_doubles(CAP, kpad);
     KnnKey *keys = (KnnKey *)wbase;
     double *xyz = wbase + 2 * CAP;
-    uint16_t *perm = (uint16_t *)(wbase + 5 * CAP);
+    double *nbr = wbase + 5 * CAP;                    // [k][3]
+    double *dk_slot = nbr + 3 * kpad;
 
     long blk = blockIdx.x;
     if (order) blk = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);       // one contiguous eighth per XCD
@@ -896,20 +927,21 @@ __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
     const int nb = (int)((Q - slot0 < (long)batch) ? (Q - slot0) : (long)batch);
     uint32_t my_q = 0;
     if (lane < nb) my_q = order ? order[slot0 + lane] : (uint32_t)(slot0 + lane);
-    double cov[6] = {0, 0, 0, 0, 0, 0};
-    bool my_ok = false;
+    const double inv_km1 = 1.0 / (double)(k - 1);
     unsigned long long n_cand = 0, n_sweeps = 0, n_slow = 0, n_surv = 0;
     const double etol = 1e-6 * G.h;
-    double r_carry = r_first;
+    // squared k-th distance the next starting radius is derived from: the caller's estimate (cell occupancy) until the data says otherwise
+    double dk_est = (r_first * r_first) * (1.0 / (1.35 * 1.35));
 
     for (int b = 0; b < nb; ++b) {
         const long q = (long)(uint32_t)__builtin_amdgcn_readlane((int)my_q, b);
         const double ax = qx[q], ay = qy[q], az = qz[q];
-        const double scale = rmax + sqrt(fma(az, az, fma(ay, ay, ax * ax))) + 1.0;
+        const double scale = rmax + (fabs(ax) + fabs(ay) + fabs(az)) + 1.0;       // (1-norm: an upper bound of |q| is all the slack needs)
         const double slack = 1e-12 * scale;
         const double c3[3] = {ax, ay, az};
-        double r = r_carry;
-        int shrinks = 0;
+        double r = (double)(1.35f * sqrtf((float)dk_est)) + slack;       // (a starting radius: any value is correct)
+        if (!(r >= 0.25 * r_first)) r = 0.25 * r_first;                   // (coincident points: never start at zero)
+        int shrinks = 0, sweeps = 0;
         int kk = 0;                                   // neighbours found (k, or every point of the cloud if it holds fewer)
         for (int pass = 0; pass < 4096; ++pass) {
             int lo[3], hi[3];
@@ -925,16 +957,24 @@ __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
             const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
             const long nrows = (long)ny * nz;
             // a candidate at d2 <= thr lies inside the ball with room for every rounding: no point of a culled cell ties or beats it
-            const double r_eff = (r - slack) / (1.0 + 1e-12);
+            const double r_eff = (r - slack) * (1.0 - 1.5e-12);       // (<= (r - slack) / (1 + 1e-12), without the division)
             const double thr = all ? __builtin_inf() : (r_eff > 0.0 ? r_eff * r_eff : -1.0);
             const double r2 = r * r;
             unsigned ns = 0;                          // survivors so far (wave-uniform)
-            n_sweeps += 1;
-            for (long rb = 0; rb < nrows; rb += 64) {
+            n_sweeps += 1; ++sweeps;
+            // (a ball spans a handful of rows: lane (y + 8 z) takes row (y, z) -- no division; wider balls enumerate their rows in full)
+            const bool few = ny <= 8 && nz <= 8;
+            for (long rb = 0; rb < (few ? 1L : nrows); rb += 64) {
                 uint32_t rbeg = 0, rlen = 0;
-                if (rb + lane < nrows) {
-                    const long rr = rb + lane;
-                    const int cy = lo[1] + (int)(rr % ny), cz = lo[2] + (int)(rr / ny);
+                int oy = lane & 7, oz = lane >> 3;
+                bool have = oy < ny && oz < nz;
+                if (!few) {
+                    const unsigned rr = (unsigned)(rb + lane);            // (nrows < 2^31: the cell table holds at most 2^27 cells)
+                    have = rb + lane < nrows;
+                    oz = (int)(rr / (unsigned)ny); oy = (int)(rr - (unsigned)oz * (unsigned)ny);
+                }
+                if (have) {
+                    const int cy = lo[1] + oy, cz = lo[2] + oz;
                     const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
                     int xl = lo[0], xh = hi[0];
                     if (!all) {
@@ -1013,11 +1053,13 @@ __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
                 r *= f < 1.25 ? 1.25 : (f > 2.0 ? 2.0 : f);
                 continue;
             }
+            ns = (unsigned)__builtin_amdgcn_readfirstlane((int)ns);       // (wave-uniform by construction: tell the compiler)
             n_surv += ns;
             kk = ns < (unsigned)k ? (int)ns : k;
             if (ns <= (unsigned)CAP) {
                 // ---- rank by counting: survivor e's rank = number of survivors below it on (d2, index) ----
                 wave_lds_sync();
+                const int slots = ns <= 64u ? 1 : NS;  // (nearly always one survivor per lane at most)
                 double md[NS]; uint32_t mi[NS]; unsigned rk[NS];
 #pragma unroll
                 for (int t = 0; t < NS; ++t) {
@@ -1027,18 +1069,27 @@ __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
                     mi[t] = has ? keys[e].idx : 0xffffffffu;
                     rk[t] = 0;
                 }
-                for (unsigned j = 0; j < ns; ++j) {
-                    const double od = keys[j].d2; const uint32_t oi = keys[j].idx;        // (same address in every lane: a broadcast)
+                if (slots == 1) {
+                    for (unsigned j = 0; j < ns; ++j) {
+                        const double od = keys[j].d2; const uint32_t oi = keys[j].idx;    // (same address in every lane: a broadcast)
+                        rk[0] += (unsigned)((od < md[0]) | ((od == md[0]) & (oi < mi[0])));
+                    }
+                } else {
+                    for (unsigned j = 0; j < ns; ++j) {
+                        const double od = keys[j].d2; const uint32_t oi = keys[j].idx;
 #pragma unroll
-                    for (int t = 0; t < NS; ++t) rk[t] += (od < md[t] || (od == md[t] && oi < mi[t])) ? 1u : 0u;
+                        for (int t = 0; t < NS; ++t) rk[t] += (unsigned)((od < md[t]) | ((od == md[t]) & (oi < mi[t])));
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < NS; ++t) {
                     const unsigned e = (unsigned)lane + 64u * t;
-                    if (e < ns && rk[t] < (unsigned)k) {
-                        perm[rk[t]] = (uint16_t)e;
-                        if (idx_out) idx_out[q * k + rk[t]] = idx_base + (int64_t)mi[t];
-                        if (d2_out) d2_out[q * k + rk[t]] = md[t];
+                    if (t < slots && e < ns && rk[t] < (unsigned)k) {
+                        const unsigned rr = rk[t];
+                        nbr[3 * rr] = xyz[3 * e]; nbr[3 * rr + 1] = xyz[3 * e + 1]; nbr[3 * rr + 2] = xyz[3 * e + 2];
+                        if (rr == (unsigned)(k - 1)) *dk_slot = md[t];
+                        if (idx_out) idx_out[q * k + rr] = idx_base + (int64_t)mi[t];
+                        if (d2_out) d2_out[q * k + rr] = md[t];
                     }
                 }
             } else {
@@ -1076,9 +1127,8 @@ __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
                     if (lane == 0) {
                         if (idx_out) idx_out[q * k + j] = idx_base + (int64_t)bidx;
                         if (d2_out) d2_out[q * k + j] = best;
-                        keys[j].d2 = best; keys[j].idx = bidx;
-                        xyz[3 * j] = W.x; xyz[3 * j + 1] = W.y; xyz[3 * j + 2] = W.z;
-                        perm[j] = (uint16_t)j;
+                        nbr[3 * j] = W.x; nbr[3 * j + 1] = W.y; nbr[3 * j + 2] = W.z;
+                        if (j == k - 1) *dk_slot = best;
                     }
                     fd = best; fi = bidx; first = false; kk = j + 1;
                 }
@@ -1091,45 +1141,57 @@ __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
             if (d2_out) d2_out[q * k + j] = __builtin_inf();
         }
         wave_lds_sync();
-        // the next query of the batch is a neighbour in space: start from this one's k-th distance
+        // the next query of the batch is a neighbour in space: its radius follows the k-th distances met so far (one k-th distance
+        // alone scatters by a third; a query that had to resize its ball resets the estimate)
         if (kk == k) {
-            const double dk = keys[perm[k - 1]].d2;
-            const double rn = 1.35 * sqrt(dk) + slack;
-            r_carry = rn > 0.25 * r_first ? rn : 0.25 * r_first;
+            const double dk = *dk_slot;
+            dk_est = sweeps > 1 ? dk : 0.75 * dk_est + 0.25 * dk;
         }
-        if (normals) {
+        if (cov_out) {
             // mean and covariance sums in rank order, one sum per lane (orc_normals' operation order: pointcloud.py:188-190)
-            double cv = 0.0;
-            if (lane < 6 && kk == k) {
-                const int a = lane < 3 ? 0 : (lane < 5 ? 1 : 2);
-                const int c = lane < 3 ? lane : (lane < 5 ? lane - 2 : 2);
-                double ma = 0.0, mc = 0.0;
-                for (int s = 0; s < k; ++s) { const int e = perm[s]; ma += xyz[3 * e + a]; mc += xyz[3 * e + c]; }
-                ma /= (double)k; mc /= (double)k;
-                for (int s = 0; s < k; ++s) { const int e = perm[s]; cv = fma(xyz[3 * e + a] - ma, xyz[3 * e + c] - mc, cv); }
-                cv *= 1.0 / (double)(k - 1);
+            double mean = 0.0;
+            if (lane < 3 && kk == k) {
+                for (int s = 0; s < k; ++s) mean += nbr[3 * s + lane];
+                mean /= (double)k;
             }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(cv);
-                const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, i);
-                const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), i);
-                if (lane == b) cov[i] = __longlong_as_double((long long)(((unsigned long long)hi32 << 32) | lo32));
+            const double m0 = rdlane_f64(mean, 0), m1 = rdlane_f64(mean, 1), m2 = rdlane_f64(mean, 2);
+            if (lane < 6) {
+                double cv = 0.0;
+                if (kk == k) {
+                    const int a = lane < 3 ? 0 : (lane < 5 ? 1 : 2);
+                    const int c = lane < 3 ? lane : (lane < 5 ? lane - 2 : 2);
+                    const double ma = a == 0 ? m0 : (a == 1 ? m1 : m2), mc = c == 0 ? m0 : (c == 1 ? m1 : m2);
+                    for (int s = 0; s < k; ++s) cv = fma(nbr[3 * s + a] - ma, nbr[3 * s + c] - mc, cv);
+                    cv *= inv_km1;
+                } else {
+                    cv = __builtin_nan("");
+                }
+                cov_out[6 * (slot0 + b) + lane] = cv;                  // (by SLOT: consecutive queries of the order write consecutive rows)
             }
-            if (lane == b) my_ok = kk == k;
         }
         wave_lds_sync();                              // (the next sweep overwrites the survivors)
-    }
-    if (normals && lane < nb) {
-        float nrm[3] = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")}, pl = __builtin_nanf("");
-        if (my_ok) normal_from_cov(cov, nrm, &pl);
-        normals[3 * (long)my_q] = nrm[0]; normals[3 * (long)my_q + 1] = nrm[1]; normals[3 * (long)my_q + 2] = nrm[2];
-        planarity[my_q] = pl;
     }
     if (work) {
         n_cand = wsum_u64(n_cand);
         if (lane == 0) { atomicAdd(work, n_cand); atomicAdd(work + 1, n_sweeps); atomicAdd(work + 2, n_slow); atomicAdd(work + 3, n_surv); }
     }
+}
+
+// covariance -> normal + planarity (pointcloud.py:192-203), one lane per query
+__global__ __launch_bounds__(64) void k_cov_normals(const double *__restrict__ cov /* by slot of the order */,
+                                                    const uint32_t *__restrict__ order /* nullable: slot = query */, long Q,
+                                                    float *__restrict__ normals, float *__restrict__ planarity)
+{
+    const long slot = (long)blockIdx.x * 64 + threadIdx.x;
+    if (slot >= Q) return;
+    const long q = order ? (long)order[slot] : slot;
+    double c6[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c6[i] = cov[6 * slot + i];
+    float nrm[3] = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")}, pl = __builtin_nanf("");
+    if (c6[0] == c6[0]) normal_from_cov(c6, nrm, &pl);                       // (NaN: a cloud with fewer than k points)
+    normals[3 * q] = nrm[0]; normals[3 * q + 1] = nrm[1]; normals[3 * q + 2] = nrm[2];
+    planarity[q] = pl;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1746,6 +1808,12 @@ void launch_cell_ids(hipStream_t s, const double *x, const double *y, const doub
     else hipLaunchKernelGGL(k_cell_ids<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, n, G, ids, counts, occupied);
 }
 
+void launch_cell_ids_tiled(hipStream_t s, const double *x, const double *y, const double *z, long n, const GridGeom &G,
+                           uint32_t *ids, uint32_t *counts)
+{
+    hipLaunchKernelGGL(k_cell_ids_tiled, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, n, G, ids, counts);
+}
+
 void launch_window_probe(hipStream_t s, const double *x, const double *y, const double *z, long n, long every, const GridGeom &Gw,
                          const double wmax[3], uint32_t *counts, unsigned long long *out2)
 {
@@ -1842,29 +1910,32 @@ void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const do
 
 bool grid_knn_sweep_handles(int k) { return k >= 1 && k <= KS_MAXK; }
 
-// the one-sweep k-NN (k <= KS_MAXK), with covariance + eigen-decomposition when `normals` is given.  avg_per_cell: points per
-// occupied cell of the grid (sets the first radius: a ball that is expected to hold ~1.8 k points of a surface)
+// the one-sweep k-NN (k <= KS_MAXK); with `cov` ((Q, 6) doubles of scratch) also covariance + eigen-decomposition -> normals,
+// planarity.  avg_per_cell: points per occupied cell of the grid (sets the first radius: a ball that is expected to hold ~1.8 k
+// points of a surface)
 void launch_grid_knn_sweep(hipStream_t s, const double *qx, const double *qy, const double *qz, const uint32_t *order, long Q, int k,
                            const GridGeom &G, double avg_per_cell, const uint32_t *cell_start, const void *rec, double rmax,
-                           int64_t idx_base, double *d2_out, int64_t *idx_out, float *normals, float *planarity,
+                           int64_t idx_base, double *d2_out, int64_t *idx_out, double *cov, float *normals, float *planarity,
                            unsigned long long *work, long batch_override)
 {
-    // enough waves to fill the machine several times over before a wave takes more than one query (8192 waves: 8 per SIMD)
-    long batch = batch_override > 0 ? batch_override : Q / 8192;
+    // a wave stays with a neighbourhood for a few queries once there are enough waves to fill the machine several times over
+    long batch = batch_override > 0 ? batch_override : (Q >= 131072 ? 8 : (Q >= 32768 ? 4 : 1));
     batch = batch < 1 ? 1 : (batch > 64 ? 64 : batch);
     const double ppc = avg_per_cell >= 1.0 ? avg_per_cell : 1.0;
     double r_first = 1.35 * G.h * std::sqrt((double)k / (3.141592653589793 * ppc));
     if (!(r_first > 0.0) || !std::isfinite(r_first)) r_first = G.h;
     unsigned g = cdiv(Q, 4 * batch);
     if (order) g = (g + 7u) & ~7u;
+    const int kpad = (k + 7) & ~7;
+    double *cov_out = normals ? cov : nullptr;
 #define SICP_KS_LAUNCH(NS)                                                                                                     \
-    hipLaunchKernelGGL((k_grid_knn_sweep<NS>), dim3(g), dim3(256), 4 * ks_wave_doubles(64 * NS) * sizeof(double), s, qx, qy, qz, order, \
-                       cell_start, (const double4 *)rec, Q, k, (int)batch, G, rmax, r_first, idx_base, d2_out, idx_out, normals,  \
-                       planarity, work)
+    hipLaunchKernelGGL((k_grid_knn_sweep<NS>), dim3(g), dim3(256), 4 * ks_wave_doubles(64 * NS, kpad) * sizeof(double), s, qx, qy, qz, order, \
+                       cell_start, (const double4 *)rec, Q, k, (int)batch, G, rmax, r_first, idx_base, d2_out, idx_out, cov_out, work)
     if (k <= 32) SICP_KS_LAUNCH(2);
     else if (k <= 64) SICP_KS_LAUNCH(4);
     else SICP_KS_LAUNCH(8);
 #undef SICP_KS_LAUNCH
+    if (cov_out) hipLaunchKernelGGL(k_cov_normals, dim3(cdiv(Q, 64)), dim3(64), 0, s, (const double *)cov_out, order, Q, normals, planarity);
 }
 
 }  // namespace sicp

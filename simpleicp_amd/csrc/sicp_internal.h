@@ -101,6 +101,8 @@ struct GridGeom { double mn[3]; double h, inv_h; int dim[3]; };
 void launch_cloud_stats(hipStream_t s, const double *x, const double *y, const double *z, long n, unsigned long long *out7);
 void launch_cell_ids(hipStream_t s, const double *x, const double *y, const double *z, long n, const GridGeom &G,
                      uint32_t *ids, uint32_t *counts, unsigned long long *occupied);
+void launch_cell_ids_tiled(hipStream_t s, const double *x, const double *y, const double *z, long n, const GridGeom &G,
+                           uint32_t *ids, uint32_t *counts);       // G.dim[0], G.dim[1]: multiples of 8
 void launch_window_probe(hipStream_t s, const double *x, const double *y, const double *z, long n, long every, const GridGeom &Gw,
                          const double wmax[3], uint32_t *counts, unsigned long long *out2);
 long grid_scan_blocks(long n);
@@ -126,8 +128,8 @@ void launch_grid_knn(hipStream_t s, const double *qx, const double *qy, const do
 bool grid_knn_sweep_handles(int k);
 void launch_grid_knn_sweep(hipStream_t s, const double *qx, const double *qy, const double *qz, const uint32_t *order, long Q, int k,
                            const GridGeom &G, double avg_per_cell, const uint32_t *cell_start, const void *rec, double rmax,
-                           int64_t idx_base, double *d2_out, int64_t *idx_out, float *normals, float *planarity,
-                           unsigned long long *work, long batch_override = 0);
+                           int64_t idx_base, double *d2_out, int64_t *idx_out, double *cov /* (Q, 6) scratch when normals are asked for */,
+                           float *normals, float *planarity, unsigned long long *work, long batch_override = 0);
 
 void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec);
 void launch_pack_idx(hipStream_t s, const int64_t *idx, long cnt, long per, double *out);

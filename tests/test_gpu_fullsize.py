@@ -292,7 +292,7 @@ def test_large_q_iterations_equal_oracle_at_full_size(data, big_q):
 
 def test_normals_at_one_million_queries_equal_oracle(data, big_q):
     """estimate_normals at Q = 1 M on 10 M points (pointcloud.py:173-203; C5-class Q): the one-sweep k-NN + covariance kernel with
-    64 cell-ordered queries per wave.  A 3 000-query sample against the oracle's brute-force k-NN over the whole cloud -- indices
+    a few cell-ordered queries per wave.  A 3 000-query sample against the oracle's brute-force k-NN over the whole cloud -- indices
     bit for bit incl. their (d2, idx) order -- and the normals / planarity the kernel formed WITHOUT writing those lists
     against the oracle's covariance + eigen step on them (float32 store, 1 ulp of a unit vector's component)."""
     from simpleicp_amd import _lib
