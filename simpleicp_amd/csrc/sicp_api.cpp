@@ -301,6 +301,7 @@ struct sicp_ctx {
     double last_ne[30] = {0};      // normal equations at last_x (fused path caches them)
     bool have_last_ne = false;
     int solve_mode = 0;            // SICP_SOLVE = fused | host (A/B + tests); 0 = auto
+    bool grid_target_forced = false;   // SICP_GRID_TARGET given: every grid uses it
     double grid_target = 16.0;     // points per occupied grid cell the cell size aims at (SICP_GRID_TARGET overrides;
                                    // measured flat from 12 to 32, 5-20 % slower below 8: fewer, longer rows win)
     bool host_trace = false;       // SICP_HOST_TRACE: per-iteration host timings on stderr
@@ -578,12 +579,18 @@ double key_to_double(unsigned long long k)
 }
 
 // bins the cloud of `slot` once (own frame); see sicp_grid.hip
-int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const double *Y, const double *Z, long n, Grid &gr);
+int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const double *Y, const double *Z, long n, Grid &gr, double target = 0.0);
 
 int grid_build(sicp_ctx *c, int slot)
 {
     Cloud &cl = c->cloud[slot];
-    return grid_build_arrays(c, cl, cl.x(), cl.y(), cl.z(), cl.n, cl.grid);
+    // Points per occupied cell.  Large query sets pay for candidates (the machine is full: 1 M queries in 10 M points take 0.61 ms
+    // per match at 16 per cell, 0.51 at 8, 0.62 at 4), the one-wave-per-query search of a few queries pays for round trips
+    // and likes its rows long -- so the movable cloud of a run with many correspondences is binned finer.  (Decided when the grid
+    // is first needed: a grid that exists is kept.)
+    double target = c->grid_target;
+    if (!c->grid_target_forced && slot == SICP_MOV && c->Q >= c->nn16_min_q && c->nn16_min_q > 0) target = 0.5 * target;
+    return grid_build_arrays(c, cl, cl.x(), cl.y(), cl.z(), cl.n, cl.grid, target);
 }
 
 // the cloud's subsample (every SUB_STRIDE-th point) and its grid
@@ -601,7 +608,7 @@ int subsample_build(sicp_ctx *c, int slot)
 }
 
 // bins n points (columns X, Y, Z, inside cl's bounding box) once; see sicp_grid.hip
-int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const double *Y, const double *Z, long n, Grid &gr)
+int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const double *Y, const double *Z, long n, Grid &gr, double target_in)
 {
     if (gr.valid) return SICP_OK;
     gr.cap_limited = false;
@@ -612,8 +619,12 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
         if (!(ex[a] >= 0) || !std::isfinite(ex[a])) return fail(SICP_ERR_INVALID, "cloud has non-finite coordinates");
         if (ex[a] > 0) { vol *= ex[a]; ++deff; }
     }
-    const double target = c->grid_target;            // points per occupied cell
-    const long cap = 1L << 27;                       // dense cell array cap (512 MiB of offsets)
+    const double target = target_in > 0.0 ? target_in : c->grid_target;       // points per occupied cell
+    // Dense cell array cap: 2^27 cells (512 MiB of offsets), more for clouds that are worth it -- the box of a 100 M-point SURFACE
+    // is mostly empty layers, and at 2^27 cells its occupied ones held 25 points (128 candidates per 1-NN query where 10 M points
+    // pay 48): six cells per point, at most 2^30 (4 GiB of offsets + as much again of build scratch, on a 288 GB device).
+    long cap = 1L << 27;
+    if (6 * n > cap) cap = std::min<long>(6 * n, 1L << 30);
     double h = deff ? std::pow(vol * target / (double)n, 1.0 / deff) : 1.0;
     if (!(h > 0) || !std::isfinite(h)) h = 1.0;
     unsigned long long *d_cnt = (unsigned long long *)(c->small.p + 54);      // 2 u64
@@ -1108,7 +1119,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
     if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : !std::strcmp(e, "mfma") ? 2 : 0;
     if (const char *e = std::getenv("SICP_FSCAN_CAP")) c->fscan_cap = std::atol(e);
-    if (const char *e = std::getenv("SICP_GRID_TARGET")) { const double t = std::atof(e); if (t >= 0.25 && t <= 1024) c->grid_target = t; }
+    if (const char *e = std::getenv("SICP_GRID_TARGET")) { const double t = std::atof(e); if (t >= 0.25 && t <= 1024) { c->grid_target = t; c->grid_target_forced = true; } }
     c->host_trace = std::getenv("SICP_HOST_TRACE") != nullptr;
     c->solve_trace = std::getenv("SICP_SOLVE_TRACE") != nullptr;
     if (const char *e = std::getenv("SICP_SOLVE")) c->solve_mode = !std::strcmp(e, "fused") ? 1 : !std::strcmp(e, "host") ? 2 : 0;

@@ -291,6 +291,21 @@ __device__ __forceinline__ void xf(const Xf &H, double x, double y, double z, do
     t = H.m[8] * x;  t = fma(H.m[9], y, t);  t = fma(H.m[10], z, t);  oz = t + H.m[11];
 }
 
+// row rr of a ny-wide block of grid rows -> (rr % ny, rr / ny) without the 64-bit integer division the plain expressions compile
+// to (~150 instructions per lane and pass: a tenth of the four-queries-per-wave search's issue budget).  Exact for rr < 2^22
+// (float quotient within one of the truth, then corrected); balls with more rows take the division.
+__device__ __forceinline__ void row_split(long rr, int ny, float inv_ny, bool small, int &oy, int &oz)
+{
+    if (small) {
+        unsigned q = (unsigned)(((float)(unsigned)rr + 0.5f) * inv_ny);
+        int r = (int)(unsigned)rr - (int)(q * (unsigned)ny);
+        if (r < 0) { q -= 1u; r += ny; } else if (r >= ny) { q += 1u; r -= ny; }
+        oy = r; oz = (int)q;
+    } else {
+        oy = (int)(rr % ny); oz = (int)(rr / ny);
+    }
+}
+
 // What k_postmatch computes (sicp_kernels.hip), by the lane that holds the winner: signed point-to-plane distance of the matched
 // point under H, contract (P), and the planarity verdict of both clouds -- the same expressions, so the same bits.
 __device__ __forceinline__ void post_match(const PostMatch &post, const Xf &H, long q, int64_t m, double px, double py, double pz,
@@ -423,12 +438,16 @@ __global__ __launch_bounds__(256) void k_grid_nn(
         // ends the search whatever it finds -- then every row is taken in full.)
         const double r2 = r * r, etol = 1e-6 * G.h;
         double cull2 = __builtin_inf();                           // rows farther than this cannot hold the answer (set by hits)
+        const float inv_ny = 1.0f / (float)ny;
+        const bool few_rows = nrows < (1L << 22);
         for (long rb = 0; rb < nrows; rb += 64) {
             uint32_t b = 0, len = 0;
             double lb2 = __builtin_inf();
             if (rb + lane < nrows) {
                 const long rr = rb + lane;
-                const int cy = lo[1] + (int)(rr % ny), cz = lo[2] + (int)(rr / ny);
+                int oy, oz;
+                row_split(rr, ny, inv_ny, few_rows, oy, oz);
+                const int cy = lo[1] + oy, cz = lo[2] + oz;
                 const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
                 int xl = lo[0], xh = hi[0];
                 lb2 = 0.0;
@@ -639,9 +658,13 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
         // the ball, not its bounding cube (see k_grid_nn); once a hit bounds the answer the ball is the hit's, not the pass's
         const double r2 = r * r, etol = 1e-6 * G.h;
         double cull2 = __builtin_inf();
+        const float inv_ny = 1.0f / (float)ny;
+        const bool few_rows = nrows < (1L << 22);
         auto row_range = [&](long rr, uint32_t &b, uint32_t &len, double &lb2) {
             b = 0; len = 0;
-            const int cy = lo[1] + (int)(rr % ny), cz = lo[2] + (int)(rr / ny);
+            int oy, oz;
+            row_split(rr, ny, inv_ny, few_rows, oy, oz);
+            const int cy = lo[1] + oy, cz = lo[2] + oz;
             const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
             int xl = lo[0], xh = hi[0];
             lb2 = 0.0;
@@ -969,9 +992,8 @@ __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
                 int oy = lane & 7, oz = lane >> 3;
                 bool have = oy < ny && oz < nz;
                 if (!few) {
-                    const unsigned rr = (unsigned)(rb + lane);            // (nrows < 2^31: the cell table holds at most 2^27 cells)
                     have = rb + lane < nrows;
-                    oz = (int)(rr / (unsigned)ny); oy = (int)(rr - (unsigned)oz * (unsigned)ny);
+                    row_split(rb + lane, ny, 1.0f / (float)ny, nrows < (1L << 22), oy, oz);
                 }
                 if (have) {
                     const int cy = lo[1] + oy, cz = lo[2] + oz;
