@@ -436,6 +436,7 @@ class Context:
         self._chk(self._L.sicp_comm_init(self._h, C.c_char_p(bytes(unique_id)), int(rank), int(world), int(bool(gn_shard))))
 
     def comm_destroy(self):
+        self._comm_key = self._comm_group = None          # (dist.attach's note of a parked communicator: there is none any more)
         self._chk(self._L.sicp_comm_destroy(self._h))
 
     def comm_activate(self, on=True, gn_shard=False):

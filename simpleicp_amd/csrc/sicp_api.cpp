@@ -319,6 +319,7 @@ struct sicp_ctx {
     unsigned long long lm_bar = 0;     // what its launches have added to the counter so far
     bool lm_one_launch = true;         // SICP_LM=launches: one launch per evaluation + finish (A/B; always with a sharded reduction)
     unsigned long long hsel_bar = 0;   // what the one-launch rejection's launches have added to its barrier counter so far
+    int test_barrier_fault = 0;    // SICP_TEST_BARRIER_FAULT = 1 / 2 (tests only): the rejection's / the solver's grid barrier expects a block that never comes
     bool hsel_one_launch = true;   // SICP_HSEL=launches: the launch-per-phase form (A/B)
     bool hsel_dirty = false;
     int nn_group = 0;              // SICP_NN_GROUP=8|16: lanes per query of the many-queries search (0: chosen per launch)
@@ -380,6 +381,33 @@ void collect_ready(sicp_ctx *c)
 // Kernels that hand a few doubles to the host write them into pinned + mapped memory and then publish a
 // sequence number there: polling that word sees the result a few microseconds before the end-of-kernel
 // signal and spares a copy + hipStreamSynchronize per hand-over.  Falls back to a stream wait.
+// An exchange that will never complete (a rank left the job, the ranks' collectives went out of step): give the communicator up,
+// so that the collective -- and every chained kernel queued behind it on the ctx's stream -- ends instead of wedging each later
+// hipStreamSynchronize (sicp_comm_destroy, sicp_ctx_destroy and sicp_icp_get_state all start with one).  ncclCommAbort makes the
+// in-flight collective return; kernels behind it then run on garbage and finish.  Should the stream still not drain (a callback
+// exchange: its collective is torch's, not ours to abort), the ctx moves to a fresh stream and the wedged one is left behind.
+void abandon_exchange(sicp_ctx *c)
+{
+    if (c->comm) { (void)rccl()->CommAbort(c->comm); c->comm = nullptr; }
+    c->comm_active = false;
+    c->xfn = nullptr; c->xuser = nullptr;
+    c->rank = 0; c->world = 1; c->gn_shard = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool drained = false;
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 5.0) {
+        if (hipStreamQuery(c->stream) != hipErrorNotReady) { drained = true; break; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    (void)hipGetLastError();
+    if (!drained) {
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) c->stream = fresh;    // (the old one is leaked on purpose)
+        c->pending.clear();                                   // their events sit on the abandoned stream
+    }
+    c->have_iter = false; c->have_corr = false; c->have_prev_match = false;
+    c->hsel_dirty = true;                                     // whatever the interrupted launches left in the selection state
+}
+
 int wait_ticket(sicp_ctx *c, const double *flag_word, double seq)
 {
     volatile const double *flag = flag_word;
@@ -397,10 +425,14 @@ int wait_ticket(sicp_ctx *c, const double *flag_word, double seq)
             const hipError_t q = hipStreamQuery(c->stream);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) return fail(SICP_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(q));
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->xchg_timeout_s)
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->xchg_timeout_s) {
+                const int rank = c->rank, world = c->world;
+                abandon_exchange(c);
                 return fail(SICP_ERR_EXCHANGE, "no result after %.0f s with a multi-GPU exchange in flight (rank %d of %d): a rank left "
-                                               "the job or the ranks' collectives are out of step (SICP_XCHG_TIMEOUT_S)",
-                            c->xchg_timeout_s, c->rank, c->world);
+                                               "the job or the ranks' collectives are out of step (SICP_XCHG_TIMEOUT_S); the "
+                                               "communicator was aborted, the context is single-GPU again",
+                            c->xchg_timeout_s, rank, world);
+            }
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -536,7 +568,7 @@ int reject_select(sicp_ctx *c, long Q, double *host_out, double seq, const IcpDe
             c->hsel_bar = 0; c->hsel_dirty = false;
         }
         e = reject_by_select_one_launch(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
-                                        &c->hsel_bar, c->ne_partial.p, host_out, seq, st);
+                                        &c->hsel_bar, c->ne_partial.p, host_out, seq, st, c->test_barrier_fault == 1 ? 1u : 0u);
     } else {
         c->hsel_dirty = true;
         e = reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
@@ -544,6 +576,23 @@ int reject_select(sicp_ctx *c, long Q, double *host_out, double seq, const IcpDe
     }
     if (e != hipSuccess) return fail(SICP_ERR_HIP, "rejection by digit selection failed: %s", hipGetErrorString(e));
     return SICP_OK;
+}
+
+// the grid barriers' state (arrival counters, generation, error word) of both one-launch kernels, as new
+int reset_barrier_state(sicp_ctx *c)
+{
+    if (c->rj_keys.p) { HIPCHK(hsel_state_init(c->stream, c->rj_keys.p)); c->hsel_bar = 0; c->hsel_dirty = false; }
+    if (c->lm_bar_buf.p) { HIPCHK(hipMemsetAsync(c->lm_bar_buf.p, 0, lm_bar_bytes(), c->stream)); c->lm_bar = 0; }
+    return sync(c);
+}
+
+// a host-read rejection whose launch could not meet itself at a grid barrier (k_hsel_all reports a negative count)
+int barrier_timed_out(sicp_ctx *c)
+{
+    (void)hipStreamSynchronize(c->stream);
+    CHK(reset_barrier_state(c));
+    return fail(SICP_ERR_HIP, "a device-wide barrier of the rejection timed out (blocks not co-resident: is another process using the "
+                              "GPU?); the barrier state was reset");
 }
 
 int check_slot(sicp_ctx *c, int slot, bool need_data)
@@ -1112,6 +1161,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_COARSE_ITERS")) c->coarse_iters = std::atoi(e);
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
     if (const char *e = std::getenv("SICP_LM")) c->lm_one_launch = std::strcmp(e, "launches") != 0;
+    if (const char *e = std::getenv("SICP_TEST_BARRIER_FAULT")) c->test_barrier_fault = std::atoi(e);
     if (const char *e = std::getenv("SICP_HSEL")) c->hsel_one_launch = std::strcmp(e, "launches") != 0;
     if (const char *e = std::getenv("SICP_NN_GROUP")) { const int v = std::atoi(e); if (v == 8 || v == 16) c->nn_group = v; }
     if (const char *e = std::getenv("SICP_MATCH_EPILOGUE")) c->match_epilogue = std::atoi(e) != 0;
@@ -1647,7 +1697,8 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                             c->lm_bar = 0;
                         }
                         launch_lm_all(c->stream, qx, qy, qz, c->normals.p, c->m_p2.p, c->keep.p, Q, A, c->icp_dev.p, c->lm_dev.p, c->small.p,
-                                      c->small.p + 4, c->ne_partial.p, c->lm_bar_buf.p, &c->lm_bar, c->resid.p, c->resid2.p, rec);
+                                      c->small.p + 4, c->ne_partial.p, c->lm_bar_buf.p, &c->lm_bar, c->resid.p, c->resid2.p, rec,
+                                      c->test_barrier_fault == 2 ? 1u : 0u);
                     } else {
                         for (int e = 0; e < c->lm_evals; ++e) {
                             launch_lm_eval(c->stream, qx, qy, qz, c->normals.p, c->m_p2.p, c->keep.p, Q, A, c->icp_dev.p, c->lm_dev.p,
@@ -1676,6 +1727,18 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
         CHK(wait_ticket(c, o + REC_TICKET, seqs[completed % REC_RING]));
         const int status = (int)o[REC_STATUS];
         if (status == 3) { ++completed; over = true; continue; }        // launched after the end of the run: not an iteration
+        if (status == 4) {
+            // a one-launch kernel could not meet itself at its grid barrier (its blocks were not all resident: CUs held by another
+            // process, a paused queue).  The launches behind it see the stop flag; start the barrier state afresh so that the next
+            // run is not poisoned by this one (the error word is sticky on the device by design: every later phase must see it)
+            ++completed; over = true;
+            (void)hipStreamSynchronize(c->stream);
+            CHK(reset_barrier_state(c));
+            c->have_iter = false;
+            rc = fail(SICP_ERR_HIP, "a device-wide barrier of iteration %lld timed out (blocks not co-resident: is another process "
+                                    "using the GPU?); the run was stopped and the barrier state reset", (long long)completed);
+            continue;
+        }
         sicp_iter_result &R = results[*done_out];
         std::memset(&R, 0, sizeof R);
         R.n_queries = Q; R.n_planar = (int64_t)o[0]; R.median = o[1]; R.mad = o[2]; R.n_kept = (int64_t)o[3];
@@ -1827,6 +1890,7 @@ int iterate_host_lm(sicp_ctx *c, const sicp_iter_params *P, sicp_iter_result *R)
     }
     HIPCHK(hipGetLastError());
     CHK(wait_ticket(c, h_st + 15, seq));
+    if (h_st[0] < 0.0) return barrier_timed_out(c);
     R->n_queries = Q;
     R->n_planar = (int64_t)h_st[0];
     R->median = h_st[1]; R->mad = h_st[2];
@@ -2031,6 +2095,7 @@ SICP_EXPORT int sicp_corr_reject_distances(sicp_ctx *c, double *median_out, doub
             CHK(reject_select(c, Q, h_st, seq, nullptr));
             HIPCHK(hipGetLastError());
             CHK(wait_ticket(c, h_st + 15, seq));
+            if (h_st[0] < 0.0) return barrier_timed_out(c);
         } else {
             launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p);
             CHK(corr_alive_stats(c, c->small.p, &h_st));
@@ -2126,6 +2191,7 @@ struct CommInit {
     bool done = false;
     ncclResult_t r = ncclSuccess;
     ncclComm_t comm = nullptr;
+    bool abandoned = false;        // the caller's deadline passed: whoever gets a communicator now must give it up
 };
 }  // namespace
 
@@ -2149,13 +2215,16 @@ SICP_EXPORT int sicp_comm_init(sicp_ctx *c, const void *id128, int rank, int wor
         const ncclResult_t r = R->CommInitRank(&comm, world, id, rank);
         std::lock_guard<std::mutex> g(job->m);
         job->r = r; job->comm = comm; job->done = true;
+        if (job->abandoned && r == ncclSuccess && comm) { (void)R->CommAbort(comm); job->comm = nullptr; }    // nobody is waiting any more
         job->cv.notify_all();
     }).detach();
     {
         std::unique_lock<std::mutex> g(job->m);
-        if (!job->cv.wait_for(g, std::chrono::duration<double>(timeout_s), [&] { return job->done; }))
+        if (!job->cv.wait_for(g, std::chrono::duration<double>(timeout_s), [&] { return job->done; })) {
+            job->abandoned = true;                                // (under the lock: the helper aborts what it gets, should it ever return)
             return fail(SICP_ERR_EXCHANGE, "ncclCommInitRank did not return within %.0f s (rank %d of %d): not every rank joined "
                                            "(SICP_COMM_TIMEOUT_S)", timeout_s, rank, world);
+        }
         if (job->r != ncclSuccess) return fail(SICP_ERR_EXCHANGE, "ncclCommInitRank failed: %s", R->GetErrorString(job->r));
         c->comm = job->comm;
     }

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <algorithm>
 #include <stdint.h>
 
@@ -1533,7 +1535,7 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
                                                   HselAll *__restrict__ S, unsigned long long bar_base, uint8_t *__restrict__ keep,
                                                   double *__restrict__ partial /*[3][NE_MAX_GRID]*/, double *__restrict__ out4,
                                                   double *__restrict__ out3, double *__restrict__ host_out, double seq,
-                                                  const IcpDev *__restrict__ st)
+                                                  const IcpDev *__restrict__ st, unsigned absent /* test hook: see grid_barrier */)
 {
     __shared__ unsigned hist[HS_BINS];
     __shared__ unsigned scan[4];
@@ -1591,7 +1593,7 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
             }
             __syncthreads();
             for (int i = tid; i < HS_BINS; i += 256) if (hist[i]) atomicAdd(&gh[i], hist[i]);
-            grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb));
+            grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb), absent);
             // every block picks the bin itself: thread t owns bins 16t .. 16t+15 of the complete histogram
             unsigned h[16], mine = 0;
 #pragma unroll
@@ -1661,7 +1663,7 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
             for (int w = 1; w < 4; ++w) tn = pnx[w] < tn ? pnx[w] : tn;
             if (tn != ~0ull) atomicMin(&S->nxt[which], tn);
         }
-        grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb));
+        grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb), absent);
         // every block ranks the survivors itself
         const unsigned long long above = __hip_atomic_load(&S->nxt[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < 2) pick[tid] = prefix;                  // (single-value interval: both middles are that value unless ...)
@@ -1718,7 +1720,7 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
     if (tid < 3)
         __hip_atomic_store(&partial[(long)tid * NE_MAX_GRID + blockIdx.x], (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb));
+    grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb), absent);
     if (blockIdx.x == 0) {
         if (wid < 3) {
             double t = 0;
@@ -1733,7 +1735,8 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
             const double cnt = bad ? 0.0 : red[0][0], mu = red[0][1] / cnt;
             const double var = red[0][2] / cnt - mu * mu;
             const double mean = med + mu, sd = sqrt(var > 0.0 ? var : 0.0);
-            out4[0] = (double)m_first; out4[1] = bad ? __builtin_nan("") : med; out4[2] = bad ? __builtin_nan("") : val[1]; out4[3] = cnt;
+            out4[0] = bad ? -1.0 : (double)m_first;       // (negative: this launch's barrier failed -- the solver's finish reports it)
+            out4[1] = bad ? __builtin_nan("") : med; out4[2] = bad ? __builtin_nan("") : val[1]; out4[3] = cnt;
             out3[0] = cnt; out3[1] = mean; out3[2] = sd;
             if (host_out) {
                 host_out[0] = out4[0]; host_out[1] = out4[1]; host_out[2] = out4[2]; host_out[3] = cnt;
@@ -1750,6 +1753,27 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
     }
 }
 
+// Blocks of `kernel` (block size `threads`, no dynamic LDS) the CURRENT device holds at once: CUs x blocks per CU, looked up once
+// per device and kernel -- a process may own contexts on devices of different sizes or partition modes, and a grid barrier
+// launched with more blocks than are co-resident cannot meet.
+long resident_blocks(const void *kernel, int threads)
+{
+    static std::mutex m;
+    static std::map<std::pair<int, const void *>, long> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    std::lock_guard<std::mutex> g(m);
+    auto it = cache.find({dev, kernel});
+    if (it != cache.end()) return it->second;
+    int cus = 0, per_cu = 0;
+    long r = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) == hipSuccess && cus >= 1 && per_cu >= 1)
+        r = (long)cus * per_cu;
+    cache[{dev, kernel}] = r;
+    return r;
+}
+
 size_t reject_select_scratch_bytes() { return sizeof(HselAll) > sizeof(HselState) ? sizeof(HselAll) : sizeof(HselState); }
 
 // a new (or re-used) state buffer of the one-launch form: all zero, the two `nxt` words at ~0
@@ -1764,20 +1788,15 @@ hipError_t hsel_state_init(hipStream_t s, void *state)
 // *bar_total is the host's running count of what the launches on this buffer have added to its barrier counter.
 hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
                                        double *out3, void *state, unsigned long long *bar_total, double *partial, double *host_out,
-                                       double seq, const IcpDev *st)
+                                       double seq, const IcpDev *st, unsigned absent)
 {
     static const long cap = [] { const char *e = std::getenv("SICP_HS_GRID"); const long v = e ? std::atol(e) : 0; return v > 0 && v <= 256 ? v : 256L; }();
     // every block must be resident at once (grid barrier): never more blocks than the device can hold (a partitioned device has
     // far fewer CUs than 256)
-    static const long resident = [] {
-        int dev = 0, cus = 0, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_hsel_all, 256, 0) != hipSuccess || cus < 1 || per_cu < 1) return 1L;
-        return (long)cus * per_cu;
-    }();
+    const long resident = resident_blocks((const void *)k_hsel_all, 256);
     const unsigned g = (unsigned)std::max<long>(1, std::min<long>(std::min<long>(cap, resident), (Q + 256 * HS_UNROLL - 1) / (256 * HS_UNROLL)));
     hipLaunchKernelGGL(k_hsel_all, dim3(g), dim3(256), 0, s, dist, flag, Q, (HselAll *)state, *bar_total, keep, partial, out4, out3,
-                       host_out, seq, st);
+                       host_out, seq, st, absent);
     *bar_total += (unsigned long long)HS_MAXB;
     return hipGetLastError();
 }

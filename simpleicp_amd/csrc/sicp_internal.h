@@ -63,7 +63,7 @@ struct TailArgs {
 // per-iteration record the tail streams into pinned host memory (doubles):
 // 0 n_planar, 1 median, 2 mad, 3 n_kept, 4 dist_mean, 5 dist_std, 6 w_used, 7 cost, 8 lm_steps, 9 ne_evals,
 // 10..15 x, 16 res_mean, 17 res_std, 18 status, 19 converged, 20..49 normal equations at x, 50..54 phase cycles
-constexpr int REC_STATUS = 18;      // 0 ok / 1 too few correspondences / 2 objective not finite / 3 skipped (run already over)
+constexpr int REC_STATUS = 18;      // 0 ok / 1 too few correspondences / 2 objective not finite / 3 skipped (run already over) / 4 a grid barrier timed out
 constexpr int REC_CONVERGED = 19;
 constexpr int REC_RESID_SLOT = 61;  // larger Q: which of the two residual buffers holds the accepted residuals
 constexpr int REC_TICKET = 63;
@@ -88,7 +88,8 @@ void launch_lm_eval(hipStream_t s, const double *qx, const double *qy, const dou
                     unsigned *ticket, double *resid0, double *resid1, int rank = 0, int world = 1, double *gsum = nullptr);
 void launch_lm_all(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
                    const uint8_t *keep, long Q, const TailArgs &A, IcpDev *st, LmDev *L, const double *rj4, const double *stats,
-                   double *partial, void *bar, unsigned long long *bar_total, double *resid0, double *resid1, double *rec);
+                   double *partial, void *bar, unsigned long long *bar_total, double *resid0, double *resid1, double *rec,
+                   unsigned absent = 0);
 size_t lm_bar_bytes();
 void launch_lm_advance(hipStream_t s, const TailArgs &A, const IcpDev *st, LmDev *L, const double *stats, const double *gsum);
 void launch_lm_finish(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
@@ -139,10 +140,11 @@ void launch_unpack_idx_postmatch(hipStream_t s, const double *gathered, long Q, 
                                  int64_t *idx, double *p2, double *dist, uint8_t *flag);
 void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, double *d2, int64_t *idx, double *p2);
 size_t reject_select_scratch_bytes();
+long resident_blocks(const void *kernel, int threads);   // blocks the current device holds at once (grid-barrier kernels)
 hipError_t hsel_state_init(hipStream_t s, void *state);
 hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
                                        double *out3, void *state, unsigned long long *bar_total, double *partial, double *host_out,
-                                       double seq, const IcpDev *st);
+                                       double seq, const IcpDev *st, unsigned absent = 0);
 hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, double *out3,
                             void *state, unsigned long long *small, double *partial, unsigned *ticket, double *host_out = nullptr,
                             double seq = 0.0, const IcpDev *st = nullptr);

@@ -106,14 +106,16 @@ struct GridBar {
     unsigned pad2[31];
 };
 // all threads call it; every cross-block datum published before must have been written with agent-scope atomics
-__device__ __forceinline__ void grid_barrier(GridBar *B, unsigned long long number)
+// `absent`: blocks the barrier is told to expect beyond those launched (0 in the product; tests/test_gpu_kernels.py asks for one
+// to see the timeout path end in an error instead of a hang)
+__device__ __forceinline__ void grid_barrier(GridBar *B, unsigned long long number, unsigned absent = 0u)
 {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         // (up to 64 blocks report to ONE group: the second level costs a dependent round trip that the serialisation of so few
         // arrivals does not)
-        const unsigned g = gridDim.x, flat = g <= 64u ? 1u : 0u, c = flat ? 0u : (blockIdx.x & 7u);
+        const unsigned g = gridDim.x + absent, flat = g <= 64u ? 1u : 0u, c = flat ? 0u : (blockIdx.x & 7u);
         const unsigned n_c = flat ? g : ((g + 7u - c) >> 3), groups = flat ? 1u : 8u;
         bool opener = false;
         if (__hip_atomic_fetch_add(&B->sub[c].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_c - 1u) {
@@ -131,6 +133,8 @@ __device__ __forceinline__ void grid_barrier(GridBar *B, unsigned long long numb
             while (__hip_atomic_load(&B->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < number) {
                 __builtin_amdgcn_s_sleep(4);
                 if (++spins > (1L << 21)) { __hip_atomic_store(&B->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                // a barrier of this buffer has already given up: the launch is lost, do not wait two seconds at each of its phases
+                if ((spins & 1023) == 0 && __hip_atomic_load(&B->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
             }
         }
     }

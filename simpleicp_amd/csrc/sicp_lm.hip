@@ -288,10 +288,22 @@ __device__ __forceinline__ void lm_finish_body(
     LmShared &S, double *out /* LDS, 64 */, const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
     const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep, long Q, const TailArgs &A,
     IcpDev *__restrict__ st, LmDev *__restrict__ L, const double *__restrict__ rj4, const double *__restrict__ stats,
-    double *__restrict__ resid0, double *__restrict__ resid1, double *__restrict__ rec)
+    double *__restrict__ resid0, double *__restrict__ resid1, double *__restrict__ rec, bool barrier_failed = false)
 {
     const int tid = threadIdx.x;
     if (tid < 64) out[tid] = 0.0;
+    // a grid barrier of this iteration gave up waiting (its blocks were not all resident: another process holds CUs, a profiler
+    // paused the queue) -- here in the minimisation, or in the rejection (k_hsel_all says so with a negative count): whatever was
+    // folded is incomplete.  Report it and end the run; the host resets the barrier state.
+    if (!st->stop && (barrier_failed || rj4[0] < 0.0)) {
+        if (tid == 0) {
+            rec[REC_STATUS] = 4.0;
+            st->stop = 1;
+            __threadfence_system();
+            __hip_atomic_store(rec + REC_TICKET, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     if (st->stop) {
         if (tid == 0) {
             rec[REC_STATUS] = 3.0;
@@ -422,15 +434,16 @@ __global__ __launch_bounds__(LB) void k_lm_all(
     const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep, long Q, TailArgs A,
     IcpDev *__restrict__ st, LmDev *__restrict__ L, const double *__restrict__ rj4, const double *__restrict__ stats,
     double *__restrict__ partial /* [2][gridDim.x][64] */, GridBar *__restrict__ B, unsigned long long bar_base,
-    double *__restrict__ resid0, double *__restrict__ resid1, double *__restrict__ rec)
+    double *__restrict__ resid0, double *__restrict__ resid1, double *__restrict__ rec, unsigned absent /* test hook: see grid_barrier */)
 {
     __shared__ LmShared S;
     __shared__ LmDev Ls;
     __shared__ double out[64];
     const int tid = threadIdx.x;
     int nb = 0;
-    if (st->stop || stats[0] < 6.0) {
-        // run over, or too few correspondences: nothing to minimise -- block 0 still reports (as k_lm_finish does)
+    if (st->stop || stats[0] < 6.0 || rj4[0] < 0.0) {
+        // run over, too few correspondences, or a rejection whose barrier failed: nothing to minimise -- block 0 still reports
+        // (as k_lm_finish does)
         if (blockIdx.x == 0) lm_finish_body(S, out, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, resid0, resid1, rec);
         return;
     }
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(LB) void k_lm_all(
         double *mypart = partial + ((long)(nb & 1) * g + blockIdx.x) * 64;
         if (tid < 64) __hip_atomic_store(&mypart[tid], S.gb[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ++nb;
-        grid_barrier(B, bar_base + (unsigned long long)nb);
+        grid_barrier(B, bar_base + (unsigned long long)nb, absent);
         // fold the block partials in the launch-per-evaluation form's order: the block's waves take eight partials each per step
         {
             const double *all = partial + (long)((nb - 1) & 1) * g * 64;
@@ -485,7 +498,8 @@ __global__ __launch_bounds__(LB) void k_lm_all(
         }
         __threadfence();
         __syncthreads();
-        lm_finish_body(S, out, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, resid0, resid1, rec);
+        const bool bad = __hip_atomic_load(&B->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        lm_finish_body(S, out, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, resid0, resid1, rec, bad);
     }
 }
 
@@ -515,18 +529,13 @@ void launch_lm_eval(hipStream_t s, const double *qx, const double *qy, const dou
 // one launch for the whole minimisation; *bar_total: what the launches on `bar` have added to its counter so far
 void launch_lm_all(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals, const double *p2,
                    const uint8_t *keep, long Q, const TailArgs &A, IcpDev *st, LmDev *L, const double *rj4, const double *stats,
-                   double *partial, void *bar, unsigned long long *bar_total, double *resid0, double *resid1, double *rec)
+                   double *partial, void *bar, unsigned long long *bar_total, double *resid0, double *resid1, double *rec, unsigned absent)
 {
     // every block must be resident at once (grid barrier): never more blocks than the device can hold
-    static const long resident = [] {
-        int dev = 0, cus = 0, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lm_all, LB, 0) != hipSuccess || cus < 1 || per_cu < 1) return 1L;
-        return (long)cus * per_cu;
-    }();
+    const long resident = resident_blocks((const void *)k_lm_all, LB);
     const unsigned g = (unsigned)std::min<long>(lm_eval_grid(Q), resident);
     hipLaunchKernelGGL(k_lm_all, dim3(g), dim3(LB), 0, s, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, partial,
-                       (GridBar *)bar, *bar_total, resid0, resid1, rec);
+                       (GridBar *)bar, *bar_total, resid0, resid1, rec, absent);
     *bar_total += (unsigned long long)LM_MAXB;
 }
 size_t lm_bar_bytes() { return sizeof(GridBar); }

@@ -131,9 +131,11 @@ def attach(ctx, gn_shard=False, partition=None, group=None):
     if os.environ.get("SICP_XCHG", "rccl") != "callback" and td.get_backend(group) != "gloo":
         pg = group if group is not None else td.group.WORLD
         key = (id(pg), rank, world)                  # (ctx._comm_group keeps `pg` alive, so the id cannot be recycled)
-        if getattr(ctx, "_comm_key", None) == key and getattr(ctx, "_comm_group", None) is pg:
+        if (getattr(ctx, "_comm_key", None) == key and getattr(ctx, "_comm_group", None) is pg
+                and ctx.comm_info()["communicator"]):
             # an earlier run left its communicator parked on this context.  Every rank is in the same position: a
-            # communicator is only ever kept when ALL ranks reported success below, so no agreement round is needed
+            # communicator is only ever kept when ALL ranks reported success below -- and a run that FAILS forgets it on
+            # every rank (forget, below) -- so no agreement round is needed
             ctx.comm_activate(True, gn_shard=gn_shard)
             return "rccl"
         ctx._comm_key = ctx._comm_group = None
@@ -163,6 +165,16 @@ def attach(ctx, gn_shard=False, partition=None, group=None):
                   + "); using the torch.distributed callback exchange", file=sys.stderr, flush=True)
     ctx.set_exchange(make_exchange(ctx, group), rank, world, gn_shard=gn_shard)
     return "callback"
+
+
+def forget(ctx):
+    """After a sharded run raised: whatever communicator the context holds is not to be trusted again (the library aborts it
+    itself on an exchange timeout; a rank that failed for another reason may be out of step with its peers) -- the next
+    attach() builds a new one."""
+    try:
+        ctx.comm_destroy()
+    except Exception:  # noqa: BLE001
+        ctx._comm_key = ctx._comm_group = None
 
 
 def detach(ctx):

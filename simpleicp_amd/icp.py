@@ -138,6 +138,10 @@ class SimpleICP:
             return self._run_uploaded(ctx, sharded, msel, n_search, upload_movable, t_start, obs, ow, H,
                                       correspondences, neighbors, min_planarity, max_overlap_distance, min_change,
                                       max_iterations, distance_weights, debug_dirpath)
+        except _lib.BackendError:
+            if sharded:
+                dist.forget(ctx)       # never revive a communicator a failed run used
+            raise
         finally:
             # the exchange lives on the process-wide context: a later standalone PointCloud operator must not issue a
             # collective the other ranks never join

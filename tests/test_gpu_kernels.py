@@ -722,3 +722,50 @@ def test_knn_sweep_equals_rounds_and_oracle(case, batch, ordered):
         ok = np.isfinite(rpl)
         assert np.abs(a[2] - rnv)[np.isfinite(rnv)].max() <= 2e-7
         assert np.abs(a[3] - rpl)[ok].max() <= 2e-6 * max(1.0, np.abs(rpl[ok]).max())
+
+
+@pytest.mark.parametrize("fault", ["1", "2"])
+def test_grid_barrier_timeout_is_an_error_not_a_hang(fault):
+    """The one-launch rejection (k_hsel_all) and minimisation (k_lm_all) meet at a grid barrier that is only correct when every block
+    is resident.  SICP_TEST_BARRIER_FAULT makes the barrier of one of them expect a block that never arrives: the bounded wait must
+    end in an error the caller sees (sicp_lanes.h: GridBar::error -> record status 4 -> SICP_ERR_HIP), the run must stop, later
+    phases must not each wait out the limit again, and the context must stay usable (the barrier state is reset, nothing sticks)."""
+    import os
+    import time
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(5)
+    n, Q = 60_000, 40_000                                           # > 16 384 correspondences: the many-workgroup path
+    P = _surface(n, 31)
+    Xm = orc.transform(np.linalg.inv(orc.params_to_H(np.array([0.002, -0.001, 0.003, 0.05, -0.03, 0.02]))), P + rng.normal(0, 0.01, P.shape))
+    sel = np.sort(rng.choice(n, Q, replace=False))
+    z = np.zeros(6)
+    os.environ["SICP_TEST_BARRIER_FAULT"] = fault
+    try:
+        c = _lib.Context(0)
+    finally:
+        del os.environ["SICP_TEST_BARRIER_FAULT"]
+    with c:
+        c.upload(_lib.FIX, P); c.upload(_lib.MOV, Xm)
+        nv, pl = c.estimate_normals(_lib.FIX, sel, 10)
+        for attempt in range(2):                                    # twice: the first failure must not poison the second call
+            c.icp_setup(sel, nv, pl)
+            t0 = time.perf_counter()
+            with pytest.raises(_lib.BackendError) as e:
+                if attempt == 0:
+                    c.icp_iterate(z, z, z, 0.3, 1.0)
+                else:
+                    c.icp_run(z, z, z, 0.3, 1.0, max_iterations=5, min_change=0.0)
+            assert e.value.code == _lib.ERR_HIP and "barrier" in str(e.value)
+            assert time.perf_counter() - t0 < 20.0                  # one bounded wait, not one per phase and launch
+        # the same context on the path without grid barriers still works, and agrees with the oracle
+        small = sel[:1000]
+        c.icp_setup(small, nv[:1000], pl[:1000])
+        R = c.icp_iterate(z, z, z, 0.3, 1.0)
+        o = orc.icp_iteration(Xm, P[small], nv[:1000], pl[:1000], z, z, 1.0, z, z, 0.3)
+        assert np.abs(np.array(R.x[:]) - o["x"]).max() < 1e-9
+    # and a context without the fault runs the same iteration through the barriers
+    with _lib.Context(0) as c2:
+        c2.upload(_lib.FIX, P); c2.upload(_lib.MOV, Xm)
+        c2.icp_setup(sel, nv, pl)
+        R = c2.icp_iterate(z, z, z, 0.3, 1.0)
+        assert R.n_kept > 6
