@@ -456,6 +456,8 @@ def run(args):
         ref = json.loads(ref_file.read_text())
         if args.config in ref.get("configs", {}):
             out["cpu_reference"] = {**ref["configs"][args.config], "measured_on": ref.get("measured_on"),
+                                    # (kept by the compact line: the two CPU numbers come from two different machines)
+                                    "box": "NOT this run's host: the build container, " + str(ref.get("measured_on")),
                                     "kind": "reference", "source": "profiles/cpu_reference.json (scripts/time_reference.py)"}
     if args.force_exchange:
         out["config"]["parallelism"] += " (exchange forced on 1 rank)"
@@ -789,12 +791,15 @@ def bruteforce_leg(device, Xf, Xm, sel, normals, planarity, pmc, pmc_src):
             "traffic": pmc.get(kern), "traffic_source": pmc_src if pmc.get(kern) is not None else None,
             "kernel": kern, "avg_ms": ms, "bytes_alg_per_launch": bytes_alg,
             "pair_evals_per_s": pairs / (ms * 1e-3),
-            "valu_or_mfma_frac": pairs * 6 / (ms * 1e-3) / (FP32_VALU_PEAK_TFLOPS * 1e12),
+            # SURVEY 8(d) prices a pair at 8 flop (3 sub + 1 mul + 2 fma in the plain distance form); the filter this kernel runs
+            # spends 6 on it (|p|^2 - 2 q.p: 3 fma): both fractions of the 157.3 TF FP32 vector peak, named for what they count
+            "valu_frac_8flop_per_pair": pairs * 8 / (ms * 1e-3) / (FP32_VALU_PEAK_TFLOPS * 1e12),
+            "valu_frac_6flop_executed": pairs * 6 / (ms * 1e-3) / (FP32_VALU_PEAK_TFLOPS * 1e12),
             "iterations_per_s": 6 / dt,
-            "note": "brute-force Q x N scan is compute-bound by construction (SURVEY 8d): 6 flop per pair in the FP32 filter "
-                    "(valu_or_mfma_frac = against the 157.3 TF FP32 vector = FP32 matrix peak); the few passing (query, group) "
-                    "pairs are recorded and re-evaluated exactly in FP64 by k_knn1_fixup; the cloud is read from HBM once per "
-                    "query block"}
+            "note": "brute-force Q x N scan is compute-bound by construction (SURVEY 8d: 8 flop per pair; the FP32 filter executes "
+                    "6, |p|^2 - 2 q.p as three fma): fractions are against the 157.3 TF FP32 vector = FP32 matrix peak; the few "
+                    "passing (query, group) pairs are recorded and re-evaluated exactly in FP64 by k_knn1_fixup; the cloud is "
+                    "read from HBM once per query block"}
 
 
 def cpu_baseline(Xf, Xm, sel, normals, planarity, iterations):
@@ -809,12 +814,17 @@ def cpu_baseline(Xf, Xm, sel, normals, planarity, iterations):
     res = ref_port.run(Xf, Xm, correspondences=len(sel), max_iterations=iterations, min_change=0.0,
                        normals=normals, planarity=planarity, sel_idx=sel)
     dt = time.perf_counter() - t0
+    import platform
+    per = res.per_iter
+    split = {k: float(np.mean([p[k] for p in per])) for k in per[0] if k.endswith("_s")} if per else {}
     return {"value": res.iterations / dt, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "box": f"this run's host ({platform.processor() or platform.machine()}, {cores} logical cores)",
             "sample": f"{res.iterations} ICP iterations of the same {len(Xm)}-vs-{len(Xf)} workload "
                       f"(cKDTree rebuild + query workers=-1 + scipy least_squares per iteration), "
                       f"{dt:.1f} s wall",
             "correspondences_per_s": len(sel) * res.iterations / dt,
-            "match_s_per_iteration": float(np.mean([p["match_s"] for p in res.per_iter]))}
+            "match_s_per_iteration": split.get("match_s"),
+            "seconds_per_iteration_by_stage": split}
 
 
 if __name__ == "__main__":

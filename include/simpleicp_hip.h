@@ -38,7 +38,7 @@ extern "C" {
 
 /* 1: round 1.  2: + sicp_corr_*, sicp_estimate_parameters, sicp_comm_*, sicp_set_partition, sicp_cloud_set_planarity,
  * sicp_cloud_download_columns, sicp_match_work; sicp_timing_enable(ctx, 2); every upload resets the slot's planarity
- * column.  3: + sicp_comm_activate, sicp_comm_info, sicp_device_memory; SICP_K_XCHG; sicp_comm_init bounded + handshake.  4: + sicp_knn_work; sicp_estimate_normals runs the one-sweep k-NN + covariance kernel.  A binding checks sicp_abi_version() against the header it was written for. */
+ * column.  3: + sicp_comm_activate, sicp_comm_info, sicp_device_memory; SICP_K_XCHG; sicp_comm_init bounded + handshake.  4: + sicp_knn_work, sicp_cloud_download_both; sicp_estimate_normals runs the one-sweep k-NN + covariance kernel.  A binding checks sicp_abi_version() against the header it was written for. */
 #define SICP_ABI_VERSION 4
 
 #define SICP_OK               0
@@ -78,6 +78,10 @@ int sicp_cloud_download(sicp_ctx *ctx, int slot, double *xyz_out);
 /* The same as three contiguous columns -- what `self[["x", "y", "z"]] = ...` leaves in the DataFrame after
  * transform_by_H (pointcloud.py:215-217): straight out of the column-wise device layout, no transpose on either side. */
 int sicp_cloud_download_columns(sicp_ctx *ctx, int slot, double *x_out, double *y_out, double *z_out);
+/* Both forms in one pass over the link: xyz_out (n, 3) row-major and / or the three columns (all three or none; xyz_out may be
+ * null).  The columns are pulled through a pinned double buffer while host threads fan each chunk out (the row form is
+ * transposed on the host) -- what PointCloud.transform_by_H needs after run() (simpleicp.py:316, pointcloud.py:205-217). */
+int sicp_cloud_download_both(sicp_ctx *ctx, int slot, double *xyz_out, double *x_out, double *y_out, double *z_out);
 /* The `planarity` column of a cloud that has one (CorrPts.reject_wrt_planarity also tests the MOVABLE cloud's
  * planarity of every matched point when pc2 carries that column, corrpts.py:158-163; NaN fails the test).
  * Only consulted for SICP_MOV by the iteration.  The column is indexed by GLOBAL point index and has n_global

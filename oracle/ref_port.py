@@ -134,11 +134,16 @@ def run(X_fix, X_mov, correspondences=1000, neighbors=10, min_planarity=0.3,
     for it in range(max_iterations):
         t0 = time.perf_counter()
         Xt = transform(X_mov, H)                              # simpleicp.py:188
-        _, nn = cKDTree(Xt).query(p1, k=1, p=2, workers=-1)   # corrpts.py:131-132
+        t_xf = time.perf_counter() - t0
+        tree = cKDTree(Xt)                                    # corrpts.py:131 (rebuilt every iteration)
+        t_build = time.perf_counter() - t0 - t_xf
+        _, nn = tree.query(p1, k=1, p=2, workers=-1)          # corrpts.py:132
+        t_query = time.perf_counter() - t0 - t_xf - t_build
         p2t = Xt[nn]
         dist = (p2t[:, 0] - p1[:, 0]) * n1[:, 0] + (p2t[:, 1] - p1[:, 1]) * n1[:, 1] + (p2t[:, 2] - p1[:, 2]) * n1[:, 2]
         _ = transform(Xt, np.linalg.inv(H))                   # simpleicp.py:202 (cost only)
         t_match = time.perf_counter() - t0
+        t_rej0 = time.perf_counter()
         keep = planarity >= np.float32(min_planarity)         # corrpts.py:139-163
         dk = dist[keep]
         med = np.median(dk)
@@ -155,6 +160,8 @@ def run(X_fix, X_mov, correspondences=1000, neighbors=10, min_planarity=0.3,
         q1, qn, q2 = p1[kidx], n1[kidx], X_mov[nn[kidx]]
 
         x0 = obs.copy() if it == 0 else x_est.copy()
+        t_reject = time.perf_counter() - t_rej0
+        t_sol0 = time.perf_counter()
 
         def resid(xf, x0=x0, q1=q1, qn=qn, q2=q2, w=w):
             x = x0.copy()
@@ -172,7 +179,8 @@ def run(X_fix, X_mov, correspondences=1000, neighbors=10, min_planarity=0.3,
         res = r_final[:len(kidx)] / w
         res_hist.append(res)
         counts.append(len(kidx))
-        per_iter.append({"match_s": t_match, "total_s": time.perf_counter() - t0})
+        per_iter.append({"match_s": t_match, "transform_s": t_xf, "tree_build_s": t_build, "tree_query_s": t_query,
+                         "reject_s": t_reject, "solve_s": time.perf_counter() - t_sol0, "total_s": time.perf_counter() - t0})
         if record is not None:
             record.append({"nn": nn.copy(), "dist": dist.copy(), "kept": kidx.copy(), "x": x_est.copy(),
                            "median": med, "mad": mad})

@@ -26,7 +26,7 @@ def timed(name):
     setattr(_lib.Context, name, wrap)
 
 
-for m in ("upload", "upload_columns", "download", "download_columns", "transform", "knn", "select_in_range", "estimate_normals", "icp_setup", "icp_run", "icp_iterate",
+for m in ("upload", "upload_columns", "download", "download_columns", "download_both", "transform", "knn", "select_in_range", "estimate_normals", "icp_setup", "icp_run", "icp_iterate",
           "icp_state", "icp_uncertainties"):
     timed(m)
 

@@ -28,7 +28,7 @@ MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1
 EXPORTS = [
     "sicp_abi_version", "sicp_last_error", "sicp_device_count", "sicp_ctx_create", "sicp_ctx_destroy",
     "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_upload_columns", "sicp_cloud_size", "sicp_cloud_transform",
-    "sicp_cloud_download", "sicp_cloud_download_columns", "sicp_cloud_set_planarity", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
+    "sicp_cloud_download", "sicp_cloud_download_columns", "sicp_cloud_download_both", "sicp_cloud_set_planarity", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
     "sicp_corr_match", "sicp_corr_reject_planarity", "sicp_corr_reject_distances", "sicp_estimate_parameters",
     "sicp_set_exchange", "sicp_comm_unique_id", "sicp_comm_init", "sicp_comm_destroy", "sicp_comm_activate", "sicp_comm_info", "sicp_device_memory", "sicp_set_partition", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_knn_work", "sicp_last_match_kernel",
@@ -95,6 +95,7 @@ def load():
     L.sicp_cloud_transform.argtypes = [vp, cint, vp]
     L.sicp_cloud_download.argtypes = [vp, cint, vp]
     L.sicp_cloud_download_columns.argtypes = [vp, cint, vp, vp, vp]
+    L.sicp_cloud_download_both.argtypes = [vp, cint, vp, vp, vp, vp]
     L.sicp_cloud_set_planarity.argtypes = [vp, cint, vp, vp, i64, i64]
     L.sicp_knn.argtypes = [vp, cint, vp, i64, cint, vp, dbl, vp, vp]
     L.sicp_select_in_range.argtypes = [vp, cint, cint, vp, i64, vp, dbl, vp]
@@ -242,6 +243,14 @@ class Context:
         cols = [np.empty(n) for _ in range(3)]
         self._chk(self._L.sicp_cloud_download_columns(self._h, slot, _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2])))
         return cols
+
+    def download_both(self, slot):
+        """((n, 3) array, [x, y, z] vectors) in ONE pass over the link (pinned, pipelined, transposed by host threads)."""
+        n = self.size(slot)
+        out = np.empty((n, 3))
+        cols = [np.empty(n) for _ in range(3)]
+        self._chk(self._L.sicp_cloud_download_both(self._h, slot, _ptr(out), _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2])))
+        return out, cols
 
     def set_planarity(self, slot, planarity=None, rows=None, n_global=None):
         """The cloud's `planarity` column (corrpts.py:158-163 tests the movable cloud's too): a dense float32 vector

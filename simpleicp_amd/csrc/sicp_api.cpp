@@ -294,6 +294,8 @@ struct sicp_ctx {
     DevBuf<double> ne_partial;
     DevBuf<unsigned> ticket;
     double *h_small = nullptr;     // pinned mirror of `small`
+    double *h_dl = nullptr;        // pinned double buffer of sicp_cloud_download_both (2 x 3 x 512 Ki doubles), on first use
+    hipEvent_t dl_ev[2] = {nullptr, nullptr};
     bool have_iter = false;
     bool have_corr = false;        // sicp_corr_match has run: m_idx / m_p2 / dist hold its correspondences, `keep` the alive mask
     DevBuf<float> corr_pl;         // per-correspondence planarity columns handed to sicp_corr_reject_planarity: pc1 [Q] | pc2 [Q]
@@ -1185,6 +1187,8 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)rccl()->CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->h_dl) { (void)hipHostFree(c->h_dl); c->h_dl = nullptr; }
+    for (auto &e : c->dl_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &cl : c->cloud) { cl.xyz.release(); cl.pl.release(); cl.grid.cell_start.release(); cl.grid.rec.release();
@@ -1359,6 +1363,88 @@ SICP_EXPORT int sicp_cloud_download_columns(sicp_ctx *c, int slot, double *x_out
     HIPCHK(hipMemcpyAsync(x_out, cl.x(), (size_t)cl.n * sizeof(double), hipMemcpyDefault, c->stream));
     HIPCHK(hipMemcpyAsync(y_out, cl.y(), (size_t)cl.n * sizeof(double), hipMemcpyDefault, c->stream));
     HIPCHK(hipMemcpyAsync(z_out, cl.z(), (size_t)cl.n * sizeof(double), hipMemcpyDefault, c->stream));
+    return sync(c);
+}
+
+// The cloud as (n, 3) rows AND as three columns in ONE pass over the link (the Python mirror's transform_by_H needs both:
+// run() returns the rows, the DataFrame keeps the columns -- simpleicp.py:316, pointcloud.py:205-217).  Two plain downloads into
+// pageable memory cost 2 x 11-21 ms per 10 M points (the copy engine waits for the host's staging copies and page faults).
+// Here the columns are pulled chunk by chunk into a pinned double buffer at link speed while host threads fan the previous chunk
+// out into both destinations (the row form is a transpose the host does from the pinned chunk: nothing crosses the link twice).
+SICP_EXPORT int sicp_cloud_download_both(sicp_ctx *c, int slot, double *xyz_out, double *x_out, double *y_out, double *z_out)
+{
+    CHK(check_slot(c, slot, true));
+    if (!xyz_out && !(x_out && y_out && z_out)) return fail(SICP_ERR_INVALID, "no destination");
+    if ((x_out || y_out || z_out) && !(x_out && y_out && z_out)) return fail(SICP_ERR_INVALID, "x_out / y_out / z_out: all or none");
+    HIPCHK(hipSetDevice(c->device));
+    Cloud &cl = c->cloud[slot];
+    const long n = cl.n, CH = 1L << 19;                       // 512 Ki points = 12 MiB per chunk
+    if (!c->h_dl) HIPCHK(hipHostMalloc((void **)&c->h_dl, (size_t)2 * 3 * CH * sizeof(double), hipHostMallocDefault));
+    if (!c->dl_ev[0]) { HIPCHK(hipEventCreateWithFlags(&c->dl_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->dl_ev[1], hipEventDisableTiming)); }
+    const long nchunks = (n + CH - 1) / CH;
+    unsigned T = std::thread::hardware_concurrency();
+    T = T < 2 ? 1 : (T > 8 ? 8 : T);
+    auto enqueue = [&](long ch) -> int {
+        const long lo = ch * CH, m = std::min(CH, n - lo);
+        double *b = c->h_dl + (size_t)(ch & 1) * 3 * CH;
+        HIPCHK(hipMemcpyAsync(b, cl.x() + lo, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(b + CH, cl.y() + lo, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(b + 2 * CH, cl.z() + lo, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->dl_ev[ch & 1], c->stream));
+        return SICP_OK;
+    };
+    // workers: chunk `ready` is in its pinned buffer; worker t fans out its share and counts itself in `done`
+    std::atomic<long> ready{-1}, done{0};
+    std::atomic<bool> quit{false};
+    auto work = [&](unsigned t) {
+        for (long ch = 0; ch < nchunks; ++ch) {
+            while (ready.load(std::memory_order_acquire) < ch) { if (quit.load()) return; std::this_thread::yield(); }
+            const long lo = ch * CH, m = std::min(CH, n - lo);
+            const long a = m * t / T, e = m * (t + 1) / T;
+            const double *b = c->h_dl + (size_t)(ch & 1) * 3 * CH;
+            if (x_out) {
+                std::memcpy(x_out + lo + a, b + a, (size_t)(e - a) * sizeof(double));
+                std::memcpy(y_out + lo + a, b + CH + a, (size_t)(e - a) * sizeof(double));
+                std::memcpy(z_out + lo + a, b + 2 * CH + a, (size_t)(e - a) * sizeof(double));
+            }
+            if (xyz_out) {
+                double *o = xyz_out + 3 * (lo + a);
+                for (long i = a; i < e; ++i) { o[0] = b[i]; o[1] = b[CH + i]; o[2] = b[2 * CH + i]; o += 3; }
+            }
+            done.fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
+    int rc = nchunks > 0 ? enqueue(0) : SICP_OK;
+    for (long ch = 0; ch < nchunks && rc == SICP_OK; ++ch) {
+        // the buffer chunk ch + 1 lands in was chunk ch - 1's: every worker must be through with it
+        while (done.load(std::memory_order_acquire) < (long)(T - 1) * ch) std::this_thread::yield();
+        if (ch + 1 < nchunks) rc = enqueue(ch + 1);
+        if (rc == SICP_OK && hipEventSynchronize(c->dl_ev[ch & 1]) != hipSuccess) rc = fail(SICP_ERR_HIP, "hipEventSynchronize failed");
+        if (rc != SICP_OK) break;
+        ready.store(ch, std::memory_order_release);
+        // this thread is worker 0 of the chunk
+        {
+            const long lo = ch * CH, m = std::min(CH, n - lo);
+            const long a = 0, e = m / T;
+            const double *b = c->h_dl + (size_t)(ch & 1) * 3 * CH;
+            if (x_out) {
+                std::memcpy(x_out + lo + a, b + a, (size_t)(e - a) * sizeof(double));
+                std::memcpy(y_out + lo + a, b + CH + a, (size_t)(e - a) * sizeof(double));
+                std::memcpy(z_out + lo + a, b + 2 * CH + a, (size_t)(e - a) * sizeof(double));
+            }
+            if (xyz_out) {
+                double *o = xyz_out + 3 * (lo + a);
+                for (long i = a; i < e; ++i) { o[0] = b[i]; o[1] = b[CH + i]; o[2] = b[2 * CH + i]; o += 3; }
+            }
+        }
+        // (the next round's wait covers the other workers; after the last chunk the joins do)
+        while (ch + 1 == nchunks && done.load(std::memory_order_acquire) < (long)(T - 1) * nchunks) std::this_thread::yield();
+    }
+    if (rc != SICP_OK) quit.store(true);
+    for (auto &th : pool) th.join();
+    if (rc != SICP_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
     return sync(c);
 }
 

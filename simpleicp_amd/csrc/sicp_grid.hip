@@ -893,8 +893,8 @@ __global__ __launch_bounds__(256) void k_grid_knn(
 //     -- its rank, exact and unique -- and the k smallest leave in rank order; fewer: the radius grows towards ~1.8 k
 //     expected points and the sweep repeats; more than the LDS holds: the radius shrinks, and data that defeats that
 //     (thousands of coincident points) takes the k-round extraction of k_grid_knn over the same cells;
-//   * the neighbours' coordinates are still in LDS: six lanes form the mean and the six covariance sums in the oracle's
-//     operation order (orc_normals: sequential in rank order), nothing is gathered again and no index goes to memory unless
+//   * the neighbours' coordinates are still in LDS: six lanes form the mean and the six covariance sums in the operation
+//     order of oracle/sicp_oracle.c:orc_normals (sequential in rank order), nothing is gathered again and no index goes to memory unless
 //     the caller asked for it;
 //   * a wave works through `batch` queries that are neighbours in space (the caller hands the queries in cell order, tile by
 //     tile): their cells are in L1 / L2, and the k-th distances met so far (smoothed) set the next starting radius, so a cloud
@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
             dk_est = sweeps > 1 ? dk : 0.75 * dk_est + 0.25 * dk;
         }
         if (cov_out) {
-            // mean and covariance sums in rank order, one sum per lane (orc_normals' operation order: pointcloud.py:188-190)
+            // mean and covariance sums in rank order, one sum per lane (the order pointcloud.py:188-190 is restated in by the oracle)
             double mean = 0.0;
             if (lane < 3 && kk == k) {
                 for (int s = 0; s < k; ++s) mean += nbr[3 * s + lane];

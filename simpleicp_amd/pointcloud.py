@@ -5,8 +5,8 @@ after ``estimate_normals``, float32 sparse columns ``nx, ny, nz, planarity`` (Na
 estimated) -- exactly the layout the reference's callers see.  The three operators that are
 on the ICP hot path run on the GPU through the C ABI (no host fallback):
 
-  select_in_range   -> brute-force 1-NN with a strict upper bound   (pointcloud.py:149-171)
-  estimate_normals  -> brute-force k-NN + covariance + 3x3 eigen    (pointcloud.py:173-203)
+  select_in_range   -> exact 1-NN with a strict upper bound (pruned grid search; brute force on small clouds)  (pointcloud.py:149-171)
+  estimate_normals  -> exact k-NN + covariance + 3x3 eigen (one sweep per query on the grid)              (pointcloud.py:173-203)
   transform_by_H    -> in-place rigid transform, contract (T)       (pointcloud.py:205-217)
 """
 from __future__ import annotations
@@ -278,11 +278,11 @@ class PointCloud(pd.DataFrame):
             slot = _lib.MOV
             self._upload(ctx, slot)
         ctx.transform(slot, np.asarray(H, dtype=np.float64))
-        Xt = ctx.download(slot)
-        # the frame wants three contiguous columns: they come straight out of the device's column-wise layout (a second
-        # copy over the link costs a third of what three strided host copies of Xt[:, j] do) and are handed to the frame
-        # WITHOUT pandas' defensive copy of freshly made arrays nobody else holds
-        cols = ctx.download_columns(slot)
+        # run() returns the (n, 3) rows, the frame wants three contiguous columns: both come out of ONE pass over the link
+        # (sicp_cloud_download_both: the device's columns through a pinned double buffer, fanned out -- and transposed -- by
+        # host threads) and the columns are handed to the frame WITHOUT pandas' defensive copy of freshly made arrays
+        # nobody else holds
+        Xt, cols = ctx.download_both(slot)
         for name, col in zip(_XYZ, cols):
             self._adopt_column(name, col)
         return Xt

@@ -25,6 +25,7 @@ def build_calls():
         "sicp_cloud_transform": lambda: L.sicp_cloud_transform(None, 0, buf),
         "sicp_cloud_download": lambda: L.sicp_cloud_download(None, 0, buf),
         "sicp_cloud_download_columns": lambda: L.sicp_cloud_download_columns(None, 0, buf, buf, buf),
+        "sicp_cloud_download_both": lambda: L.sicp_cloud_download_both(None, 0, buf, buf, buf, buf),
         "sicp_cloud_set_planarity": lambda: L.sicp_cloud_set_planarity(None, 0, None, None, 0, 0),
         "sicp_knn": lambda: L.sicp_knn(None, 0, buf, 1, 1, None, 1.0, buf, buf),
         "sicp_select_in_range": lambda: L.sicp_select_in_range(None, 0, 1, None, 0, None, 1.0, buf),
@@ -54,6 +55,7 @@ def build_calls():
         "sicp_timing_reset": lambda: L.sicp_timing_reset(None),
         "sicp_timing_get": lambda: L.sicp_timing_get(None, 0, C.byref(d), C.byref(i64)),
         "sicp_match_work": lambda: L.sicp_match_work(None, buf),
+        "sicp_knn_work": lambda: L.sicp_knn_work(None, buf),
         "sicp_last_match_kernel": lambda: L.sicp_last_match_kernel(None, C.byref(ci)),
         "sicp_xyz_count": lambda: L.sicp_xyz_count(None, C.byref(i64)),
         "sicp_xyz_read": lambda: L.sicp_xyz_read(None, buf, 1, C.byref(i64), 1),

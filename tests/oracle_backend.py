@@ -55,6 +55,9 @@ class OracleContext:
         X = self.cloud[slot][0]
         return [np.ascontiguousarray(X[:, j]) for j in range(3)]
 
+    def download_both(self, slot):
+        return self.download(slot), self.download_columns(slot)
+
     def set_planarity(self, slot, planarity=None, rows=None, n_global=None):
         self._log("set_planarity")
         if planarity is None:

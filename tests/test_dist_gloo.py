@@ -169,7 +169,14 @@ class _FakeCtx:
         self.calls.append(("comm_init", rank, world))
 
     def comm_destroy(self):
+        self._comm_key = self._comm_group = None           # (as _lib.Context.comm_destroy does)
         self.calls.append(("comm_destroy",))
+
+    def comm_info(self):
+        live = False
+        for x in self.calls:
+            live = True if x[0] == "comm_init" else (False if x[0] == "comm_destroy" else live)
+        return {"communicator": live}
 
     def comm_activate(self, on=True, gn_shard=False):
         self.calls.append(("comm_activate", bool(on)))
@@ -198,6 +205,14 @@ def _worker_attach(rank, world, port, tmp):
         assert c.calls[-3:] == [("comm_activate", False), ("callback", 0, 1), ("partition", 0)]
         n_init = sum(x[0] == "comm_init" for x in c.calls)
         assert dist.attach(c) == "rccl" and c.calls[-1] == ("comm_activate", True) and sum(x[0] == "comm_init" for x in c.calls) == n_init
+        # a run that failed forgets the communicator (dist.forget; the library aborts it itself on an exchange timeout): the next
+        # attach builds a new one instead of reviving a communicator that may be out of step -- also after a plain comm_destroy
+        dist.detach(c)
+        dist.forget(c)
+        assert dist.attach(c) == "rccl" and sum(x[0] == "comm_init" for x in c.calls) == n_init + 1
+        dist.detach(c)
+        c.comm_destroy()
+        assert dist.attach(c) == "rccl" and sum(x[0] == "comm_init" for x in c.calls) == n_init + 2
         # ONE rank fails -> ALL ranks drop their communicator and register the callback exchange
         c = _FakeCtx(rank, fail_on=1)
         assert dist.attach(c) == "callback" and ("comm_destroy",) in c.calls and c.calls[-1] == ("callback", rank, world)

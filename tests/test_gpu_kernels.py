@@ -769,3 +769,26 @@ def test_grid_barrier_timeout_is_an_error_not_a_hang(fault):
         c2.icp_setup(sel, nv, pl)
         R = c2.icp_iterate(z, z, z, 0.3, 1.0)
         assert R.n_kept > 6
+
+
+@pytest.mark.parametrize("n", [1, 7, 524_288, 524_289, 1_600_003])
+def test_download_both_equals_the_two_downloads(ctx, n):
+    """sicp_cloud_download_both (pinned double buffer, host threads fan out and transpose) == sicp_cloud_download and
+    sicp_cloud_download_columns, bit for bit, across its 512 Ki-point chunk boundaries; each destination also on its own."""
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(n)
+    X = rng.uniform(-1e3, 1e3, (n, 3))
+    ctx.upload(_lib.MOV, X)
+    ctx.transform(_lib.MOV, _H(3))
+    rows, cols = ctx.download_both(_lib.MOV)
+    assert np.array_equal(rows, ctx.download(_lib.MOV))
+    for a, b in zip(cols, ctx.download_columns(_lib.MOV)):
+        assert np.array_equal(a, b)
+    only_rows = np.empty((n, 3))
+    ctx._chk(ctx._L.sicp_cloud_download_both(ctx._h, _lib.MOV, _lib._ptr(only_rows), None, None, None))
+    assert np.array_equal(only_rows, rows)
+    x, y, z = np.empty(n), np.empty(n), np.empty(n)
+    ctx._chk(ctx._L.sicp_cloud_download_both(ctx._h, _lib.MOV, None, _lib._ptr(x), _lib._ptr(y), _lib._ptr(z)))
+    assert np.array_equal(np.column_stack((x, y, z)), rows)
+    with pytest.raises(_lib.BackendError):
+        ctx._chk(ctx._L.sicp_cloud_download_both(ctx._h, _lib.MOV, None, _lib._ptr(x), None, None))
