@@ -322,6 +322,8 @@ struct sicp_ctx {
     bool lm_one_launch = true;         // SICP_LM=launches: one launch per evaluation + finish (A/B; always with a sharded reduction)
     unsigned long long hsel_bar = 0;   // what the one-launch rejection's launches have added to its barrier counter so far
     int test_barrier_fault = 0;    // SICP_TEST_BARRIER_FAULT = 1 / 2 (tests only): the rejection's / the solver's grid barrier expects a block that never comes
+    bool hsel_window = true;       // SICP_HSEL_WINDOW=0: never the windowed (three-barrier) form of the large-Q rejection
+    long hsel_run_launches = 0;    // chained rejection launches since the last setup (the window needs two of them behind it)
     bool hsel_one_launch = true;   // SICP_HSEL=launches: the launch-per-phase form (A/B)
     bool hsel_dirty = false;
     int nn_group = 0;              // SICP_NN_GROUP=8|16: lanes per query of the many-queries search (0: chosen per launch)
@@ -510,6 +512,25 @@ int exchange_best(sicp_ctx *c, double *d2, int64_t *idx, double *p2, long Q)
     return SICP_OK;
 }
 
+// The same behind the match of a chained ICP iteration, in two launches fewer: the match kernel's winning lanes left the packed
+// records themselves (PostMatch::pack), and ONE kernel takes the lexicographic minimum over the ranks and forms the
+// point-to-plane distance + planarity verdict (k_postmatch's work) from it.
+int exchange_best_chained(sicp_ctx *c, const TailArgs &A, long Q, bool packed_by_match)
+{
+    Timed t(c, SICP_K_XCHG);
+    CHK(c->x_recv.reserve((size_t)5 * Q * c->world));
+    if (!packed_by_match) {
+        launch_pack_best(c->stream, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q, c->x_send.p);
+        HIPCHK(hipGetLastError());
+    }
+    CHK(all_gather_f64(c, c->x_send.p, c->x_recv.p, 5 * Q));
+    launch_lexmin_postmatch(c->stream, c->x_recv.p, c->world, Q, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p,
+                            c->planarity.p, A.min_planarity, A.pl2, A.pl2_n, c->icp_dev.p, c->m_d2.p, c->m_idx.p, c->m_p2.p,
+                            c->dist.p, c->flag.p);
+    HIPCHK(hipGetLastError());
+    return SICP_OK;
+}
+
 // query shards (cloud replicated): rank r matched queries [r * per, (r + 1) * per); the slices are gathered in rank
 // order, which IS query order, so every rank ends up with all Q results
 long query_slice(const sicp_ctx *c, long Q, long *lo)
@@ -520,7 +541,7 @@ long query_slice(const sicp_ctx *c, long Q, long *lo)
 }
 // ... gathered slim: 8 bytes per query (the matched index) instead of the 40-byte (d2, idx, xyz) record -- the cloud is replicated,
 // so every rank looks the coordinates up itself and forms distance + verdict in the same pass (k_postmatch's work)
-int exchange_query_slices_idx(sicp_ctx *c, const TailArgs &A, long Q)
+int exchange_query_slices_idx(sicp_ctx *c, const TailArgs &A, long Q, bool packed_by_match)
 {
     const Cloud &cl = c->cloud[SICP_MOV];
     const long per = (Q + c->world - 1) / c->world;
@@ -528,8 +549,13 @@ int exchange_query_slices_idx(sicp_ctx *c, const TailArgs &A, long Q)
     Timed t(c, SICP_K_XCHG);
     CHK(c->x_send.reserve((size_t)per));
     CHK(c->x_recv.reserve((size_t)per * c->world));
-    launch_pack_idx(c->stream, c->m_idx.p + lo, cnt, per, c->x_send.p);
-    HIPCHK(hipGetLastError());
+    if (packed_by_match) {
+        // the match kernel's winning lanes wrote the slice's entries; the padding behind a short last slice reads "no match"
+        if (per > cnt) HIPCHK(hipMemsetAsync(c->x_send.p + cnt, 0xff, (size_t)(per - cnt) * sizeof(double), c->stream));
+    } else {
+        launch_pack_idx(c->stream, c->m_idx.p + lo, cnt, per, c->x_send.p);
+        HIPCHK(hipGetLastError());
+    }
     CHK(all_gather_f64(c, c->x_send.p, c->x_recv.p, per));
     launch_unpack_idx_postmatch(c->stream, c->x_recv.p, Q, cl.x(), cl.y(), cl.z(), cl.idx_base, cl.n, c->q.p, c->q.p + c->qpad,
                                 c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, A.min_planarity, A.pl2, A.pl2_n, c->icp_dev.p,
@@ -570,7 +596,9 @@ int reject_select(sicp_ctx *c, long Q, double *host_out, double seq, const IcpDe
             c->hsel_bar = 0; c->hsel_dirty = false;
         }
         e = reject_by_select_one_launch(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
-                                        &c->hsel_bar, c->ne_partial.p, host_out, seq, st, c->test_barrier_fault == 1 ? 1u : 0u);
+                                        &c->hsel_bar, c->ne_partial.p, host_out, seq, st, c->test_barrier_fault == 1 ? 1u : 0u,
+                                        c->hsel_window && st != nullptr && c->hsel_run_launches >= 2);
+        if (st) ++c->hsel_run_launches;
     } else {
         c->hsel_dirty = true;
         e = reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
@@ -1163,6 +1191,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_COARSE_ITERS")) c->coarse_iters = std::atoi(e);
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
     if (const char *e = std::getenv("SICP_LM")) c->lm_one_launch = std::strcmp(e, "launches") != 0;
+    if (const char *e = std::getenv("SICP_HSEL_WINDOW")) c->hsel_window = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_TEST_BARRIER_FAULT")) c->test_barrier_fault = std::atoi(e);
     if (const char *e = std::getenv("SICP_HSEL")) c->hsel_one_launch = std::strcmp(e, "launches") != 0;
     if (const char *e = std::getenv("SICP_NN_GROUP")) { const int v = std::atoi(e); if (v == 8 || v == 16) c->nn_group = v; }
@@ -1587,6 +1616,7 @@ SICP_EXPORT int sicp_icp_setup(sicp_ctx *c, const int64_t *sel_idx, int64_t Q, c
     c->have_corr = false;
     c->have_prev_match = false;
     c->q_order_lo = -1; c->q_order_cnt = 0;
+    c->hsel_run_launches = 0;
     return sync(c);
 }
 
@@ -1678,6 +1708,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
             const double *prev = c->have_prev_match ? c->m_p2.p : nullptr;
             const bool qshard = c->collective() && c->partition == SICP_PART_QUERIES;
             bool post_done = false;             // distances + planarity verdicts already written by the match kernel
+            bool packed = false;                // ... the exchange's packed records
             if (grid) {
                 // (query shards: this rank searches its slice of the queries in the whole cloud, results land in
                 // their place in the full arrays)
@@ -1710,13 +1741,20 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 // table's limit leaves 25 points per cell, 8 lanes need twice the steps: 2.07 -> 2.53 ms per step) nor below ~200 k
                 // queries (too few waves to fill the machine)
                 const bool eight = c->nn_group ? c->nn_group == 8 : (cnt >= 196608 && !cl.grid.cap_limited && cl.grid.avg_per_cell <= 20.0);
-                PostMatch pm = {c->normals.p, c->planarity.p, A.pl2, A.pl2_n, A.min_planarity, c->dist.p, c->flag.p};
+                // behind a cloud-shard exchange the winning lanes leave the exchange's packed record instead (no k_pack_best launch)
+                // (query shards: the slim record, the matched index alone -- no k_pack_idx launch)
+                const bool pack = c->collective() && !qshard, pack_idx = c->collective() && qshard;
+                if (pack) CHK(c->x_send.reserve((size_t)5 * Q));
+                if (pack_idx) CHK(c->x_send.reserve((size_t)((Q + c->world - 1) / c->world)));
+                PostMatch pm = {c->normals.p, c->planarity.p, A.pl2, A.pl2_n, A.min_planarity, post_done ? c->dist.p : nullptr,
+                                post_done ? c->flag.p : nullptr, pack ? c->x_send.p : nullptr, pack_idx ? c->x_send.p : nullptr};
+                packed = (pack || pack_idx) && cnt > 0;
                 if (cnt > 0)
                     launch_grid_nn_chained(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt,
                                            coarse ? c->bound_p2.p + 3 * lo : (prev ? prev + 3 * lo : nullptr), cl.grid.g,
                                            cl.grid.cell_start.p, cl.grid.rec.p, c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p + lo,
                                            c->m_idx.p + lo, c->m_p2.p + 3 * lo, c->count_work ? c->match_work.p : nullptr,
-                                           ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q, coarse, post_done ? &pm : nullptr, eight);
+                                           ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q, coarse, (post_done || pack || pack_idx) ? &pm : nullptr, eight);
             } else if (qshard) {
                 return fail(SICP_ERR_INVALID, "query shards need the grid search (SICP_KNN1 forces another kernel)");
             } else {
@@ -1728,8 +1766,11 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
             }
             HIPCHK(hipGetLastError());
             c->have_prev_match = true;          // (after an exchange: the job-wide winner's coordinates -- still a valid bound)
-            if (qshard) { CHK(exchange_query_slices_idx(c, A, Q)); post_done = true; }      // (distances + verdicts formed by the unpack)
-            else CHK(exchange_best(c, c->m_d2.p, c->m_idx.p, c->m_p2.p, Q));
+            if (qshard) { CHK(exchange_query_slices_idx(c, A, Q, packed)); post_done = true; }      // (distances + verdicts formed by the unpack)
+            else if (c->collective() && c->partition == SICP_PART_CLOUD) {
+                CHK(c->x_send.reserve((size_t)5 * Q));
+                CHK(exchange_best_chained(c, A, Q, packed)); post_done = true;                 // (... by the lexicographic minimum's kernel)
+            }
             A.seq = (double)(++c->solve_seq);
             seqs[launched % REC_RING] = A.seq;
             double *rec = c->h_rec + (launched % REC_RING) * REC_DOUBLES;

@@ -549,6 +549,12 @@ __global__ __launch_bounds__(256) void k_grid_nn(
                     p2_out[3 * q + 2] = ok ? bz : 0.0;
                 }
                 if (post.dist) post_match(post, H, q, m, ok ? bx : 0.0, ok ? by : 0.0, ok ? bz : 0.0, ax, ay, az, pnx, pny, pnz, ppl);
+                if (post.pack) {
+                    double *r5 = post.pack + 5 * q;
+                    r5[0] = ok ? best : __builtin_inf(); r5[1] = __longlong_as_double((long long)m);
+                    r5[2] = ok ? bx : 0.0; r5[3] = ok ? by : 0.0; r5[4] = ok ? bz : 0.0;
+                }
+                if (post.pack_idx) post.pack_idx[q] = __longlong_as_double((long long)m);
             }
             break;
         }
@@ -572,8 +578,11 @@ __global__ __launch_bounds__(256) void k_grid_nn(
 // are one DPP row, so the lexicographic minimum stays a register butterfly; row ranges travel inside the group by
 // ds_bpermute (per-group source lane: no uniform readlane).  Groups of a wave run in lock step and idle once done.
 // ------------------------------------------------------------------------------------
+#ifndef SICP_NN16_OCC
+#define SICP_NN16_OCC 4                     // waves per SIMD the register budget is set for (A/B builds: build.build_variant)
+#endif
 template <bool XFORM, bool CHAINED, int GS /* lanes per query: 16 (four queries per wave) or 8 (eight) */>
-__global__ __launch_bounds__(256, 4) void k_grid_nn16(
+__global__ __launch_bounds__(256, SICP_NN16_OCC) void k_grid_nn16(
     const IcpDev *__restrict__ st, const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
     const double *__restrict__ prev_p2, const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
     const uint32_t *__restrict__ order, long Q, GridGeom G,
@@ -762,10 +771,16 @@ __global__ __launch_bounds__(256, 4) void k_grid_nn16(
                 if (winner || (!found && gl == 0)) {
                     d2_out[q] = ok ? best : __builtin_inf();
                     idx_out[q] = ok ? idx_base + (int64_t)bidx : (int64_t)-1;
-                    if (p2_out || post.dist) {
+                    if (post.pack_idx) post.pack_idx[q] = __longlong_as_double(ok ? (long long)(idx_base + (int64_t)bidx) : -1ll);
+                    if (p2_out || post.dist || post.pack) {
                         double4 W = make_double4(0.0, 0.0, 0.0, 0.0);
                         if (ok) W = rec[bpos];
                         if (p2_out) { p2_out[3 * q] = W.x; p2_out[3 * q + 1] = W.y; p2_out[3 * q + 2] = W.z; }
+                        if (post.pack) {
+                            double *r5 = post.pack + 5 * q;
+                            r5[0] = ok ? best : __builtin_inf(); r5[1] = __longlong_as_double(ok ? (long long)(idx_base + (int64_t)bidx) : -1ll);
+                            r5[2] = W.x; r5[3] = W.y; r5[4] = W.z;
+                        }
                         // (normal and planarity are fetched here, not up front: this flavour lives at its register limit, and a
                         // full machine hides the round trip)
                         if (post.dist)
@@ -1522,24 +1537,78 @@ __global__ __launch_bounds__(256) void k_keep_stats(const double *__restrict__ d
 // Same integers as the launch-per-phase form, so median / MAD / keep mask are bit-identical; the kept statistics are folded
 // from the same per-block partials in the same order.
 // ------------------------------------------------------------------------------------
-constexpr int HS_MAXB = 2 * HS_PASSES + 3;
+// ---- the WINDOWED form of the two selections: three barriers instead of seven ---------------------------------------------------
+// From the second iteration of a run on, median and MAD are where the last iteration left them, give or take a little.  So:
+//   sweep 1   every block histograms the distances over H3_NB linear bins of a window med' -+ 1.5 MAD' around the previous
+//             median (two more bins catch what lies below / above); the bins are added up in global memory        -- barrier --
+//             every block reads the whole histogram: the bin that holds the median's rank, and -- counting outwards from that
+//             bin on both sides until half the keys are inside -- two SHELLS of five bins each in which the MAD's rank must end;
+//   sweep 2   the keys of the median's bin and of the two shells are collected (raw distances)                    -- barrier --
+//             every block sorts the median bin's keys in LDS and reads the exact median off them; forms |d - median| of the
+//             shells' keys, sorts those, and reads the MAD off them -- then CHECKS the premise: every key between the shells
+//             is nearer to the median than the MAD, every key outside is at least as far (binning is monotone in d, so probe
+//             values placed in the shells' end bins bound the two groups);
+//   sweep 3   keep mask + kept statistics, as before                                                             -- barrier --
+// Exact: the answers are order statistics of the same keys, and a premise that does not hold (the window missed: an estimate
+// that still moves, a distribution with a hole at the MAD) sends every block -- they all see the same numbers -- to the general
+// digit selection above, at the cost of the phases spent.  To keep that rare the window is only tried when the last two launches
+// of this run agree on the MAD to 20 % and on the median to 0.3 MAD.
+constexpr int H3_NB = 4096, H3_CAP = 2048;
+constexpr int HS_MAXB = 2 * HS_PASSES + 3 + 2;
 struct HselAll {
     GridBar bar;                   // (sicp_lanes.h) all zero when the buffer is new
     unsigned long long nxt[2];     // per statistic: smallest key above the prefix interval (~0 between launches; see hsel_state_init)
     unsigned ncand[2];             // per statistic: candidates appended (0 between launches)
     unsigned hist[3][HS_BINS];     // all zero between launches
     unsigned long long cand[2][HS_CAP];
+    // windowed form
+    double prior[2][2];            // (median, MAD) of the last two launches, [1] the latest
+    unsigned n_prior;              // how many of them this run has produced (the host restarts the count with every setup)
+    unsigned pad3[3];
+    unsigned whist[H3_NB + 2];     // all zero between launches
+    double wcand[2][H3_CAP];       // raw distances: the median bin's keys / the shells' keys
 };
+
+// ascending bitonic sort of n <= H3_CAP doubles in LDS (padded with +inf to a power of two), 256 threads
+__device__ void h3_sort(double *a, int n)
+{
+    int N = 64;
+    while (N < n) N <<= 1;
+    for (int i = n + (int)threadIdx.x; i < N; i += 256) a[i] = __builtin_inf();
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < N / 2; t += 256) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;        // the pair (i, i + j) of this step
+                const bool up = (i & k) == 0;
+                const double x = a[i], y = a[l];
+                if ((x > y) == up) { a[i] = y; a[l] = x; }
+            }
+            __syncthreads();
+        }
+}
+__device__ __forceinline__ int h3_bin(double d, double lo, double inv_bw)
+{
+    // monotone non-decreasing in d (IEEE subtraction, multiplication by a positive constant, min, floor): keys of a lower bin are
+    // below the keys of a higher one -- the only property the exactness argument uses
+    if (d < lo) return 0;
+    const double t = fmin((d - lo) * inv_bw, (double)H3_NB);
+    return 1 + (int)t;                                    // 1 .. H3_NB inside the window, H3_NB + 1 above it
+}
 
 __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
                                                   HselAll *__restrict__ S, unsigned long long bar_base, uint8_t *__restrict__ keep,
                                                   double *__restrict__ partial /*[3][NE_MAX_GRID]*/, double *__restrict__ out4,
                                                   double *__restrict__ out3, double *__restrict__ host_out, double seq,
-                                                  const IcpDev *__restrict__ st, unsigned absent /* test hook: see grid_barrier */)
+                                                  const IcpDev *__restrict__ st, unsigned absent /* test hook: see grid_barrier */,
+                                                  int use_prior /* the windowed form may be tried (launch >= 3 of a run) */)
 {
-    __shared__ unsigned hist[HS_BINS];
+    __shared__ unsigned hist[HS_BINS + 8];
     __shared__ unsigned scan[4];
     __shared__ unsigned long long sc[HS_CAP];
+    __shared__ double wk[H3_CAP];                    // windowed form: candidate keys being sorted
+    __shared__ int h3i[12];
+    __shared__ double h3d[8];
     __shared__ unsigned long long pnx[4], pick[2];
     __shared__ unsigned long long sel[3];            // picked by the bin's owner: prefix, rank inside it, its count
     __shared__ double red[4][3];
@@ -1552,8 +1621,194 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
     const long stride = (long)g * (256 * HS_UNROLL);
     double val[2] = {0.0, 0.0};                       // median, MAD
     unsigned long long m_first = 0;
+    bool have = false;                                // the windowed form delivered both statistics
+    // ---- windowed form (see the comment above HselAll) ----
+    const double pm1 = S->prior[1][0], pd1 = S->prior[1][1], pm0 = S->prior[0][0], pd0 = S->prior[0][1];
+    const unsigned n_prior = S->n_prior;              // (written by the previous launch's block 0: a kernel boundary ago)
+    // (not above ~260 k correspondences: there every block fills nearly every bin, and a million same-bin additions to the global
+    // histogram plus two thousand appends to one candidate counter cost what the saved barriers bring -- measured at 1 M: 98 us
+    // against 91)
+    bool try_w = use_prior && Q <= 262144 && n_prior >= 2u && pd1 > 0.0 && pd1 < __builtin_inf() && fabs(pd1 - pd0) <= 0.2 * pd1 &&
+                 fabs(pm1 - pm0) <= 0.3 * pd1;
+#ifdef SICP_HSEL_DEBUG
+    if (blockIdx.x == 0 && tid == 0 && !try_w)
+        printf("[hsel3] not tried: use_prior %d n_prior %u prior med %.6g mad %.6g (before: %.6g %.6g)\n", use_prior, n_prior, pm1, pd1, pm0, pd0);
+#endif
+    if (try_w) {
+        const double wlo = pm1 - 1.5 * pd1, inv_bw = (double)H3_NB / (3.0 * pd1);
+        for (int i = tid; i < H3_NB + 2; i += 256) hist[i] = 0;
+        __syncthreads();
+        for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {
+            double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < HS_UNROLL; ++u) {
+                const long i = base + u * 256 + tid;
+                f[u] = i < Q ? flag[i] : (uint8_t)0;
+                d[u] = i < Q ? dist[i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < HS_UNROLL; ++u) if (f[u]) atomicAdd(&hist[h3_bin(d[u], wlo, inv_bw)], 1u);
+        }
+        __syncthreads();
+        for (int i = tid; i < H3_NB + 2; i += 256) if (hist[i]) atomicAdd(&S->whist[i], hist[i]);
+        grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb), absent);
+        // every block: the complete histogram as inclusive prefix sums in LDS (thread t owns bins 16 t .. 16 t + 15, thread 0 the
+        // last two as well), then one thread finds the median's bin and the shells
+        unsigned h[16], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { h[j] = __hip_atomic_load(&S->whist[16 * tid + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mine += h[j]; }
+        const unsigned incl = wscan_u32(mine);
+        if (lane == 63) scan[wid] = incl;
+        __syncthreads();
+        unsigned run = incl - mine;
+        for (int w = 0; w < wid; ++w) run += scan[w];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { run += h[j]; hist[16 * tid + j] = run; }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned e = hist[H3_NB - 1];
+            e += __hip_atomic_load(&S->whist[H3_NB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); hist[H3_NB] = e;
+            e += __hip_atomic_load(&S->whist[H3_NB + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); hist[H3_NB + 1] = e;
+            const long m = e, r = m ? (m - 1) / 2 : 0;
+            int ok = m > 0 ? 1 : 0, bm = 0, js = 0;
+            if (ok) {
+                int a = 0, b = H3_NB + 1;                   // first bin whose inclusive prefix exceeds r
+                while (a < b) { const int c = (a + b) >> 1; if ((long)hist[c] > r) b = c; else a = c + 1; }
+                bm = a;
+                ok = bm >= 1 && bm <= H3_NB && (hist[bm] - hist[bm - 1]) <= (unsigned)H3_CAP;
+            }
+            if (ok) {
+                // smallest radius js (in bins) with at least r + 1 keys in bins [bm - js, bm + js]
+                const int jmax = (bm - 1 < H3_NB - bm) ? bm - 1 : H3_NB - bm;
+                int a = 0, b = jmax + 1;
+                while (a < b) { const int c = (a + b) >> 1; if ((long)(hist[bm + c] - hist[bm - c - 1]) > r) b = c; else a = c + 1; }
+                js = a;
+                ok = js >= 4 && js + 2 <= jmax;
+                if (ok) {
+                    // shells: the five bins at distance js - 2 .. js + 2 from the median's bin, on either side
+                    const unsigned c1 = hist[bm - js + 2] - hist[bm - js - 3], c2 = hist[bm + js + 2] - hist[bm + js - 3];
+                    ok = c1 + c2 <= (unsigned)H3_CAP;
+                }
+            }
+            h3i[0] = ok; h3i[1] = bm; h3i[2] = js;
+            h3i[3] = ok ? (int)(hist[bm] - hist[bm - 1]) : 0;                       // keys in the median's bin
+            h3i[4] = ok ? (int)hist[bm - 1] : 0;                                      // keys below it
+            h3i[5] = ok ? (int)(hist[bm + js - 3] - hist[bm - js + 2]) : 0;           // keys strictly between the shells
+            h3i[6] = ok ? (int)((hist[bm - js + 2] - hist[bm - js - 3]) + (hist[bm + js + 2] - hist[bm + js - 3])) : 0;
+            h3i[7] = (int)(m & 0x7fffffff);
+        }
+        __syncthreads();
+#ifdef SICP_HSEL_DEBUG
+        if (blockIdx.x == 0 && tid == 0)
+            printf("[hsel3] tried: ok %d bm %d js %d cnt_m %d below %d c_in %d c_sh %d m %d | prior med %.6g mad %.6g (before: %.6g %.6g)\n", h3i[0], h3i[1],
+                   h3i[2], h3i[3], h3i[4], h3i[5], h3i[6], h3i[7], pm1, pd1, pm0, pd0);
+#endif
+        bool okw = h3i[0] != 0;
+        const int bm = h3i[1], js = h3i[2], cnt_m = h3i[3], below_m = h3i[4], c_in = h3i[5], c_sh = h3i[6];
+        const long mw = h3i[7], rw = mw ? (mw - 1) / 2 : 0;
+        if (okw) {
+            // ---- sweep 2: the median bin's keys, the shells' keys, the smallest key above the median's bin ----
+            unsigned long long nxt = ~0ull;
+            for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {
+                double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
+#pragma unroll
+                for (int u = 0; u < HS_UNROLL; ++u) {
+                    const long i = base + u * 256 + tid;
+                    f[u] = i < Q ? flag[i] : (uint8_t)0;
+                    d[u] = i < Q ? dist[i] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < HS_UNROLL; ++u) {
+                    if (!f[u]) continue;
+                    const int b = h3_bin(d[u], wlo, inv_bw);
+                    if (b == bm) {
+                        const unsigned pos = atomicAdd(&S->ncand[0], 1u);
+                        if (pos < (unsigned)H3_CAP) __hip_atomic_store(&S->wcand[0][pos], d[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        if (b > bm) { const unsigned long long k = okey(d[u]); nxt = k < nxt ? k : nxt; }
+                        const int off = b < bm ? bm - b : b - bm;
+                        if (off >= js - 2 && off <= js + 2) {
+                            const unsigned pos = atomicAdd(&S->ncand[1], 1u);
+                            if (pos < (unsigned)H3_CAP) __hip_atomic_store(&S->wcand[1][pos], d[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+            { unsigned long long o;
+              o = lane_xor64<32>(nxt); nxt = o < nxt ? o : nxt;  o = lane_xor64<16>(nxt); nxt = o < nxt ? o : nxt;
+              o = lane_xor64<8>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<4>(nxt);  nxt = o < nxt ? o : nxt;
+              o = lane_xor64<2>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<1>(nxt);  nxt = o < nxt ? o : nxt; }
+            if (lane == 0) pnx[wid] = nxt;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long tn = pnx[0];
+                for (int w = 1; w < 4; ++w) tn = pnx[w] < tn ? pnx[w] : tn;
+                if (tn != ~0ull) atomicMin(&S->nxt[0], tn);
+            }
+            grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb), absent);
+            // ---- every block: exact median from the bin's keys ----
+            for (int i = tid; i < cnt_m; i += 256) wk[i] = __hip_atomic_load(&S->wcand[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            h3_sort(wk, cnt_m);
+            const long t = rw - below_m;                                   // rank inside the bin
+            const double ka = wk[t];
+            double kb = ka;
+            if (!(mw & 1)) {
+                if (t + 1 < cnt_m) kb = wk[t + 1];
+                else kb = oval64(__hip_atomic_load(&S->nxt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            const double med = (ka + kb) / 2.0;
+            __syncthreads();
+            // ---- exact MAD from the shells' keys.  The premise -- every key between the shells is nearer to the median than the
+            //      MAD, every key outside at least as far -- is checked with four probe values, one just inside either end of either
+            //      shell: binning is monotone, so a probe that h3_bin puts into a shell's first (last) bin is above (below) every
+            //      key of the bins before (after) it, and |x - median| is monotone in x on either side of the median ----
+            for (int i = tid; i < c_sh; i += 256) {
+                const double d = __hip_atomic_load(&S->wcand[1][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wk[i] = fabs(d - med);
+            }
+            __syncthreads();
+            h3_sort(wk, c_sh);
+            const double bw = 3.0 * pd1 / (double)H3_NB;
+            const double xl_out = wlo + ((double)(bm - js - 3) + 0.02) * bw, xl_in = wlo + ((double)(bm - js + 2) - 0.02) * bw;
+            const double xr_in = wlo + ((double)(bm + js - 3) + 0.02) * bw, xr_out = wlo + ((double)(bm + js + 2) - 0.02) * bw;
+            const long jr = rw - c_in;                                     // the MAD's rank among the shells' keys, if the premise holds
+            okw = jr >= 0 && jr + ((mw & 1) ? 0 : 1) < c_sh &&
+                  h3_bin(xl_out, wlo, inv_bw) >= bm - js - 2 && h3_bin(xl_in, wlo, inv_bw) <= bm - js + 2 &&
+                  h3_bin(xr_in, wlo, inv_bw) >= bm + js - 2 && h3_bin(xr_out, wlo, inv_bw) <= bm + js + 2 &&
+                  xl_in < med && med < xr_in;                              // (an even count whose upper middle key lies far out)
+            if (okw) {
+                const double v = wk[jr], v2 = (mw & 1) ? v : wk[jr + 1];
+                const double t_in = fmax(fabs(xl_in - med), fabs(xr_in - med));      // >= |d - median| of every key between the shells
+                const double t_out = fmin(fabs(xl_out - med), fabs(xr_out - med));   // <= |d - median| of every key outside them
+                okw = t_in < v && v2 <= t_out;
+                if (okw) { val[0] = med; val[1] = (v + v2) / 2.0; m_first = (unsigned long long)mw; have = true; }
+#ifdef SICP_HSEL_DEBUG
+                if (blockIdx.x == 0 && tid == 0)
+                    printf("[hsel3] premise %d: bm %d js %d cnt_m %d c_in %d c_sh %d jr %ld v %.6g v2 %.6g t_in %.6g t_out %.6g med %.6g\n", (int)okw, bm, js,
+                           cnt_m, c_in, c_sh, jr, v, v2, t_in, t_out, med);
+#endif
+            }
+#ifdef SICP_HSEL_DEBUG
+            else if (blockIdx.x == 0 && tid == 0) printf("[hsel3] rank outside the shells / probes: jr %ld c_sh %d c_in %d\n", jr, c_sh, c_in);
+#endif
+            __syncthreads();
+        }
+        // Missed (every block sees the same numbers, so every block is here): meet once more, so that nobody still reads what is
+        // wiped and reset below.  (A hit needs no extra meeting: the histogram was last read before the second barrier, and the
+        // counters are reset where the launch ends, as always.)
+        if (!have) grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb), absent);
+        for (unsigned i = blockIdx.x * 256u + (unsigned)tid; i < (unsigned)(H3_NB + 2); i += g * 256u)
+            __hip_atomic_store(&S->whist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!have && blockIdx.x == 0 && tid == 0) {
+            // (the general form touches these only in its collecting sweeps, behind a barrier of its own)
+            __hip_atomic_store(&S->nxt[0], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&S->ncand[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&S->ncand[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     int p = 0;                                        // running pass index over both statistics: hist[p % 3]
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < 2 && !have; ++which) {
         const double ctr = which ? val[0] : 0.0;
         unsigned long long prefix = 0, rank = 0, m = 0;
         unsigned cnt = 0;
@@ -1744,6 +1999,15 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
                 __threadfence_system();
                 __hip_atomic_store(host_out + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            // what the next launch's window is centred on (kept for two launches: it is only tried when they agree)
+            if (!bad && val[1] == val[1]) {
+                S->prior[0][0] = S->prior[1][0]; S->prior[0][1] = S->prior[1][1];
+                S->prior[1][0] = med; S->prior[1][1] = val[1];
+                // (a window that was tried and missed costs its phases: the next two launches take the general form)
+                S->n_prior = (try_w && !have) ? 1u : (n_prior < 2u ? n_prior + 1u : 2u);
+            } else {
+                S->n_prior = 0u;
+            }
             // leave the state as the next launch expects it (every other block is past its last use of these words)
             __hip_atomic_store(&S->nxt[0], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&S->nxt[1], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1788,7 +2052,7 @@ hipError_t hsel_state_init(hipStream_t s, void *state)
 // *bar_total is the host's running count of what the launches on this buffer have added to its barrier counter.
 hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
                                        double *out3, void *state, unsigned long long *bar_total, double *partial, double *host_out,
-                                       double seq, const IcpDev *st, unsigned absent)
+                                       double seq, const IcpDev *st, unsigned absent, bool use_prior)
 {
     static const long cap = [] { const char *e = std::getenv("SICP_HS_GRID"); const long v = e ? std::atol(e) : 0; return v > 0 && v <= 256 ? v : 256L; }();
     // every block must be resident at once (grid barrier): never more blocks than the device can hold (a partitioned device has
@@ -1796,7 +2060,7 @@ hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const 
     const long resident = resident_blocks((const void *)k_hsel_all, 256);
     const unsigned g = (unsigned)std::max<long>(1, std::min<long>(std::min<long>(cap, resident), (Q + 256 * HS_UNROLL - 1) / (256 * HS_UNROLL)));
     hipLaunchKernelGGL(k_hsel_all, dim3(g), dim3(256), 0, s, dist, flag, Q, (HselAll *)state, *bar_total, keep, partial, out4, out3,
-                       host_out, seq, st, absent);
+                       host_out, seq, st, absent, use_prior ? 1 : 0);
     *bar_total += (unsigned long long)HS_MAXB;
     return hipGetLastError();
 }

@@ -49,6 +49,9 @@ struct PostMatch {
     float min_planarity;
     double *dist;                 // (Q) out
     uint8_t *flag;                // (Q) out: 1 = matched and planar enough in both clouds
+    double *pack;                 // nullable, (Q, 5) out: the exchange's (d2, index bits, x, y, z) record of this rank's winner --
+                                  // what k_pack_best would re-read 48 bytes per query for, in a launch of its own
+    double *pack_idx;             // nullable, (Q) out: query shards' slim record, the matched index as int64 bits (k_pack_idx's output)
 };
 struct TailArgs {
     double obs[6], ow[6];
@@ -139,12 +142,15 @@ void launch_unpack_idx_postmatch(hipStream_t s, const double *gathered, long Q, 
                                  const float *planarity, float min_planarity, const float *pl2, long pl2_n, const IcpDev *st,
                                  int64_t *idx, double *p2, double *dist, uint8_t *flag);
 void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, double *d2, int64_t *idx, double *p2);
+void launch_lexmin_postmatch(hipStream_t s, const double *g, int world, long Q, const double *qx, const double *qy, const double *qz,
+                             const float *normals, const float *planarity, float min_planarity, const float *pl2, long pl2_n,
+                             const IcpDev *st, double *d2, int64_t *idx, double *p2, double *dist, uint8_t *flag);
 size_t reject_select_scratch_bytes();
 long resident_blocks(const void *kernel, int threads);   // blocks the current device holds at once (grid-barrier kernels)
 hipError_t hsel_state_init(hipStream_t s, void *state);
 hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
                                        double *out3, void *state, unsigned long long *bar_total, double *partial, double *host_out,
-                                       double seq, const IcpDev *st, unsigned absent = 0);
+                                       double seq, const IcpDev *st, unsigned absent = 0, bool use_prior = false);
 hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, double *out3,
                             void *state, unsigned long long *small, double *partial, unsigned *ticket, double *host_out = nullptr,
                             double seq = 0.0, const IcpDev *st = nullptr);

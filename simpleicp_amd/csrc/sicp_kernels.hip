@@ -1311,6 +1311,38 @@ __global__ void k_lexmin_gathered(const double *__restrict__ g, int world, long 
     if (p2) { p2[3 * q] = bx; p2[3 * q + 1] = by; p2[3 * q + 2] = bz; }
 }
 
+// the two in one launch for a chained iteration behind a cloud-shard exchange: job-wide winner per query (the single-GPU rule:
+// lexicographic minimum on (d2, global index) over the ranks' records), then what k_postmatch does with it -- signed
+// point-to-plane distance under the run's current H and the planarity verdict (corrpts.py:139-163,195-211)
+__global__ void k_lexmin_postmatch(const double *__restrict__ g, int world, long Q, const double *__restrict__ qx,
+                                   const double *__restrict__ qy, const double *__restrict__ qz, const float *__restrict__ normals,
+                                   const float *__restrict__ planarity, float min_planarity, const float *__restrict__ pl2, long pl2_n,
+                                   const IcpDev *__restrict__ st, double *__restrict__ d2, int64_t *__restrict__ idx,
+                                   double *__restrict__ p2, double *__restrict__ dist, uint8_t *__restrict__ flag)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (st->stop) return;
+    if (q >= Q) return;
+    const Xf H = st->H;
+    double bd = __builtin_inf(), bx = 0, by = 0, bz = 0;
+    int64_t bi = -1;
+    for (int r = 0; r < world; ++r) {
+        const double *rec = g + ((long)r * Q + q) * 5;
+        const double d = rec[0];
+        const int64_t i = (int64_t)__double_as_longlong(rec[1]);
+        if (i >= 0 && (bi < 0 || d < bd || (d == bd && i < bi))) { bd = d; bi = i; bx = rec[2]; by = rec[3]; bz = rec[4]; }
+    }
+    d2[q] = bi >= 0 ? bd : __builtin_inf();
+    idx[q] = bi;
+    p2[3 * q] = bx; p2[3 * q + 1] = by; p2[3 * q + 2] = bz;
+    double X, Y, Z;
+    xform(H, bx, by, bz, X, Y, Z);
+    dist[q] = plane_dist(X - qx[q], Y - qy[q], Z - qz[q], normals[3 * q], normals[3 * q + 1], normals[3 * q + 2]);
+    bool f = bi >= 0 && planarity[q] >= min_planarity;
+    if (f && pl2) f = bi < pl2_n && pl2[bi] >= min_planarity;        // corrpts.py:158-163 (NaN fails)
+    flag[q] = f ? 1 : 0;
+}
+
 // ---- query shards (every rank holds the WHOLE searched cloud): the exchange carries nothing but the matched index ----
 // 8 bytes per query instead of the 40-byte (d2, idx, xyz) record: the coordinates are this rank's own to look up, the squared
 // distance is not used after the match, and the point-to-plane distance is formed from the looked-up point anyway.
@@ -1366,6 +1398,13 @@ void launch_unpack_idx_postmatch(hipStream_t s, const double *gathered, long Q, 
 {
     hipLaunchKernelGGL(k_unpack_idx_postmatch, dim3(cdiv(Q, 256)), dim3(256), 0, s, gathered, Q, cx, cy, cz, idx_base, n, qx, qy, qz,
                        normals, planarity, min_planarity, pl2, pl2_n, st, idx, p2, dist, flag);
+}
+void launch_lexmin_postmatch(hipStream_t s, const double *g, int world, long Q, const double *qx, const double *qy, const double *qz,
+                             const float *normals, const float *planarity, float min_planarity, const float *pl2, long pl2_n,
+                             const IcpDev *st, double *d2, int64_t *idx, double *p2, double *dist, uint8_t *flag)
+{
+    hipLaunchKernelGGL(k_lexmin_postmatch, dim3(cdiv(Q, 256)), dim3(256), 0, s, g, world, Q, qx, qy, qz, normals, planarity,
+                       min_planarity, pl2, pl2_n, st, d2, idx, p2, dist, flag);
 }
 void launch_lexmin_gathered(hipStream_t s, const double *g, int world, long Q, double *d2, int64_t *idx, double *p2)
 {

@@ -792,3 +792,56 @@ def test_download_both_equals_the_two_downloads(ctx, n):
     assert np.array_equal(np.column_stack((x, y, z)), rows)
     with pytest.raises(_lib.BackendError):
         ctx._chk(ctx._L.sicp_cloud_download_both(ctx._h, _lib.MOV, None, _lib._ptr(x), None, None))
+
+
+@pytest.mark.parametrize("Q,kind", [(40_000, "plain"), (40_000, "quantised"), (40_000, "layers"), (150_000, "plain")])
+def test_windowed_rejection_equals_the_general_form(Q, kind):
+    """Large-Q rejection, windowed form (three grid barriers: a linear histogram around the previous iteration's median, the
+    median bin's and the MAD shells' keys collected and sorted, premise checked on the keys -- tried from a run's third
+    iteration on) against the general digit selection (SICP_HSEL_WINDOW=0) and the oracle: median, MAD, counts and keep masks
+    bit for bit over ten chained iterations, on plain data, on quantised data (thousands of exactly equal distances) and on
+    data whose distances sit in a few layers (windows that must miss and fall back)."""
+    import os
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(Q + len(kind))
+    n = max(2 * Q, 120_000)
+    P = _surface(n, 77)
+    x_true = np.array([0.003, -0.002, 0.004, 0.2, -0.1, 0.08])
+    noise = rng.normal(0, 0.01, P.shape)
+    if kind == "layers":
+        noise[:, 2] = rng.choice([-0.03, 0.0, 0.03], len(P))          # distances in three thin layers: holes where the MAD lies
+    Xm = orc.transform(np.linalg.inv(orc.params_to_H(x_true)), P + noise)
+    if kind == "quantised":
+        P, Xm = np.round(P, 2), np.round(Xm, 2)
+    sel = np.sort(rng.choice(n, Q, replace=False))
+    z = np.zeros(6)
+    out = {}
+    for window in ("1", "0"):
+        os.environ["SICP_HSEL_WINDOW"] = window
+        try:
+            c = _lib.Context(0)
+        finally:
+            del os.environ["SICP_HSEL_WINDOW"]
+        with c:
+            c.upload(_lib.FIX, P); c.upload(_lib.MOV, Xm)
+            nv, pl = c.estimate_normals(_lib.FIX, sel, 10)
+            c.icp_setup(sel, nv, pl)
+            whole = c.icp_run(z, z, z, 0.3, 1.0, max_iterations=10, min_change=0.0)
+            _, _, keep, resid = c.icp_state()
+            # ... and a host-driven loop on the same context (one launch per call; priors carried over from the run above)
+            x, host = z.copy(), []
+            c.icp_setup(sel, nv, pl)
+            for it in range(5):
+                R = c.icp_iterate(x, z, z, 0.3, 1.0)
+                host.append((R.n_planar, R.median, R.mad, R.n_kept, tuple(R.x[:])))
+                x = np.array(R.x[:])
+            out[window] = ([(w.n_planar, w.median, w.mad, w.n_kept, w.dist_mean, w.dist_std, tuple(w.x[:])) for w in whole], keep, resid, host)
+    a, b = out["1"], out["0"]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    # the oracle on the host-driven iterations (every one of them a launch that may use the window: the run before left its priors;
+    # the chained run carries sin / cos forward on the device, so only the host-driven loop meets the oracle's H bit for bit)
+    x = z.copy()
+    for it in range(3):
+        o = orc.icp_iteration(Xm, P[sel], nv, pl, x, x, 1.0, z, z, 0.3)
+        assert (a[3][it][1], a[3][it][2], a[3][it][3]) == (o["median"], o["mad"], int(o["keep"].sum()))
+        x = np.array(a[3][it][4])
