@@ -1,4 +1,4 @@
-"""Brute-force (filtered scan) iterations only, for profiling one flavour:  SICP_FSCAN=mfma|record|inline python scripts/bf_only.py [n] [Q]"""
+"""Brute-force (filtered scan) iterations only, for profiling one flavour:  SICP_FSCAN=record|inline python scripts/bf_only.py [n] [Q]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

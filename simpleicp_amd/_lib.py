@@ -23,7 +23,7 @@ PART_CLOUD, PART_QUERIES = 0, 1
 K_KNN1, K_KNNK, K_NORMALEQ, K_SELECT, K_XCHG = 0, 1, 2, 3, 4
 ABI_VERSION = 4          # include/simpleicp_hip.h SICP_ABI_VERSION this binding was written for
 KERNEL_NAMES = {K_KNN1: "match", K_KNNK: "knnk_scan", K_NORMALEQ: "solve", K_SELECT: "reject_select", K_XCHG: "exchange"}
-MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1_frec", 4: "k_knn1_fmfma", 5: "k_grid_nn16"}
+MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1_frec", 5: "k_grid_nn16"}
 
 EXPORTS = [
     "sicp_abi_version", "sicp_last_error", "sicp_device_count", "sicp_ctx_create", "sicp_ctx_destroy",

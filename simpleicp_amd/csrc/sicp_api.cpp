@@ -258,8 +258,7 @@ struct sicp_ctx {
     DevBuf<double> x_send, x_recv; // exchange records: [Q][5] and [world][Q][5]
     int fs_blocks_per_cu[2] = {0, 0};   // occupancy of k_knn1_fscan<128>, <256>
     int fr_blocks_per_cu[2] = {0, 0};   // occupancy of k_knn1_frec<128>, <256>
-    int fscan_variant = 0;         // SICP_FSCAN = record (default: VALU filter, candidates recorded) | mfma (filter on the FP32 matrix pipe) | inline
-    int fm_blocks_per_cu = 0;      // occupancy of k_knn1_fmfma
+    int fscan_variant = 0;         // SICP_FSCAN = record (default: VALU filter, candidates recorded) | inline
     long fscan_cap = 0;            // SICP_FSCAN_CAP: recorded groups per query (tests force overflow with tiny values)
     DevBuf<uint32_t> hit_cnt, hit_list;
     int knn1_mode = 0;             // SICP_KNN1 = exact | filter | grid: force one 1-NN flavour (A/B + tests); 0 = auto
@@ -278,7 +277,6 @@ struct sicp_ctx {
     bool knn_sweep = true;         // SICP_KNN_SWEEP=0: k extraction rounds (k_grid_knn) + k_normals instead of the one-sweep kernel
     DevBuf<double> bound_p2, bound_d2;   // cold search: nearest subsample point per query (coordinates = the bound) + scratch
     DevBuf<int64_t> bound_idx;
-    bool reject_split = true;      // SICP_REJECT_SPLIT=0: mid-Q distances inside the single-workgroup rejection kernel
     int coarse_iters = 1;          // SICP_COARSE_ITERS: chained iterations (from a cold start) whose search is bounded by the subsample's
     long coarse_min_n = 262144;    // ... for clouds of at least this many points
     long nn16_min_q = 32768;       // SICP_NN16_MIN_Q: from this many queries per launch on the grid search runs four queries per wave
@@ -324,7 +322,6 @@ struct sicp_ctx {
     int test_barrier_fault = 0;    // SICP_TEST_BARRIER_FAULT = 1 / 2 (tests only): the rejection's / the solver's grid barrier expects a block that never comes
     bool hsel_window = true;       // SICP_HSEL_WINDOW=0: never the windowed (three-barrier) form of the large-Q rejection
     long hsel_run_launches = 0;    // chained rejection launches since the last setup (the window needs two of them behind it)
-    bool hsel_one_launch = true;   // SICP_HSEL=launches: the launch-per-phase form (A/B)
     bool hsel_dirty = false;
     int nn_group = 0;              // SICP_NN_GROUP=8|16: lanes per query of the many-queries search (0: chosen per launch)
     bool match_epilogue = true;    // SICP_MATCH_EPILOGUE=0: distances + verdicts by k_postmatch even without an exchange (A/B)
@@ -579,8 +576,7 @@ void plan_chunks(const sicp_ctx *c, long npad, long qblocks, size_t bytes_per_ch
     *nchunks = (int)((tiles + tiles_per_chunk - 1) / tiles_per_chunk);
 }
 
-// median / MAD rejection + keep mask + kept statistics for Q > REJECT_MAX_Q: ONE launch with grid barriers (default) or the
-// launch-per-phase form (SICP_HSEL=launches)
+// median / MAD rejection + keep mask + kept statistics for Q > REJECT_MAX_Q: ONE launch with grid barriers
 int reject_select(sicp_ctx *c, long Q, double *host_out, double seq, const IcpDev *st)
 {
     const size_t words = (reject_select_scratch_bytes() + 7) / 8;
@@ -589,21 +585,14 @@ int reject_select(sicp_ctx *c, long Q, double *host_out, double seq, const IcpDe
         HIPCHK(hsel_state_init(c->stream, c->rj_keys.p));                    // the one-launch form keeps its state clean from here on
         c->hsel_bar = 0;
     }
-    hipError_t e;
-    if (c->hsel_one_launch) {
-        if (c->hsel_dirty) {                                                 // the other form ran in between (tests): start clean
-            HIPCHK(hsel_state_init(c->stream, c->rj_keys.p));
-            c->hsel_bar = 0; c->hsel_dirty = false;
-        }
-        e = reject_by_select_one_launch(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
-                                        &c->hsel_bar, c->ne_partial.p, host_out, seq, st, c->test_barrier_fault == 1 ? 1u : 0u,
-                                        c->hsel_window && st != nullptr && c->hsel_run_launches >= 2);
-        if (st) ++c->hsel_run_launches;
-    } else {
-        c->hsel_dirty = true;
-        e = reject_by_select(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
-                             (unsigned long long *)(c->small.p + 56), c->ne_partial.p, c->ticket.p, host_out, seq, st);
+    if (c->hsel_dirty) {                                                     // interrupted launches may have left anything: start clean
+        HIPCHK(hsel_state_init(c->stream, c->rj_keys.p));
+        c->hsel_bar = 0; c->hsel_dirty = false;
     }
+    const hipError_t e = reject_by_select_one_launch(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->small.p + 4, c->rj_keys.p,
+                                                     &c->hsel_bar, c->ne_partial.p, host_out, seq, st, c->test_barrier_fault == 1 ? 1u : 0u,
+                                                     c->hsel_window && st != nullptr && c->hsel_run_launches >= 2);
+    if (st) ++c->hsel_run_launches;
     if (e != hipSuccess) return fail(SICP_ERR_HIP, "rejection by digit selection failed: %s", hipGetErrorString(e));
     return SICP_OK;
 }
@@ -973,16 +962,12 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
     const int blk = (Q > 1024) ? 256 : 128;                  // 8 queries per lane either way
     const long qblocks = (Q + blk * FS_R - 1) / (blk * FS_R);
     const int ftiles = (int)(cl.npad / FS_TILE);
-    // (a) record + fix-up: the streaming kernel carries no FP64 state; exact work in a second, tiny kernel.
-    //     Default: the filter on the VALU (k_knn1_frec, the faster one as measured); SICP_FSCAN=mfma runs it on the
-    //     FP32 matrix pipe (k_knn1_fmfma).
+    // (a) record + fix-up: the streaming kernel carries no FP64 state; exact work in a second, tiny kernel.  (The filter runs on the
+    //     vector ALU: the FP32 matrix-pipe form measured slower -- profiles/r2/README.md -- and was removed in round 4.)
     if (c->fscan_variant != 1) {
-        const bool mfma = c->fscan_variant == 2;
-        const int blk_r = mfma ? 256 : blk;
-        const long qblocks_r = mfma ? (Q + 1023) / 1024 : qblocks;
-        int &bpr = mfma ? c->fm_blocks_per_cu : c->fr_blocks_per_cu[blk == 256];
-        if (bpr == 0) bpr = mfma ? fmfma_blocks_per_cu() : frec_blocks_per_cu(blk);
-        long nparts = std::max<long>(1, ((long)cus * bpr) / qblocks_r);
+        int &bpr = c->fr_blocks_per_cu[blk == 256];
+        if (bpr == 0) bpr = frec_blocks_per_cu(blk);
+        long nparts = std::max<long>(1, ((long)cus * bpr) / qblocks);
         nparts = std::min<long>(nparts, ftiles);
         uint32_t cap = c->fscan_cap > 0 ? (uint32_t)c->fscan_cap
                                         : (uint32_t)std::max<long>(32, std::min<long>(4096, (256L << 20) / qpad));
@@ -992,20 +977,16 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
         uint32_t *d_over = c->hit_cnt.p + qpad;
         {
             Timed t(c, SICP_K_KNN1);
-            if (mfma)
-                launch_knn1_fmfma(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, (int)qblocks_r, c->bound.p, cl.x(), cl.y(), cl.z(),
-                                  ftiles, (int)nparts, H, rmax_t, c->hit_cnt.p, c->hit_list.p, cap);
-            else
-                launch_knn1_frec(c->stream, blk_r, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, (int)qblocks_r, c->bound.p, cl.x(), cl.y(),
-                                 cl.z(), ftiles, (int)nparts, H, rmax_t, c->hit_cnt.p, c->hit_list.p, cap);
+            launch_knn1_frec(c->stream, blk, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, (int)qblocks, c->bound.p, cl.x(), cl.y(),
+                             cl.z(), ftiles, (int)nparts, H, rmax_t, c->hit_cnt.p, c->hit_list.p, cap);
         }
         launch_knn1_fixup(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, cl.x(), cl.y(), cl.z(), H, c->hit_cnt.p,
-                          c->hit_list.p, cap, mfma ? 1u : (uint32_t)FS_G, max_d2, cl.idx_base, d2_out, idx_out, p2_out, d_over);
+                          c->hit_list.p, cap, (uint32_t)FS_G, max_d2, cl.idx_base, d2_out, idx_out, p2_out, d_over);
         HIPCHK(hipGetLastError());
         uint32_t *h_over = (uint32_t *)(c->h_small + 62);
         HIPCHK(hipMemcpyAsync(h_over, d_over, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         CHK(sync(c));
-        if (*h_over == 0) { c->last_match_kernel = mfma ? 4 : 3; return SICP_OK; }
+        if (*h_over == 0) { c->last_match_kernel = 3; return SICP_OK; }
         // some query's candidate list overflowed (poor bound): fall through to the self-contained kernel
     }
     // (b) self-contained variant: exact re-evaluation inside the scan (tightens its own threshold)
@@ -1187,18 +1168,16 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_KNN_SWEEP")) c->knn_sweep = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_KNN_BATCH")) c->knn_batch = std::atol(e);
     if (const char *e = std::getenv("SICP_NN16_MIN_Q")) c->nn16_min_q = std::atol(e);
-    if (const char *e = std::getenv("SICP_REJECT_SPLIT")) c->reject_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_COARSE_ITERS")) c->coarse_iters = std::atoi(e);
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
     if (const char *e = std::getenv("SICP_LM")) c->lm_one_launch = std::strcmp(e, "launches") != 0;
     if (const char *e = std::getenv("SICP_HSEL_WINDOW")) c->hsel_window = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_TEST_BARRIER_FAULT")) c->test_barrier_fault = std::atoi(e);
-    if (const char *e = std::getenv("SICP_HSEL")) c->hsel_one_launch = std::strcmp(e, "launches") != 0;
     if (const char *e = std::getenv("SICP_NN_GROUP")) { const int v = std::atoi(e); if (v == 8 || v == 16) c->nn_group = v; }
     if (const char *e = std::getenv("SICP_MATCH_EPILOGUE")) c->match_epilogue = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_XCHG_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) c->xchg_timeout_s = v; }
     if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
-    if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : !std::strcmp(e, "mfma") ? 2 : 0;
+    if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : 0;
     if (const char *e = std::getenv("SICP_FSCAN_CAP")) c->fscan_cap = std::atol(e);
     if (const char *e = std::getenv("SICP_GRID_TARGET")) { const double t = std::atof(e); if (t >= 0.25 && t <= 1024) { c->grid_target = t; c->grid_target_forced = true; } }
     c->host_trace = std::getenv("SICP_HOST_TRACE") != nullptr;
@@ -1787,18 +1766,12 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 // distances + rejections (corrpts.py:139-211), kept-distance statistics, then the solver chain
                 if (Q <= REJECT_MAX_Q) {
                     Timed t(c, SICP_K_SELECT);
-                    if (c->reject_split || post_done) {
-                        // distances + flags by the whole machine (the match kernel's epilogue, or k_postmatch behind an exchange),
-                        // then selection + keep mask + statistics by one workgroup on the 9 bytes per correspondence it still has to read
-                        if (!post_done)
-                            launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
-                                             A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
-                        launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->icp_dev.p, c->small.p + 4);
-                    } else {
-                        launch_dist_reject_stats(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q,
-                                                 A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->keep.p, c->small.p,
-                                                 c->small.p + 4, c->icp_dev.p);
-                    }
+                    // distances + flags by the whole machine (the match kernel's epilogue, or k_postmatch behind an exchange), then
+                    // selection + keep mask + statistics by one workgroup on the 9 bytes per correspondence it still has to read
+                    if (!post_done)
+                        launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
+                                         A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
+                    launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->icp_dev.p, c->small.p + 4);
                 } else {
                     if (!post_done)
                         launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,

@@ -1254,276 +1254,13 @@ __device__ __forceinline__ double oval64(unsigned long long k)
 }
 
 constexpr int HS_BINS = 4096, HS_CAP = 256, HS_PASSES = 6, HS_UNROLL = 4;
-struct HselState {
-    unsigned long long prefix;     // digits selected so far (low bits zero)
-    unsigned long long rank;       // wanted rank among the keys that match the prefix
-    unsigned long long m;          // number of valid keys (pass 0)
-    unsigned long long nxt;        // finish: smallest key above the prefix interval
-    int fixed;                     // number of leading bits the prefix fixes
-    int done;                      // the prefix interval holds <= HS_CAP keys, or every bit is fixed
-    unsigned cnt;                  // keys inside the prefix interval
-    unsigned ncand;                // finish: candidates appended
-    unsigned ticket;
-    unsigned pad;
-    unsigned hist[HS_BINS];
-    unsigned long long cand[HS_CAP];
-};
-
-__device__ __forceinline__ bool last_block_arrives(unsigned *ticket, int *is_last_lds)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *is_last_lds = (t == gridDim.x - 1) ? 1 : 0;
-        if (*is_last_lds) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    return *is_last_lds != 0;
-}
-
-// the same for a block whose only publications are device-scope ATOMICS (histogram bins, candidate appends, minima):
-// they are performed at the coherence point already, no write-back of plain stores to order before the ticket
-__device__ __forceinline__ bool last_block_arrives_atomics(unsigned *ticket, int *is_last_lds)
-{
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *is_last_lds = (t == gridDim.x - 1) ? 1 : 0;
-        if (*is_last_lds) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    return *is_last_lds != 0;
-}
-
-// key of correspondence i for the statistic at hand: the distance itself (median) or |d - median| (MAD); ~0 = not a candidate
-template <bool ABS>
-__device__ __forceinline__ unsigned long long hs_key(double d, uint8_t f, double ctr)
-{
-    return f ? okey(ABS ? fabs(d - ctr) : d) : ~0ull;
-}
-
-template <bool ABS>
-__global__ __launch_bounds__(256) void k_hsel_pass(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q, int pass,
-                                                   HselState *__restrict__ S, const double *__restrict__ center,
-                                                   const IcpDev *__restrict__ st)
-{
-    __shared__ unsigned hist[HS_BINS];
-    __shared__ unsigned scan[4];
-    __shared__ int is_last;
-    if (st && st->stop) return;
-    if (S->done) return;                                        // (written by an earlier launch: uniform)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int bits = pass < 5 ? 12 : 4, shift = pass < 5 ? 52 - 12 * pass : 0;
-    const unsigned mask = (1u << bits) - 1u;
-    const unsigned long long prefix = S->prefix;
-    const double ctr = ABS ? center[0] : 0.0;
-    for (int i = tid; i < HS_BINS; i += 256) hist[i] = 0;
-    __syncthreads();
-    const long stride = (long)gridDim.x * (256 * HS_UNROLL);
-    for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {      // block-uniform trip count
-        double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
-#pragma unroll
-        for (int u = 0; u < HS_UNROLL; ++u) {                   // all loads first
-            const long i = base + u * 256 + tid;
-            f[u] = i < Q ? flag[i] : (uint8_t)0;
-            d[u] = i < Q ? dist[i] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < HS_UNROLL; ++u) {
-            const unsigned long long k = hs_key<ABS>(d[u], f[u], ctr);
-            bool act = f[u] && (pass == 0 || (k >> (shift + bits)) == (prefix >> (shift + bits)));
-            const unsigned bin = (unsigned)(k >> shift) & mask;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const unsigned long long am = __ballot(act);
-                if (am == 0) break;
-                const int leader = __ffsll((long long)am) - 1;
-                const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
-                const unsigned long long same = __ballot(act && bin == b0);
-                if (lane == leader) atomicAdd(&hist[b0], (unsigned)__popcll(same));
-                act = act && bin != b0;
-            }
-            if (act) atomicAdd(&hist[bin], 1u);
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < HS_BINS; i += 256) if (hist[i]) atomicAdd(&S->hist[i], hist[i]);
-    if (!last_block_arrives_atomics(&S->ticket, &is_last)) return;
-    // thread t owns bins 16t .. 16t+15 of the complete histogram
-    unsigned h[16], mine = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { h[j] = S->hist[16 * tid + j]; mine += h[j]; S->hist[16 * tid + j] = 0; }
-    const unsigned incl = wscan_u32(mine);
-    if (lane == 63) scan[tid >> 6] = incl;
-    const unsigned long long rank_in = S->rank;                 // (read by all before the owner of the bin rewrites it)
-    __syncthreads();
-    unsigned before = 0;
-    for (int w = 0; w < (tid >> 6); ++w) before += scan[w];
-    const unsigned long long total = (unsigned long long)scan[0] + scan[1] + scan[2] + scan[3];
-    const unsigned long long m = pass == 0 ? total : S->m;
-    const unsigned long long rank = pass == 0 ? (m ? (m - 1) / 2 : 0) : rank_in;
-    if (tid == 0) {
-        S->ticket = 0;
-        if (pass == 0) { S->m = m; if (m == 0) { S->done = 1; S->cnt = 0; S->fixed = 0; } }
-    }
-    unsigned long long acc = before + incl - mine;
-    if (m > 0 && rank >= acc && rank < acc + mine) {
-        int j = 0;
-        while (rank >= acc + h[j]) { acc += h[j]; ++j; }
-        S->prefix = prefix | ((unsigned long long)(16 * tid + j) << shift);
-        S->rank = rank - acc;
-        S->cnt = h[j];
-        S->fixed = 64 - shift;
-        S->done = (h[j] <= (unsigned)HS_CAP || pass == HS_PASSES - 1) ? 1 : 0;
-    }
-}
-
-// collects the survivors of the prefix interval, finds the smallest key above it, and (last block) ranks the survivors:
-// dst[0] = mean of the two middle values = np.median (NaN without candidates).  Resets the state for the next statistic.
-template <bool ABS>
-__global__ __launch_bounds__(256) void k_hsel_finish(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
-                                                     HselState *__restrict__ S, const double *__restrict__ center,
-                                                     double *__restrict__ dst, unsigned long long *__restrict__ m_out,
-                                                     const IcpDev *__restrict__ st)
-{
-    __shared__ unsigned long long sc[HS_CAP];
-    __shared__ unsigned long long pnx[4], pick[2];
-    __shared__ int is_last;
-    if (st && st->stop) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const unsigned long long prefix = S->prefix, m = S->m;
-    const int fixed = S->fixed;
-    const unsigned cnt = S->cnt;
-    const bool collect = cnt <= (unsigned)HS_CAP;               // otherwise every bit is fixed: the interval is ONE value
-    const unsigned long long hi = fixed >= 64 ? prefix : (prefix | (~0ull >> fixed));
-    const double ctr = ABS ? center[0] : 0.0;
-    unsigned long long nxt = ~0ull;
-    if (m > 0) {
-        const long stride = (long)gridDim.x * (256 * HS_UNROLL);
-        for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {
-            double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
-#pragma unroll
-            for (int u = 0; u < HS_UNROLL; ++u) {
-                const long i = base + u * 256 + tid;
-                f[u] = i < Q ? flag[i] : (uint8_t)0;
-                d[u] = i < Q ? dist[i] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < HS_UNROLL; ++u) {
-                if (!f[u]) continue;
-                const unsigned long long k = hs_key<ABS>(d[u], f[u], ctr);
-                if (k > hi) nxt = k < nxt ? k : nxt;
-                else if (collect && k >= prefix) { const unsigned pos = atomicAdd(&S->ncand, 1u); if (pos < (unsigned)HS_CAP) __hip_atomic_store(&S->cand[pos], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            }
-        }
-    }
-    { unsigned long long o;
-      o = lane_xor64<32>(nxt); nxt = o < nxt ? o : nxt;  o = lane_xor64<16>(nxt); nxt = o < nxt ? o : nxt;
-      o = lane_xor64<8>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<4>(nxt);  nxt = o < nxt ? o : nxt;
-      o = lane_xor64<2>(nxt);  nxt = o < nxt ? o : nxt;  o = lane_xor64<1>(nxt);  nxt = o < nxt ? o : nxt; }
-    if (lane == 0) pnx[tid >> 6] = nxt;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long tn = pnx[0];
-        for (int w = 1; w < 4; ++w) tn = pnx[w] < tn ? pnx[w] : tn;
-        if (tn != ~0ull) atomicMin(&S->nxt, tn);
-    }
-    if (!last_block_arrives(&S->ticket, &is_last)) return;
-    const unsigned long long rank = S->rank, above = S->nxt;
-    if (tid < 2) pick[tid] = prefix;                            // (single-value interval: both middles are that value unless ...)
-    if (collect) {
-        if (tid < (int)cnt) sc[tid] = S->cand[tid];
-        __syncthreads();
-        if (tid < (int)cnt) {
-            const unsigned long long k = sc[tid];
-            unsigned r = 0;
-            for (unsigned j = 0; j < cnt; ++j) { const unsigned long long o = sc[j]; r += (o < k || (o == k && j < (unsigned)tid)) ? 1u : 0u; }
-            if (r == rank) pick[0] = k;
-            if (r == rank + 1) pick[1] = k;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long ka = pick[0];
-        unsigned long long kb = ka;
-        if (!(m & 1)) kb = (rank + 1 < cnt) ? pick[1] : above;    // even count: the next value up, inside the interval or just above it
-        dst[0] = m > 0 ? (oval64(ka) + oval64(kb)) / 2.0 : __builtin_nan("");
-        if (m_out) *m_out = m;
-        S->prefix = 0; S->rank = 0; S->m = 0; S->nxt = ~0ull; S->fixed = 0; S->done = 0; S->cnt = 0; S->ncand = 0; S->ticket = 0;
-    }
-}
-
-// keep mask of the rejection (corrpts.py:182-188: |d - median| <= 3 * MAD among the flagged) and, in the same pass, count /
-// mean / std of the kept distances -- sums taken relative to the median, so one pass loses nothing to cancellation.
-// Block partials are folded by the last block to arrive in a fixed order.  out4 = (m, median, mad, n_kept), out3 = (n, mean, std).
-__global__ __launch_bounds__(256) void k_keep_stats(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
-                                                    const double *__restrict__ med_mad, const unsigned long long *__restrict__ m_in,
-                                                    uint8_t *__restrict__ keep, double *__restrict__ partial /*[3][NE_MAX_GRID]*/,
-                                                    unsigned *__restrict__ ticket, double *__restrict__ out4, double *__restrict__ out3,
-                                                    double *__restrict__ host_out, double seq, const IcpDev *__restrict__ st)
-{
-    __shared__ double red[4][3];
-    __shared__ int is_last;
-    if (st && st->stop) return;
-    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-    const double med = med_mad[0], bound = 3 * med_mad[1];
-    double n = 0, s1 = 0, s2 = 0;
-    const long stride = (long)gridDim.x * (256 * HS_UNROLL);
-    for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {
-        double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
-#pragma unroll
-        for (int u = 0; u < HS_UNROLL; ++u) {
-            const long i = base + u * 256 + tid;
-            f[u] = i < Q ? flag[i] : (uint8_t)0;
-            d[u] = i < Q ? dist[i] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < HS_UNROLL; ++u) {
-            const long i = base + u * 256 + tid;
-            const double e = d[u] - med;
-            const bool k = f[u] && fabs(e) <= bound;
-            if (i < Q) keep[i] = k ? 1 : 0;
-            if (k) { n += 1.0; s1 += e; s2 += e * e; }
-        }
-    }
-    n = wsum(n); s1 = wsum(s1); s2 = wsum(s2);
-    if (lane == 0) { red[wid][0] = n; red[wid][1] = s1; red[wid][2] = s2; }
-    __syncthreads();
-    if (tid < 3) partial[(long)tid * NE_MAX_GRID + blockIdx.x] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    if (!last_block_arrives(ticket, &is_last)) return;
-    if (wid < 3) {
-        double t = 0;
-        for (unsigned blk = lane; blk < gridDim.x; blk += 64) t += partial[(long)wid * NE_MAX_GRID + blk];
-        t = wsum(t);
-        if (lane == 0) red[0][wid] = t;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        *ticket = 0;
-        const double cnt = red[0][0], mu = red[0][1] / cnt;
-        const double var = red[0][2] / cnt - mu * mu;
-        const double mean = med + mu, sd = sqrt(var > 0.0 ? var : 0.0);
-        out4[0] = (double)m_in[0]; out4[1] = med; out4[2] = med_mad[1]; out4[3] = cnt;
-        out3[0] = cnt; out3[1] = mean; out3[2] = sd;
-        if (host_out) {
-            host_out[0] = out4[0]; host_out[1] = med; host_out[2] = med_mad[1]; host_out[3] = cnt;
-            host_out[4] = cnt; host_out[5] = mean; host_out[6] = sd;
-            __threadfence_system();
-            __hip_atomic_store(host_out + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
 
 // ------------------------------------------------------------------------------------
-// The same rejection in ONE launch (default): the passes of both statistics, the two finishing steps and the keep / statistics
-// pass are phases of a single kernel separated by GRID BARRIERS, so only the passes the data needs are executed (real distances:
-// two per statistic) and nothing is dispatched in between -- the launch-per-phase form above enqueues 6 + 1 + 6 + 1 + 1 kernels
-// of which 8 exit at once, ~4 us apiece: at 32 768 correspondences that was ALL of the 65 us this step took.
+// The rejection in ONE launch: the passes of both statistics, the two finishing steps and the keep / statistics pass are phases
+// of a single kernel separated by GRID BARRIERS, so only the passes the data needs are executed (real distances: two per
+// statistic) and nothing is dispatched in between (rounds 2-3 kept a launch-per-phase form next to it -- 6 + 1 + 6 + 1 + 1 kernels of
+// which 8 exit at once, ~4 us apiece -- as a cross-check; round 4 removed it: the windowed form below, the general form and the
+// oracle check each other now).
 //
 //   * every block is resident at once (at most one block per CU is asked for, 256 lanes, 16 KiB of LDS), so the phases can meet
 //     at the grid barrier of sicp_lanes.h (fence-free: everything blocks tell each other here travels in agent-scope atomics;
@@ -1534,8 +1271,6 @@ __global__ __launch_bounds__(256) void k_keep_stats(const double *__restrict__ d
 //     and is next added to after barrier p + 1;
 //   * polling is bounded (about two seconds): a launch that cannot meet itself flags an error and ends instead of hanging
 //     the queue.
-// Same integers as the launch-per-phase form, so median / MAD / keep mask are bit-identical; the kept statistics are folded
-// from the same per-block partials in the same order.
 // ------------------------------------------------------------------------------------
 // ---- the WINDOWED form of the two selections: three barriers instead of seven ---------------------------------------------------
 // From the second iteration of a run on, median and MAD are where the last iteration left them, give or take a little.  So:
@@ -2038,7 +1773,7 @@ long resident_blocks(const void *kernel, int threads)
     return r;
 }
 
-size_t reject_select_scratch_bytes() { return sizeof(HselAll) > sizeof(HselState) ? sizeof(HselAll) : sizeof(HselState); }
+size_t reject_select_scratch_bytes() { return sizeof(HselAll); }
 
 // a new (or re-used) state buffer of the one-launch form: all zero, the two `nxt` words at ~0
 hipError_t hsel_state_init(hipStream_t s, void *state)
@@ -2065,35 +1800,6 @@ hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const 
     return hipGetLastError();
 }
 
-
-// state: reject_select_scratch_bytes() of device scratch; small: 4 x 8 bytes ([0] m, [2] median, [3] mad);
-// partial / ticket: the solver's block-partial scratch (3 * NE_MAX_GRID doubles) and its ticket word
-hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, double *out3,
-                            void *state, unsigned long long *small, double *partial, unsigned *ticket, double *host_out, double seq,
-                            const IcpDev *st)
-{
-    double *med_mad = (double *)(small + 2);       // [0] median, [1] mad
-    HselState *S = (HselState *)state;
-    // (a chained launch that finds the run over skips every kernel below: the scratch is never read)
-    hipError_t e = hipMemsetAsync(state, 0, sizeof(HselState), s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(&S->nxt, 0xff, sizeof(unsigned long long), s);
-    if (e != hipSuccess) return e;
-    // every block ends with ONE same-address ticket atomic, and those serialise at ~20 ns apiece across the 8 XCDs (measured:
-    // 1024 blocks 28 us, 256 blocks 12 us for the same 9 MB) -- so few, fat blocks: one per CU
-    static const long cap = [] { const char *e = std::getenv("SICP_HS_GRID"); const long v = e ? std::atol(e) : 0; return v > 0 && v <= NE_MAX_GRID ? v : 256L; }();
-    const unsigned g = (unsigned)std::min<long>(cap, (Q + 256 * HS_UNROLL - 1) / (256 * HS_UNROLL));
-    for (int pass = 0; pass < HS_PASSES; ++pass)
-        hipLaunchKernelGGL((k_hsel_pass<false>), dim3(g), dim3(256), 0, s, dist, flag, Q, pass, S, (const double *)nullptr, st);
-    hipLaunchKernelGGL((k_hsel_finish<false>), dim3(g), dim3(256), 0, s, dist, flag, Q, S, (const double *)nullptr, med_mad, small, st);
-    for (int pass = 0; pass < HS_PASSES; ++pass)
-        hipLaunchKernelGGL((k_hsel_pass<true>), dim3(g), dim3(256), 0, s, dist, flag, Q, pass, S, (const double *)med_mad, st);
-    hipLaunchKernelGGL((k_hsel_finish<true>), dim3(g), dim3(256), 0, s, dist, flag, Q, S, (const double *)med_mad, med_mad + 1,
-                       (unsigned long long *)nullptr, st);
-    hipLaunchKernelGGL(k_keep_stats, dim3(g), dim3(256), 0, s, dist, flag, Q, (const double *)med_mad, (const unsigned long long *)small,
-                       keep, partial, ticket, out4, out3, host_out, seq, st);
-    return hipGetLastError();
-}
 
 // ------------------------------------------------------------------------------------
 // host launchers

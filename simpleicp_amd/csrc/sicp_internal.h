@@ -151,9 +151,6 @@ hipError_t hsel_state_init(hipStream_t s, void *state);
 hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
                                        double *out3, void *state, unsigned long long *bar_total, double *partial, double *host_out,
                                        double seq, const IcpDev *st, unsigned absent = 0, bool use_prior = false);
-hipError_t reject_by_select(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, double *out3,
-                            void *state, unsigned long long *small, double *partial, unsigned *ticket, double *host_out = nullptr,
-                            double seq = 0.0, const IcpDev *st = nullptr);
 void launch_aos_to_soa(hipStream_t s, const double *aos, long n, long npad, double *x, double *y, double *z);
 void launch_found_mask(hipStream_t s, const int64_t *idx, long Q, uint8_t *out);
 void launch_pad_fill(hipStream_t s, double *x, double *y, double *z, long n, long npad);
@@ -176,10 +173,6 @@ void launch_knn1_fixup(hipStream_t s, const double *qx, const double *qy, const 
                        const double *py, const double *pz, const Xf *H, const uint32_t *hit_cnt, const uint32_t *hit_list,
                        uint32_t cap, uint32_t group, double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out,
                        double *p2_out, uint32_t *overflow);
-void launch_knn1_fmfma(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int qblocks, const double *bound,
-                       const double *px, const double *py, const double *pz, int ntiles, int nparts, const Xf *H, double rmax,
-                       uint32_t *hit_cnt, uint32_t *hit_list, uint32_t cap);
-int  fmfma_blocks_per_cu();
 int  frec_blocks_per_cu(int block);
 void launch_bound_prev(hipStream_t s, const double *qx, const double *qy, const double *qz, const double *p2, long Q,
                        long qpad, const Xf &H, double *bound);
@@ -199,10 +192,6 @@ void launch_postmatch(hipStream_t s, const double *qx, const double *qy, const d
 // st (nullable): loop state of a chained run -- H comes from it (postmatch) and every kernel exits at once when the run is over
 void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
                    const IcpDev *st = nullptr, double *out3 = nullptr);
-void launch_dist_reject_stats(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
-                              const float *planarity, const double *p2, const int64_t *idx, long Q, float min_planarity,
-                              const float *pl2, long pl2_n, double *dist, uint8_t *flag, uint8_t *keep, double *out4, double *out3,
-                              const IcpDev *st);
 void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3, const double *also4 = nullptr,
                   double *host_out = nullptr, double seq = 0.0, double *partial = nullptr, unsigned *ticket = nullptr,
                   const IcpDev *st = nullptr);

@@ -398,122 +398,6 @@ __global__ __launch_bounds__(BLOCK) void k_knn1_frec(
     }
 }
 
-// ------------------------------------------------------------------------------------
-// K1m (opt-in, SICP_FSCAN=mfma): the same conservative filter on the FP32 MATRIX pipe.
-// s = [x y z |p|^2] . [-2qx -2qy -2qz 1] is a K = 4 contraction: two v_mfma_f32_32x32x2_f32 per tile of 32 points x
-// 32 queries (the f32-input MFMA is an exact fmaf chain, so the rigorous error bound carries over with one more
-// rounding: margin 8 instead of 6 ulp-units).  Points are the A operand (rows), queries the B operand (columns): a
-// lane then holds ONE query's column (col = lane & 31) and 16 of the tile's 32 points in its D registers, so the
-// test is a min3 tree over those registers and one compare against the lane's own threshold.  A wave keeps 8 query
-// tiles (256 queries) in registers and runs two accumulator chains at a time; the 4 waves of a block share the LDS
-// point tiles.  Passing (query, point) pairs are recorded one by one (group size 1 for k_knn1_fixup).
-// MEASURED: 0.94-0.96 ms per 1e10 pairs against 0.88 ms for the VALU filter -- the matrix pipe
-// is busy 62 % of the time (PMC), the clock sits at ~1.9 GHz under either load, and the K = 4 product costs four
-// FMAs per pair where the VALU form needs three; a 16x16x4 variant (one product per tile, 16 in flight) was slower
-// still (1.46 ms, 160 VGPRs).  Kept for reference; the VALU filter stays the default.
-// ------------------------------------------------------------------------------------
-typedef float v16f __attribute__((ext_vector_type(16)));
-constexpr int FM_TILES = 8;                     // query tiles (of 32) per wave
-constexpr int FM_BLOCK = 256;                   // 4 waves -> 1024 queries per block
-
-__device__ __forceinline__ float min16(const v16f &D)
-{
-    float m = fminf(fminf(D[0], D[1]), D[2]);
-    m = fminf(fminf(m, D[3]), D[4]);   m = fminf(fminf(m, D[5]), D[6]);   m = fminf(fminf(m, D[7]), D[8]);
-    m = fminf(fminf(m, D[9]), D[10]);  m = fminf(fminf(m, D[11]), D[12]); m = fminf(fminf(m, D[13]), D[14]);
-    return fminf(m, D[15]);
-}
-// D of a 32x32 tile: col = lane & 31 (this lane's query q), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); base = id of row 4 (lane >> 5)'s origin
-__device__ __noinline__ void record_hits(const v16f &D, float thr, long q, uint32_t base, uint32_t *__restrict__ hit_cnt,
-                                         uint32_t *__restrict__ hit_list, uint32_t cap)
-{
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-        if (D[r] < thr) {
-            const uint32_t slot = atomicAdd(hit_cnt + q, 1u);
-            if (slot < cap) hit_list[(size_t)q * cap + slot] = base + (uint32_t)((r & 3) + 8 * (r >> 2));
-        }
-}
-
-template <bool XFORM>
-__global__ __launch_bounds__(FM_BLOCK) void k_knn1_fmfma(
-    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, long Q,
-    const double *__restrict__ bound,
-    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
-    int ntiles, Xf H, double rmax, uint32_t *__restrict__ hit_cnt, uint32_t *__restrict__ hit_list, uint32_t cap)
-{
-    __shared__ float4 tile[2][FS_TILE];
-    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-    const int col = lane & 31, half = lane >> 5;
-    const long q0 = (long)blockIdx.x * (FM_BLOCK * 4) + (long)wid * (FM_TILES * 32);     // this wave's first query
-
-    float b1[FM_TILES], b2[FM_TILES], thr[FM_TILES];
-#pragma unroll
-    for (int t = 0; t < FM_TILES; ++t) {
-        const long q = q0 + t * 32 + col;                   // (the query arrays are padded to a multiple of 2048)
-        const double x = qx[q], y = qy[q], z = qz[q];
-        const double qq = fma(z, z, fma(y, y, x * x));
-        b1[t] = half ? (float)(-2.0 * y) : (float)(-2.0 * x);        // B[k = lane >> 5][j = lane & 31], k = 0, 1
-        b2[t] = half ? 1.0f : (float)(-2.0 * z);                      //                                  k = 2, 3
-        thr[t] = (q < Q) ? filter_threshold(bound[q], qq, rmax, 8.0) : -__builtin_inff();   // padding lanes never hit
-    }
-    const int t_lo = (int)((long)blockIdx.y * ntiles / gridDim.y);
-    const int t_hi = (int)((long)(blockIdx.y + 1) * ntiles / gridDim.y);
-
-    constexpr int PER = FS_TILE / FM_BLOCK;
-    double lx[PER], ly[PER], lz[PER];
-    auto gload = [&](int t) {
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const long g = (long)t * FS_TILE + u * FM_BLOCK + tid;
-            lx[u] = px[g]; ly[u] = py[g]; lz[u] = pz[g];
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            double X = lx[u], Y = ly[u], Z = lz[u];
-            if (XFORM) { double a, b, c; xform(H, X, Y, Z, a, b, c); X = a; Y = b; Z = c; }
-            const double pp = fma(Z, Z, fma(Y, Y, X * X));
-            tile[buf][u * FM_BLOCK + tid] = make_float4((float)X, (float)Y, (float)Z, (float)pp);
-        }
-    };
-    if (t_lo < t_hi) { gload(t_lo); lstore(0); }
-    int cur = 0;
-    for (int t = t_lo; t < t_hi; ++t) {
-        __syncthreads();
-        const bool more = (t + 1 < t_hi);
-        if (more) gload(t + 1);
-        const uint32_t tbase = (uint32_t)t * FS_TILE;
-        const float *tf = reinterpret_cast<const float *>(&tile[cur][0]);
-#pragma unroll 2
-        for (int g = 0; g < FS_TILE / 32; ++g) {
-            // A[i = lane & 31][k = lane >> 5]: (x | y) of point i for the first product, (z | |p|^2) for the second
-            const float a1 = tf[(g * 32 + col) * 4 + half];
-            const float a2 = tf[(g * 32 + col) * 4 + 2 + half];
-#pragma unroll
-            for (int qt = 0; qt < FM_TILES; qt += 2) {
-                const v16f Z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                v16f D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[qt], Z, 0, 0, 0);
-                v16f D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[qt + 1], Z, 0, 0, 0);
-                D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[qt], D0, 0, 0, 0);
-                D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[qt + 1], D1, 0, 0, 0);
-                const float m0 = min16(D0), m1 = min16(D1);
-                if (__builtin_amdgcn_ballot_w64(m0 < thr[qt] || m1 < thr[qt + 1]) != 0ull) {
-                    // rare: record the passing (query, point) pairs
-                    record_hits(D0, thr[qt], q0 + qt * 32 + col, tbase + (uint32_t)(g * 32 + 4 * half), hit_cnt, hit_list, cap);
-                    record_hits(D1, thr[qt + 1], q0 + (qt + 1) * 32 + col, tbase + (uint32_t)(g * 32 + 4 * half), hit_cnt, hit_list, cap);
-                }
-            }
-        }
-        if (more) lstore(cur ^ 1);
-        cur ^= 1;
-    }
-}
-
-// one wave per query: exact FP64 evaluation of the recorded groups, lexicographic minimum, strict
-// upper bound, gather of the winner's original coordinates; overflow[0] counts queries whose list
-// did not fit (their result is NOT final)
 template <bool XFORM>
 __global__ __launch_bounds__(256) void k_knn1_fixup(
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, long Q,
@@ -950,12 +834,8 @@ __device__ void lds_range_select(RejectShared &S, int n, long r, bool want2, uin
     __syncthreads();                          // S.cand / S.wmin consumed
 }
 
-template <bool FUSED>
 __global__ __launch_bounds__(RJ_BLOCK) void k_reject(
-    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz, const float *__restrict__ normals,
-    const float *__restrict__ planarity, const double *__restrict__ p2, const int64_t *__restrict__ idx, float min_planarity,
-    const float *__restrict__ pl2, long pl2_n,
-    double *__restrict__ dist, uint8_t *__restrict__ flag, long Q, uint8_t *__restrict__ keep, double *__restrict__ out4,
+    const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q, uint8_t *__restrict__ keep, double *__restrict__ out4,
     double *__restrict__ out3, const IcpDev *__restrict__ st)
 {
     __shared__ RejectShared S;
@@ -964,48 +844,22 @@ __global__ __launch_bounds__(RJ_BLOCK) void k_reject(
     const int n = (int)Q;
     for (int i = tid; i < RJ_HC * 257; i += RJ_BLOCK) S.hc[i] = 0u;
     if (tid == 0) S.ncand = 0u;
-    Xf H;
-    if (FUSED) H = st->H;
     unsigned cnt = 0;
     double dmn = __builtin_inf(), dmx = -__builtin_inf();
     // four rows per lane and step: their loads are issued together (one workgroup has to cover the memory latency itself)
     for (int base = tid; base < n; base += 4 * RJ_BLOCK) {
         double d[4];
         bool f[4];
-        if (FUSED) {
-            double P[4][3], Qp[4][3];
-            float N[4][3], pl[4];
-            int64_t mi[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * RJ_BLOCK;
-                const int ic = i < n ? i : n - 1;
-                P[u][0] = p2[3 * ic]; P[u][1] = p2[3 * ic + 1]; P[u][2] = p2[3 * ic + 2];
-                Qp[u][0] = qx[ic]; Qp[u][1] = qy[ic]; Qp[u][2] = qz[ic];
-                N[u][0] = normals[3 * ic]; N[u][1] = normals[3 * ic + 1]; N[u][2] = normals[3 * ic + 2];
-                pl[u] = planarity[ic]; mi[u] = idx[ic];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                double X, Y, Z;
-                xform(H, P[u][0], P[u][1], P[u][2], X, Y, Z);
-                d[u] = plane_dist(X - Qp[u][0], Y - Qp[u][1], Z - Qp[u][2], N[u][0], N[u][1], N[u][2]);
-                f[u] = mi[u] >= 0 && pl[u] >= min_planarity;
-                if (f[u] && pl2) f[u] = mi[u] < pl2_n && pl2[mi[u]] >= min_planarity;          // corrpts.py:158-163 (NaN fails)
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * RJ_BLOCK;
-                const int ic = i < n ? i : n - 1;
-                d[u] = dist[ic]; f[u] = flag[ic] != 0;
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * RJ_BLOCK;
+            const int ic = i < n ? i : n - 1;
+            d[u] = dist[ic]; f[u] = flag[ic] != 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = base + u * RJ_BLOCK;
             if (i >= n) continue;
-            if (FUSED) { dist[i] = d[u]; flag[i] = f[u] ? 1 : 0; }
             S.key[i] = f[u] ? ord_key(d[u]) : ~0ull;
             if (f[u]) { cnt += 1; dmn = fmin(dmn, d[u]); dmx = fmax(dmx, d[u]); }
         }
@@ -1517,26 +1371,6 @@ void launch_knn1_fixup(hipStream_t s, const double *qx, const double *qy, const 
                            max_d2, idx_base, d2_out, idx_out, p2_out, overflow);
 }
 
-void launch_knn1_fmfma(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, int qblocks, const double *bound,
-                       const double *px, const double *py, const double *pz, int ntiles, int nparts, const Xf *H, double rmax,
-                       uint32_t *hit_cnt, uint32_t *hit_list, uint32_t cap)
-{
-    const dim3 grid(qblocks, nparts), block(FM_BLOCK);
-    Xf id = {};
-    if (H)
-        hipLaunchKernelGGL((k_knn1_fmfma<true>), grid, block, 0, s, qx, qy, qz, Q, bound, px, py, pz, ntiles, *H, rmax, hit_cnt,
-                           hit_list, cap);
-    else
-        hipLaunchKernelGGL((k_knn1_fmfma<false>), grid, block, 0, s, qx, qy, qz, Q, bound, px, py, pz, ntiles, id, rmax, hit_cnt,
-                           hit_list, cap);
-}
-
-int fmfma_blocks_per_cu()
-{
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_knn1_fmfma<true>, FM_BLOCK, 0) != hipSuccess || nb < 1) nb = 2;
-    return nb > 8 ? 8 : nb;
-}
 
 int frec_blocks_per_cu(int block)
 {
@@ -1637,18 +1471,7 @@ void launch_scatter_f32(hipStream_t s, float *dst, const int64_t *rows, const fl
 void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, const IcpDev *st,
                    double *out3)
 {
-    hipLaunchKernelGGL(k_reject<false>, dim3(1), dim3(RJ_BLOCK), 0, s, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
-                       nullptr, 0L, (double *)dist, (uint8_t *)flag, Q, keep, out4, out3, st);
-}
-
-// chained runs, 2048 < Q <= REJECT_MAX_Q: distances + flags + rejection + kept-distance statistics in one launch
-void launch_dist_reject_stats(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
-                              const float *planarity, const double *p2, const int64_t *idx, long Q, float min_planarity,
-                              const float *pl2, long pl2_n, double *dist, uint8_t *flag, uint8_t *keep, double *out4, double *out3,
-                              const IcpDev *st)
-{
-    hipLaunchKernelGGL(k_reject<true>, dim3(1), dim3(RJ_BLOCK), 0, s, qx, qy, qz, normals, planarity, p2, idx, min_planarity, pl2, pl2_n,
-                       dist, flag, Q, keep, out4, out3, st);
+    hipLaunchKernelGGL(k_reject, dim3(1), dim3(RJ_BLOCK), 0, s, dist, flag, Q, keep, out4, out3, st);
 }
 
 void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3, const double *also4,
