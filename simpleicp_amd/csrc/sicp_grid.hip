@@ -1289,6 +1289,26 @@ constexpr int HS_BINS = 4096, HS_CAP = 256, HS_PASSES = 6, HS_UNROLL = 4;
 // digit selection above, at the cost of the phases spent.  To keep that rare the window is only tried when the last two launches
 // of this run agree on the MAD to 20 % and on the median to 0.3 MAD.
 constexpr int H3_NB = 4096, H3_CAP = 2048;
+constexpr int HS_GRID_MAX = 256;                     // blocks of the one-launch rejection (one per CU at most)
+constexpr int H3_BCAP_M = 32, H3_BCAP_S = 96;       // keys ONE block may contribute: from the median's bin / from the shells
+// zoned flush (more than H3_ZONED_Q correspondences: every block fills nearly every bin, and a million additions to the global
+// histogram cost more than the barriers saved): only the bins where the median's bin and the shells are EXPECTED -- the window is
+// centred on the last median and 3 MAD wide, so bin 2049 and 2049 -+ 1365 -- are added up bin by bin, what lies between as four sums
+constexpr long H3_ZONED_Q = 262144;
+constexpr int H3_BM0 = H3_NB / 2 + 1, H3_JS0 = H3_NB / 3, H3_ZH = 64;
+constexpr int H3_ZM_LO = H3_BM0 - H3_ZH, H3_ZM_HI = H3_BM0 + H3_ZH;
+constexpr int H3_ZL_LO = H3_BM0 - H3_JS0 - H3_ZH - 6, H3_ZL_HI = H3_BM0 - H3_JS0 + H3_ZH + 6;
+constexpr int H3_ZR_LO = H3_BM0 + H3_JS0 - H3_ZH - 6, H3_ZR_HI = H3_BM0 + H3_JS0 + H3_ZH + 6;
+__device__ __forceinline__ int h3_region(int b)      // 0..3: a coarse region, -1: inside a zone
+{
+    if (b < H3_ZL_LO) return 0;
+    if (b <= H3_ZL_HI) return -1;
+    if (b < H3_ZM_LO) return 1;
+    if (b <= H3_ZM_HI) return -1;
+    if (b < H3_ZR_LO) return 2;
+    if (b <= H3_ZR_HI) return -1;
+    return 3;
+}
 constexpr int HS_MAXB = 2 * HS_PASSES + 3 + 2;
 struct HselAll {
     GridBar bar;                   // (sicp_lanes.h) all zero when the buffer is new
@@ -1301,26 +1321,75 @@ struct HselAll {
     unsigned n_prior;              // how many of them this run has produced (the host restarts the count with every setup)
     unsigned pad3[3];
     unsigned whist[H3_NB + 2];     // all zero between launches
-    double wcand[2][H3_CAP];       // raw distances: the median bin's keys / the shells' keys
+    unsigned wcoarse[4];           // zoned flush (large Q): keys below / between / above the three zones; zero between launches
+    unsigned wcnt[HS_GRID_MAX][2]; // per block: median-bin keys, shell keys it found (rewritten by every launch that collects)
+    double wcand[HS_GRID_MAX][H3_BCAP_M + H3_BCAP_S];     // ... and the keys themselves (raw distances)
 };
 
-// ascending bitonic sort of n <= H3_CAP doubles in LDS (padded with +inf to a power of two), 256 threads
-__device__ void h3_sort(double *a, int n)
+// Order statistics of n <= H3_CAP doubles in LDS without sorting them (a bitonic sort of 2048 keys cost 54 us here: strided LDS
+// traffic and 66 barriers): 256 linear bins between the smallest and the largest key, the bin that holds `rank`, its <= 256 keys
+// ranked by counting.  v = key of 0-based rank `rank`; v2 = key of rank + 1 (want2; rank + 1 < n).  False when a bin holds more
+// than 256 keys (thousands of equal keys: the caller falls back).  256 threads; hb: >= 260 words, sm: >= 264 doubles of LDS.
+__device__ bool h3_pick(const double *a, int n, long rank, bool want2, unsigned *hb, double *sm, double &v, double &v2)
 {
-    int N = 64;
-    while (N < n) N <<= 1;
-    for (int i = n + (int)threadIdx.x; i < N; i += 256) a[i] = __builtin_inf();
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double lo = __builtin_inf(), nh = __builtin_inf();
+    for (int i = tid; i < n; i += 256) { lo = fmin(lo, a[i]); nh = fmin(nh, -a[i]); }
+    lo = wmin_d(lo); nh = wmin_d(nh);
+    if (lane == 0) { sm[256 + wid] = lo; sm[260 + wid] = nh; }
+    for (int i = tid; i < 260; i += 256) hb[i] = 0u;
     __syncthreads();
-    for (int k = 2; k <= N; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < N / 2; t += 256) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;        // the pair (i, i + j) of this step
-                const bool up = (i & k) == 0;
-                const double x = a[i], y = a[l];
-                if ((x > y) == up) { a[i] = y; a[l] = x; }
-            }
-            __syncthreads();
+    lo = fmin(fmin(sm[256], sm[257]), fmin(sm[258], sm[259]));
+    const double hi = -fmin(fmin(sm[260], sm[261]), fmin(sm[262], sm[263]));
+    const double inv = hi > lo ? 255.0 / (hi - lo) : 0.0;
+    auto bin = [&](double x) { const int b = (int)((x - lo) * inv); return b > 255 ? 255 : b; };       // monotone in x
+    for (int i = tid; i < n; i += 256) atomicAdd(&hb[bin(a[i])], 1u);
+    __syncthreads();
+    if (wid == 0) {
+        // lane l owns bins 4 l .. 4 l + 3
+        const unsigned h0 = hb[4 * lane], h1 = hb[4 * lane + 1], h2 = hb[4 * lane + 2], h3 = hb[4 * lane + 3];
+        const unsigned mine = h0 + h1 + h2 + h3, incl = wscan_u32(mine);
+        const unsigned before = incl - mine;
+        if ((long)before <= rank && rank < (long)incl) {
+            unsigned acc = before; int j = 0; unsigned c = h0;
+            if (rank >= (long)(acc + h0)) { acc += h0; j = 1; c = h1;
+                if (rank >= (long)(acc + h1)) { acc += h1; j = 2; c = h2;
+                    if (rank >= (long)(acc + h2)) { acc += h2; j = 3; c = h3; } } }
+            hb[256] = (unsigned)(4 * lane + j); hb[257] = acc; hb[258] = c;
         }
+        if (lane == 0) hb[259] = 0u;
+    }
+    __syncthreads();
+    const int bs = (int)hb[256];
+    const long below = hb[257];
+    const unsigned cnt = hb[258];
+    if (cnt > 256u) return false;
+    double above = __builtin_inf();                       // smallest key of the later bins
+    for (int i = tid; i < n; i += 256) {
+        const double x = a[i];
+        const int b = bin(x);
+        if (b == bs) sm[atomicAdd(&hb[259], 1u)] = x;
+        else if (b > bs) above = fmin(above, x);
+    }
+    above = wmin_d(above);
+    __syncthreads();
+    if (lane == 0) sm[256 + wid] = above;
+    double mine = 0.0;
+    unsigned r = 0;
+    if ((unsigned)tid < cnt) {
+        mine = sm[tid];
+        for (unsigned j = 0; j < cnt; ++j) { const double o = sm[j]; r += (o < mine || (o == mine && j < (unsigned)tid)) ? 1u : 0u; }
+    }
+    __syncthreads();
+    above = fmin(fmin(sm[256], sm[257]), fmin(sm[258], sm[259]));
+    const long t = rank - below;
+    if ((unsigned)tid < cnt && (long)r == t) sm[264] = mine;
+    if ((unsigned)tid < cnt && (long)r == t + 1) sm[265] = mine;
+    __syncthreads();
+    v = sm[264];
+    v2 = want2 ? (t + 1 < (long)cnt ? sm[265] : above) : v;
+    __syncthreads();
+    return true;
 }
 __device__ __forceinline__ int h3_bin(double d, double lo, double inv_bw)
 {
@@ -1331,6 +1400,8 @@ __device__ __forceinline__ int h3_bin(double d, double lo, double inv_bw)
     return 1 + (int)t;                                    // 1 .. H3_NB inside the window, H3_NB + 1 above it
 }
 
+template <int HSU /* keys per lane and sweep step: all their loads are in flight together (one block per CU has only its own
+                       waves to hide the latency behind: 4 at up to ~260 k correspondences, 16 at a million) */>
 __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q,
                                                   HselAll *__restrict__ S, unsigned long long bar_base, uint8_t *__restrict__ keep,
                                                   double *__restrict__ partial /*[3][NE_MAX_GRID]*/, double *__restrict__ out4,
@@ -1343,7 +1414,10 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
     __shared__ unsigned long long sc[HS_CAP];
     __shared__ double wk[H3_CAP];                    // windowed form: candidate keys being sorted
     __shared__ int h3i[12];
-    __shared__ double h3d[8];
+    __shared__ double lcand[H3_BCAP_M + H3_BCAP_S];  // this block's candidates on their way out
+    __shared__ double lsm[272];                      // h3_pick's scratch
+    __shared__ unsigned lcnt[2];
+    __shared__ unsigned creg[4][4];
     __shared__ unsigned long long pnx[4], pick[2];
     __shared__ unsigned long long sel[3];            // picked by the bin's owner: prefix, rank inside it, its count
     __shared__ double red[4][3];
@@ -1353,18 +1427,24 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
     if (st && st->stop) {                             // the run is over: leave, but leave the counter where the next launch expects it
         return;
     }
-    const long stride = (long)g * (256 * HS_UNROLL);
+    const long stride = (long)g * (256 * HSU);
     double val[2] = {0.0, 0.0};                       // median, MAD
     unsigned long long m_first = 0;
     bool have = false;                                // the windowed form delivered both statistics
+#ifdef SICP_HSEL_DEBUG
+    long long tq[16]; int nq = 0;
+#define SICP_TQ() tq[nq++] = clock64()
+#else
+#define SICP_TQ()
+#endif
+    SICP_TQ();
     // ---- windowed form (see the comment above HselAll) ----
     const double pm1 = S->prior[1][0], pd1 = S->prior[1][1], pm0 = S->prior[0][0], pd0 = S->prior[0][1];
     const unsigned n_prior = S->n_prior;              // (written by the previous launch's block 0: a kernel boundary ago)
-    // (not above ~260 k correspondences: there every block fills nearly every bin, and a million same-bin additions to the global
-    // histogram plus two thousand appends to one candidate counter cost what the saved barriers bring -- measured at 1 M: 98 us
-    // against 91)
-    bool try_w = use_prior && Q <= 262144 && n_prior >= 2u && pd1 > 0.0 && pd1 < __builtin_inf() && fabs(pd1 - pd0) <= 0.2 * pd1 &&
-                 fabs(pm1 - pm0) <= 0.3 * pd1;
+    const bool zoned = Q > H3_ZONED_Q;
+    const double tol_mad = zoned ? 0.01 : 0.2, tol_med = zoned ? 0.01 : 0.3;      // (zones are +-64 bins = +-0.047 MAD wide)
+    bool try_w = use_prior && g <= (unsigned)HS_GRID_MAX && n_prior >= 2u && pd1 > 0.0 && pd1 < __builtin_inf() &&
+                 fabs(pd1 - pd0) <= tol_mad * pd1 && fabs(pm1 - pm0) <= tol_med * pd1;
 #ifdef SICP_HSEL_DEBUG
     if (blockIdx.x == 0 && tid == 0 && !try_w)
         printf("[hsel3] not tried: use_prior %d n_prior %u prior med %.6g mad %.6g (before: %.6g %.6g)\n", use_prior, n_prior, pm1, pd1, pm0, pd0);
@@ -1373,25 +1453,50 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
         const double wlo = pm1 - 1.5 * pd1, inv_bw = (double)H3_NB / (3.0 * pd1);
         for (int i = tid; i < H3_NB + 2; i += 256) hist[i] = 0;
         __syncthreads();
-        for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {
-            double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
+        for (long base = (long)blockIdx.x * (256 * HSU); base < Q; base += stride) {
+            double d[HSU]; uint8_t f[HSU];
 #pragma unroll
-            for (int u = 0; u < HS_UNROLL; ++u) {
+            for (int u = 0; u < HSU; ++u) {
                 const long i = base + u * 256 + tid;
                 f[u] = i < Q ? flag[i] : (uint8_t)0;
                 d[u] = i < Q ? dist[i] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < HS_UNROLL; ++u) if (f[u]) atomicAdd(&hist[h3_bin(d[u], wlo, inv_bw)], 1u);
+            for (int u = 0; u < HSU; ++u) if (f[u]) atomicAdd(&hist[h3_bin(d[u], wlo, inv_bw)], 1u);
         }
         __syncthreads();
-        for (int i = tid; i < H3_NB + 2; i += 256) if (hist[i]) atomicAdd(&S->whist[i], hist[i]);
+        if (!zoned) {
+            for (int i = tid; i < H3_NB + 2; i += 256) if (hist[i]) atomicAdd(&S->whist[i], hist[i]);
+        } else {
+            unsigned cr[4] = {0u, 0u, 0u, 0u};
+            for (int i = tid; i < H3_NB + 2; i += 256) {
+                const unsigned v = hist[i];
+                const int rg = h3_region(i);
+                if (rg < 0) { if (v) atomicAdd(&S->whist[i], v); }
+                else cr[rg] += v;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { cr[k] = (unsigned)wsum_u64(cr[k]); if (lane == 0) creg[wid][k] = cr[k]; }
+            __syncthreads();
+            if (tid < 4) { const unsigned t = (creg[0][tid] + creg[1][tid]) + (creg[2][tid] + creg[3][tid]); if (t) atomicAdd(&S->wcoarse[tid], t); }
+        }
+        SICP_TQ();
         grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb), absent);
+        SICP_TQ();
         // every block: the complete histogram as inclusive prefix sums in LDS (thread t owns bins 16 t .. 16 t + 15, thread 0 the
-        // last two as well), then one thread finds the median's bin and the shells
+        // last two as well), then one thread finds the median's bin and the shells.  (Zoned flush: a coarse region's keys are
+        // booked on its LAST bin -- prefix sums are then exact on that bin and inside the zones, which is where they are read.)
         unsigned h[16], mine = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { h[j] = __hip_atomic_load(&S->whist[16 * tid + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mine += h[j]; }
+        for (int j = 0; j < 16; ++j) {
+            const int bi = 16 * tid + j;
+            h[j] = __hip_atomic_load(&S->whist[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (zoned) {
+                const int rg = bi == H3_ZL_LO - 1 ? 0 : (bi == H3_ZM_LO - 1 ? 1 : (bi == H3_ZR_LO - 1 ? 2 : -1));
+                if (rg >= 0) h[j] += __hip_atomic_load(&S->wcoarse[rg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            mine += h[j];
+        }
         const unsigned incl = wscan_u32(mine);
         if (lane == 63) scan[wid] = incl;
         __syncthreads();
@@ -1403,7 +1508,9 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
         if (tid == 0) {
             unsigned e = hist[H3_NB - 1];
             e += __hip_atomic_load(&S->whist[H3_NB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); hist[H3_NB] = e;
-            e += __hip_atomic_load(&S->whist[H3_NB + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); hist[H3_NB + 1] = e;
+            e += __hip_atomic_load(&S->whist[H3_NB + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (zoned) e += __hip_atomic_load(&S->wcoarse[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (region 3 ends with the last bin)
+            hist[H3_NB + 1] = e;
             const long m = e, r = m ? (m - 1) / 2 : 0;
             int ok = m > 0 ? 1 : 0, bm = 0, js = 0;
             if (ok) {
@@ -1411,14 +1518,23 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
                 while (a < b) { const int c = (a + b) >> 1; if ((long)hist[c] > r) b = c; else a = c + 1; }
                 bm = a;
                 ok = bm >= 1 && bm <= H3_NB && (hist[bm] - hist[bm - 1]) <= (unsigned)H3_CAP;
+                if (zoned) ok = ok && bm > H3_ZM_LO && bm <= H3_ZM_HI;       // (bm - 1 may be the region's last bin: exact there too)
             }
             if (ok) {
-                // smallest radius js (in bins) with at least r + 1 keys in bins [bm - js, bm + js]
+                // smallest radius js (in bins) with at least r + 1 keys in bins [bm - js, bm + js]; zoned: among the radii whose
+                // both ends -- and the shells and probes around them, 3 bins either way -- lie inside the outer zones
                 const int jmax = (bm - 1 < H3_NB - bm) ? bm - 1 : H3_NB - bm;
-                int a = 0, b = jmax + 1;
-                while (a < b) { const int c = (a + b) >> 1; if ((long)(hist[bm + c] - hist[bm - c - 1]) > r) b = c; else a = c + 1; }
+                int c_lo = 0, c_hi = jmax;
+                if (zoned) {
+                    c_lo = (H3_ZR_LO - bm > bm - 1 - H3_ZL_HI ? H3_ZR_LO - bm : bm - 1 - H3_ZL_HI) + 4;
+                    c_hi = (H3_ZR_HI - bm < bm - 1 - H3_ZL_LO ? H3_ZR_HI - bm : bm - 1 - H3_ZL_LO) - 4;
+                    ok = c_lo >= 4 && c_lo < c_hi && c_hi <= jmax && (long)(hist[bm + c_lo] - hist[bm - c_lo - 1]) <= r &&
+                         (long)(hist[bm + c_hi] - hist[bm - c_hi - 1]) > r;
+                }
+                int a = c_lo, b = c_hi + 1;
+                while (ok && a < b) { const int c = (a + b) >> 1; if ((long)(hist[bm + c] - hist[bm - c - 1]) > r) b = c; else a = c + 1; }
                 js = a;
-                ok = js >= 4 && js + 2 <= jmax;
+                ok = ok && js >= 4 && js + 2 <= jmax;
                 if (ok) {
                     // shells: the five bins at distance js - 2 .. js + 2 from the median's bin, on either side
                     const unsigned c1 = hist[bm - js + 2] - hist[bm - js - 3], c2 = hist[bm + js + 2] - hist[bm + js - 3];
@@ -1433,38 +1549,39 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
             h3i[7] = (int)(m & 0x7fffffff);
         }
         __syncthreads();
-#ifdef SICP_HSEL_DEBUG
-        if (blockIdx.x == 0 && tid == 0)
-            printf("[hsel3] tried: ok %d bm %d js %d cnt_m %d below %d c_in %d c_sh %d m %d | prior med %.6g mad %.6g (before: %.6g %.6g)\n", h3i[0], h3i[1],
-                   h3i[2], h3i[3], h3i[4], h3i[5], h3i[6], h3i[7], pm1, pd1, pm0, pd0);
-#endif
+        SICP_TQ();
         bool okw = h3i[0] != 0;
         const int bm = h3i[1], js = h3i[2], cnt_m = h3i[3], below_m = h3i[4], c_in = h3i[5], c_sh = h3i[6];
         const long mw = h3i[7], rw = mw ? (mw - 1) / 2 : 0;
         if (okw) {
-            // ---- sweep 2: the median bin's keys, the shells' keys, the smallest key above the median's bin ----
+            SICP_TQ();
+            // ---- sweep 2: the median bin's keys, the shells' keys, the smallest key above the median's bin.  A block lists what it
+            //      finds in LDS and writes the lists into a region of its own: no counter every block appends to (two thousand
+            //      same-address additions at a million correspondences would serialise at ~20 ns apiece) ----
+            if (tid < 2) lcnt[tid] = 0u;
+            __syncthreads();
             unsigned long long nxt = ~0ull;
-            for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {
-                double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
+            for (long base = (long)blockIdx.x * (256 * HSU); base < Q; base += stride) {
+                double d[HSU]; uint8_t f[HSU];
 #pragma unroll
-                for (int u = 0; u < HS_UNROLL; ++u) {
+                for (int u = 0; u < HSU; ++u) {
                     const long i = base + u * 256 + tid;
                     f[u] = i < Q ? flag[i] : (uint8_t)0;
                     d[u] = i < Q ? dist[i] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < HS_UNROLL; ++u) {
+                for (int u = 0; u < HSU; ++u) {
                     if (!f[u]) continue;
                     const int b = h3_bin(d[u], wlo, inv_bw);
                     if (b == bm) {
-                        const unsigned pos = atomicAdd(&S->ncand[0], 1u);
-                        if (pos < (unsigned)H3_CAP) __hip_atomic_store(&S->wcand[0][pos], d[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned pos = atomicAdd(&lcnt[0], 1u);
+                        if (pos < (unsigned)H3_BCAP_M) lcand[pos] = d[u];
                     } else {
                         if (b > bm) { const unsigned long long k = okey(d[u]); nxt = k < nxt ? k : nxt; }
                         const int off = b < bm ? bm - b : b - bm;
                         if (off >= js - 2 && off <= js + 2) {
-                            const unsigned pos = atomicAdd(&S->ncand[1], 1u);
-                            if (pos < (unsigned)H3_CAP) __hip_atomic_store(&S->wcand[1][pos], d[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned pos = atomicAdd(&lcnt[1], 1u);
+                            if (pos < (unsigned)H3_BCAP_S) lcand[H3_BCAP_M + pos] = d[u];
                         }
                     }
                 }
@@ -1480,30 +1597,47 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
                 for (int w = 1; w < 4; ++w) tn = pnx[w] < tn ? pnx[w] : tn;
                 if (tn != ~0ull) atomicMin(&S->nxt[0], tn);
             }
-            grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb), absent);
-            // ---- every block: exact median from the bin's keys ----
-            for (int i = tid; i < cnt_m; i += 256) wk[i] = __hip_atomic_load(&S->wcand[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            h3_sort(wk, cnt_m);
-            const long t = rw - below_m;                                   // rank inside the bin
-            const double ka = wk[t];
-            double kb = ka;
-            if (!(mw & 1)) {
-                if (t + 1 < cnt_m) kb = wk[t + 1];
-                else kb = oval64(__hip_atomic_load(&S->nxt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            {   // this block's lists -> its region (counts beyond the capacity say so: the gather below then misses)
+                const unsigned nm = lcnt[0], nsh = lcnt[1];
+                if (tid < 2) __hip_atomic_store(&S->wcnt[blockIdx.x][tid], tid ? nsh : nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned km = nm < (unsigned)H3_BCAP_M ? nm : (unsigned)H3_BCAP_M, ks = nsh < (unsigned)H3_BCAP_S ? nsh : (unsigned)H3_BCAP_S;
+                if ((unsigned)tid < km) __hip_atomic_store(&S->wcand[blockIdx.x][tid], lcand[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid >= H3_BCAP_M && (unsigned)(tid - H3_BCAP_M) < ks)
+                    __hip_atomic_store(&S->wcand[blockIdx.x][tid], lcand[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            SICP_TQ();
+            grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb), absent);
+            SICP_TQ();
+            // ---- every block gathers every block's lists: thread t owns block t's (at most 256 blocks) ----
+            unsigned my_m = 0, my_s = 0;
+            if ((unsigned)tid < g) {
+                my_m = __hip_atomic_load(&S->wcnt[tid][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                my_s = __hip_atomic_load(&S->wcnt[tid][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const bool fits = __syncthreads_and(my_m <= (unsigned)H3_BCAP_M && my_s <= (unsigned)H3_BCAP_S) != 0;
+            unsigned tot_m, tot_s;
+            const unsigned off_m = block_excl_scan(my_m, &tot_m);
+            __syncthreads();
+            const unsigned off_s = block_excl_scan(my_s, &tot_s);
+            okw = fits && tot_m == (unsigned)cnt_m && tot_s == (unsigned)c_sh;
+            if (okw)
+                for (unsigned i = 0; i < my_m; ++i) wk[off_m + i] = __hip_atomic_load(&S->wcand[tid][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            SICP_TQ();
+            const long t = rw - below_m;                                   // the median's rank inside its bin
+            double ka = 0.0, kb = 0.0;
+            if (okw) okw = h3_pick(wk, cnt_m, t, !(mw & 1) && t + 1 < cnt_m, hist, lsm, ka, kb);
+            if (okw) {
+            if (!(mw & 1) && t + 1 >= cnt_m) kb = oval64(__hip_atomic_load(&S->nxt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             const double med = (ka + kb) / 2.0;
             __syncthreads();
             // ---- exact MAD from the shells' keys.  The premise -- every key between the shells is nearer to the median than the
             //      MAD, every key outside at least as far -- is checked with four probe values, one just inside either end of either
             //      shell: binning is monotone, so a probe that h3_bin puts into a shell's first (last) bin is above (below) every
             //      key of the bins before (after) it, and |x - median| is monotone in x on either side of the median ----
-            for (int i = tid; i < c_sh; i += 256) {
-                const double d = __hip_atomic_load(&S->wcand[1][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                wk[i] = fabs(d - med);
-            }
+            for (unsigned i = 0; i < my_s; ++i)
+                wk[off_s + i] = fabs(__hip_atomic_load(&S->wcand[tid][H3_BCAP_M + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - med);
             __syncthreads();
-            h3_sort(wk, c_sh);
             const double bw = 3.0 * pd1 / (double)H3_NB;
             const double xl_out = wlo + ((double)(bm - js - 3) + 0.02) * bw, xl_in = wlo + ((double)(bm - js + 2) - 0.02) * bw;
             const double xr_in = wlo + ((double)(bm + js - 3) + 0.02) * bw, xr_out = wlo + ((double)(bm + js + 2) - 0.02) * bw;
@@ -1512,21 +1646,15 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
                   h3_bin(xl_out, wlo, inv_bw) >= bm - js - 2 && h3_bin(xl_in, wlo, inv_bw) <= bm - js + 2 &&
                   h3_bin(xr_in, wlo, inv_bw) >= bm + js - 2 && h3_bin(xr_out, wlo, inv_bw) <= bm + js + 2 &&
                   xl_in < med && med < xr_in;                              // (an even count whose upper middle key lies far out)
+            double v = 0.0, v2 = 0.0;
+            if (okw) okw = h3_pick(wk, c_sh, jr, !(mw & 1), hist, lsm, v, v2);
             if (okw) {
-                const double v = wk[jr], v2 = (mw & 1) ? v : wk[jr + 1];
                 const double t_in = fmax(fabs(xl_in - med), fabs(xr_in - med));      // >= |d - median| of every key between the shells
                 const double t_out = fmin(fabs(xl_out - med), fabs(xr_out - med));   // <= |d - median| of every key outside them
                 okw = t_in < v && v2 <= t_out;
                 if (okw) { val[0] = med; val[1] = (v + v2) / 2.0; m_first = (unsigned long long)mw; have = true; }
-#ifdef SICP_HSEL_DEBUG
-                if (blockIdx.x == 0 && tid == 0)
-                    printf("[hsel3] premise %d: bm %d js %d cnt_m %d c_in %d c_sh %d jr %ld v %.6g v2 %.6g t_in %.6g t_out %.6g med %.6g\n", (int)okw, bm, js,
-                           cnt_m, c_in, c_sh, jr, v, v2, t_in, t_out, med);
-#endif
             }
-#ifdef SICP_HSEL_DEBUG
-            else if (blockIdx.x == 0 && tid == 0) printf("[hsel3] rank outside the shells / probes: jr %ld c_sh %d c_in %d\n", jr, c_sh, c_in);
-#endif
+            }
             __syncthreads();
         }
         // Missed (every block sees the same numbers, so every block is here): meet once more, so that nobody still reads what is
@@ -1535,12 +1663,9 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
         if (!have) grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb), absent);
         for (unsigned i = blockIdx.x * 256u + (unsigned)tid; i < (unsigned)(H3_NB + 2); i += g * 256u)
             __hip_atomic_store(&S->whist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!have && blockIdx.x == 0 && tid == 0) {
-            // (the general form touches these only in its collecting sweeps, behind a barrier of its own)
+        if (blockIdx.x == 0 && tid < 4) __hip_atomic_store(&S->wcoarse[tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!have && blockIdx.x == 0 && tid == 0)      // (the general form touches it only in its collecting sweeps, behind a barrier of its own)
             __hip_atomic_store(&S->nxt[0], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&S->ncand[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&S->ncand[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
     int p = 0;                                        // running pass index over both statistics: hist[p % 3]
     for (int which = 0; which < 2 && !have; ++which) {
@@ -1555,16 +1680,16 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
             unsigned *gh = S->hist[p % 3];
             for (int i = tid; i < HS_BINS; i += 256) hist[i] = 0;
             __syncthreads();
-            for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {      // block-uniform trip count
-                double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
+            for (long base = (long)blockIdx.x * (256 * HSU); base < Q; base += stride) {      // block-uniform trip count
+                double d[HSU]; uint8_t f[HSU];
 #pragma unroll
-                for (int u = 0; u < HS_UNROLL; ++u) {
+                for (int u = 0; u < HSU; ++u) {
                     const long i = base + u * 256 + tid;
                     f[u] = i < Q ? flag[i] : (uint8_t)0;
                     d[u] = i < Q ? dist[i] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < HS_UNROLL; ++u) {
+                for (int u = 0; u < HSU; ++u) {
                     const unsigned long long k = f[u] ? okey(which ? fabs(d[u] - ctr) : d[u]) : ~0ull;
                     bool act = f[u] && (pass == 0 || (k >> (shift + bits)) == (prefix >> (shift + bits)));
                     const unsigned bin = (unsigned)(k >> shift) & mask;
@@ -1622,16 +1747,16 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
         const unsigned long long hi = fixed >= 64 ? prefix : (prefix | (~0ull >> fixed));
         unsigned long long nxt = ~0ull;
         if (m > 0) {
-            for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {
-                double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
+            for (long base = (long)blockIdx.x * (256 * HSU); base < Q; base += stride) {
+                double d[HSU]; uint8_t f[HSU];
 #pragma unroll
-                for (int u = 0; u < HS_UNROLL; ++u) {
+                for (int u = 0; u < HSU; ++u) {
                     const long i = base + u * 256 + tid;
                     f[u] = i < Q ? flag[i] : (uint8_t)0;
                     d[u] = i < Q ? dist[i] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < HS_UNROLL; ++u) {
+                for (int u = 0; u < HSU; ++u) {
                     if (!f[u]) continue;
                     const unsigned long long k = okey(which ? fabs(d[u] - ctr) : d[u]);
                     if (k > hi) nxt = k < nxt ? k : nxt;
@@ -1684,19 +1809,20 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
         }
         __syncthreads();
     }
-    // ---- keep mask + count / mean / std of the kept distances (sums relative to the median), as k_keep_stats ----
+    SICP_TQ();
+    // ---- keep mask + count / mean / std of the kept distances (sums relative to the median) ----
     const double med = val[0], bound = 3 * val[1];
     double n = 0, s1 = 0, s2 = 0;
-    for (long base = (long)blockIdx.x * (256 * HS_UNROLL); base < Q; base += stride) {
-        double d[HS_UNROLL]; uint8_t f[HS_UNROLL];
+    for (long base = (long)blockIdx.x * (256 * HSU); base < Q; base += stride) {
+        double d[HSU]; uint8_t f[HSU];
 #pragma unroll
-        for (int u = 0; u < HS_UNROLL; ++u) {
+        for (int u = 0; u < HSU; ++u) {
             const long i = base + u * 256 + tid;
             f[u] = i < Q ? flag[i] : (uint8_t)0;
             d[u] = i < Q ? dist[i] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < HS_UNROLL; ++u) {
+        for (int u = 0; u < HSU; ++u) {
             const long i = base + u * 256 + tid;
             const double e = d[u] - med;
             const bool k = f[u] && fabs(e) <= bound;
@@ -1710,7 +1836,14 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
     if (tid < 3)
         __hip_atomic_store(&partial[(long)tid * NE_MAX_GRID + blockIdx.x], (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SICP_TQ();
     grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb), absent);
+    SICP_TQ();
+#ifdef SICP_HSEL_DEBUG
+    if (blockIdx.x == 0 && tid == 0 && have)
+        printf("[hsel3-t] sweep1+flush %lld | B1 %lld | analysis %lld | sweep2+lists %lld (incl. stamp) | B2 %lld | gather %lld | sorts+premise %lld | sweep3 %lld | B3 %lld\n",
+               tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[5] - tq[3], tq[6] - tq[5], tq[7] - tq[6], tq[8] - tq[7], tq[9] - tq[8], tq[10] - tq[9]);
+#endif
     if (blockIdx.x == 0) {
         if (wid < 3) {
             double t = 0;
@@ -1792,10 +1925,17 @@ hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const 
     static const long cap = [] { const char *e = std::getenv("SICP_HS_GRID"); const long v = e ? std::atol(e) : 0; return v > 0 && v <= 256 ? v : 256L; }();
     // every block must be resident at once (grid barrier): never more blocks than the device can hold (a partitioned device has
     // far fewer CUs than 256)
-    const long resident = resident_blocks((const void *)k_hsel_all, 256);
-    const unsigned g = (unsigned)std::max<long>(1, std::min<long>(std::min<long>(cap, resident), (Q + 256 * HS_UNROLL - 1) / (256 * HS_UNROLL)));
-    hipLaunchKernelGGL(k_hsel_all, dim3(g), dim3(256), 0, s, dist, flag, Q, (HselAll *)state, *bar_total, keep, partial, out4, out3,
-                       host_out, seq, st, absent, use_prior ? 1 : 0);
+    const int hsu = Q >= 900000 ? 16 : (Q >= 450000 ? 8 : 4);
+    const void *fn = hsu == 16 ? (const void *)k_hsel_all<16> : hsu == 8 ? (const void *)k_hsel_all<8> : (const void *)k_hsel_all<4>;
+    const long resident = resident_blocks(fn, 256);
+    const unsigned g = (unsigned)std::max<long>(1, std::min<long>(std::min<long>(cap, resident), (Q + 256 * hsu - 1) / (256 * hsu)));
+#define SICP_HSEL_LAUNCH(U)                                                                                                       \
+    hipLaunchKernelGGL((k_hsel_all<U>), dim3(g), dim3(256), 0, s, dist, flag, Q, (HselAll *)state, *bar_total, keep, partial, out4, out3, \
+                       host_out, seq, st, absent, use_prior ? 1 : 0)
+    if (hsu == 16) SICP_HSEL_LAUNCH(16);
+    else if (hsu == 8) SICP_HSEL_LAUNCH(8);
+    else SICP_HSEL_LAUNCH(4);
+#undef SICP_HSEL_LAUNCH
     *bar_total += (unsigned long long)HS_MAXB;
     return hipGetLastError();
 }
