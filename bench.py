@@ -357,6 +357,8 @@ def run(args):
         d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
              "traffic": traffic, "traffic_source": pmc_src if (traffic is not None or not pmc) else None,
              "kernel": kernel, "avg_ms": ms, "bytes_alg_per_launch": int(bytes_alg), "note": note}
+        if traffic is not None and ms > 0:
+            d["frac_on_pmc_traffic"] = traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS        # the counters' bytes over the same time
         if extra:
             d.update(extra)
         return d
@@ -623,6 +625,8 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
         d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
              "traffic": pmc.get(kernel + tag), "traffic_source": pmc_src if (pmc.get(kernel + tag) is not None or not pmc) else None,
              "kernel": kernel, "avg_ms": ms, "bytes_alg_per_launch": int(bytes_alg), "note": note}
+        if d["traffic"] is not None and ms > 0:
+            d["frac_on_pmc_traffic"] = d["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS    # the counters' bytes over the same time
         d.update(extra or {})
         return d
 
@@ -635,9 +639,9 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
                             "timed_region": "K steps from the cold state (icp_setup just called), min_change=0, events off"},
            "parallelism": f"query shards x{world}, movable cloud replicated" if exchange else "1 GPU",
            "roofline": roof(kern, avg["match"], bytes_match,
-                            "exact 1-NN on the static grid, four cell-ordered queries per wave; bytes = the candidates (32-B records) and "
-                            "grid rows the search itself tallied + 96 B per query; scattered 32..512-B reads: bandwidth- and "
-                            "issue-bound", {"candidates_per_query": per["candidates"] / max(1, nq_local),
+                            "exact 1-NN on the static grid, four or eight cell-ordered queries per wave; bytes = the candidates (32-B records) and "
+                            "grid rows the search itself TALLIED + 96 B per query (they include what neighbouring queries share in L2: "
+                            "`frac_on_pmc_traffic` prices the same time on the HBM counters' bytes); issue- and latency-bound", {"candidates_per_query": per["candidates"] / max(1, nq_local),
                                            "grid_rows_per_query": per["rows"] / max(1, nq_local),
                                            "pruning_ratio": (Nm * 24 + nq_local * 40) / max(1.0, bytes_match)}),
            "roofline_solver": roof("k_lm_eval" if exchange else "k_lm_all", avg["solve"], int(last.n_kept) * 72 * evals,
@@ -789,6 +793,7 @@ def bruteforce_leg(device, Xf, Xm, sel, normals, planarity, pmc, pmc_src):
     ctx.close()
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": pmc.get(kern), "traffic_source": pmc_src if pmc.get(kern) is not None else None,
+            "frac_on_pmc_traffic": (pmc[kern] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pmc.get(kern) is not None else None,
             "kernel": kern, "avg_ms": ms, "bytes_alg_per_launch": bytes_alg,
             "pair_evals_per_s": pairs / (ms * 1e-3),
             # SURVEY 8(d) prices a pair at 8 flop (3 sub + 1 mul + 2 fma in the plain distance form); the filter this kernel runs

@@ -2,7 +2,7 @@
 # Everything the round's records are made of, in one GPU call:  scripts/final_measure.sh <tag>  -> gpurun_out/final_<tag>/ (+ prof_<tag>*/)
 # Every step under its own timeout; partial results survive a cut-off call.  STEPS selects (default: all).
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/final_$TAG
 STEPS=${STEPS:-"bench configs exchange sweeps traces profiles c5"}
@@ -25,6 +25,8 @@ if has exchange; then
 fi
 if has sweeps; then
   timeout 600 python scripts/q_sweep.py 1e7 1000 2048 2049 10000 16384 32768 100000 1000000 > "$OUT/q_sweep.txt" 2>&1; stamp "q_sweep rc=$?"
+  timeout 600 python scripts/steady_sweep.py 1e7 32768 100000 500000 1000000 > "$OUT/steady_sweep.txt" 2>&1; stamp "steady_sweep rc=$?"
+  timeout 600 python scripts/normals_probe.py 10000000 1000000 10 rounds sweep sweep_b1 sweep_b64 sweep_unordered > "$OUT/normals_probe.txt" 2>&1; stamp "normals probe rc=$?"
   timeout 600 python scripts/datasets_run.py > "$OUT/datasets_run.txt" 2>&1; stamp "datasets rc=$?"
   timeout 600 python scripts/cold_match.py > "$OUT/cold_match.txt" 2>&1; stamp "cold match rc=$?"
 fi

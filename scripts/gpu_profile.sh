@@ -4,7 +4,7 @@
 #   e.g. scripts/gpu_profile.sh r3                                            the default line's kernels (C4, Q = 1000)
 #        scripts/gpu_profile.sh r3_q1000000 --correspondences 1000000         the large-Q kernels at Q = 1 M on the same clouds
 # PMC passes are separate runs without any trace domain (gpurun refuses --pmc with sys/hip traces); FETCH_SIZE and
-# WRITE_SIZE do not fit one pass (MI355X_MICROARCH.md, PMC slots).  PASSES="trace fetch write sq1 sq2" selects.
+# WRITE_SIZE do not fit one pass (MI355X_MICROARCH.md, PMC slots); those two passes include the brute-force leg (k_knn1_frec's traffic).  PASSES="trace fetch write sq1 sq2" selects.
 set -u
 TAG=${1:-r1}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -17,8 +17,8 @@ BENCH="python $REPO/bench.py --steps 20 --warmup 3 --repeats 5 --no-cpu-baseline
 for P in $PASSES; do
   case $P in
     trace) rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --no-work-pass > "$OUT/bench_trace.json" 2> "$OUT/trace.err" ;;
-    fetch) rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --no-bruteforce-leg > "$OUT/bench_pmc_fetch.json" 2> "$OUT/pmc_fetch.err" ;;
-    write) rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH --no-bruteforce-leg > "$OUT/bench_pmc_write.json" 2> "$OUT/pmc_write.err" ;;
+    fetch) rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/bench_pmc_fetch.json" 2> "$OUT/pmc_fetch.err" ;;
+    write) rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > "$OUT/bench_pmc_write.json" 2> "$OUT/pmc_write.err" ;;
     sq1)   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/pmc_sq1" -- $BENCH --no-bruteforce-leg > "$OUT/bench_pmc_sq1.json" 2> "$OUT/pmc_sq1.err" ;;
     sq2)   rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq2" -- $BENCH --no-bruteforce-leg > "$OUT/bench_pmc_sq2.json" 2> "$OUT/pmc_sq2.err" ;;
   esac

@@ -26,6 +26,7 @@ VARIANTS = {
     "sweep_b8": {"SICP_KNN_BATCH": "8"},
     "sweep_b16": {"SICP_KNN_BATCH": "16"},
     "sweep_b32": {"SICP_KNN_BATCH": "32"},
+    "sweep_b64": {"SICP_KNN_BATCH": "64"},
     "sweep_unordered": {"SICP_ORDER_MIN_Q": "0"},
     "sweep_unordered_b1": {"SICP_ORDER_MIN_Q": "0", "SICP_KNN_BATCH": "1"},
     "sweep_target8": {"SICP_GRID_TARGET": "8"},

@@ -667,7 +667,7 @@ int grid_build(sicp_ctx *c, int slot)
 }
 
 // the cloud's subsample (every SUB_STRIDE-th point) and its grid
-constexpr long SUB_STRIDE = 64;
+static const long SUB_STRIDE = [] { const char *e = std::getenv("SICP_SUB_STRIDE"); const long v = e ? std::atol(e) : 0; return v >= 2 && v <= 4096 ? v : 64L; }();   // (A/B: SICP_SUB_STRIDE)
 int subsample_build(sicp_ctx *c, int slot)
 {
     Cloud &cl = c->cloud[slot];
