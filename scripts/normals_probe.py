@@ -20,6 +20,10 @@ K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 VARIANTS = {
     "rounds": {"SICP_KNN_SWEEP": "0"},
     "sweep": {},
+    "sweep_g1": {"SICP_KNN_GROUP": "1"},
+    "sweep_g4_b4": {"SICP_KNN_GROUP": "4", "SICP_KNN_BATCH": "4"},
+    "sweep_g4_b16": {"SICP_KNN_GROUP": "4", "SICP_KNN_BATCH": "16"},
+    "sweep_g4_b1": {"SICP_KNN_GROUP": "4", "SICP_KNN_BATCH": "1"},
     "sweep_b1": {"SICP_KNN_BATCH": "1"},
     "sweep_b2": {"SICP_KNN_BATCH": "2"},
     "sweep_b4": {"SICP_KNN_BATCH": "4"},

@@ -274,6 +274,8 @@ struct sicp_ctx {
     DevBuf<int64_t> k_sel;         // sicp_estimate_normals: selected rows, normals and planarity before they leave
     DevBuf<float> k_nv, k_pl;
     DevBuf<double> k_cov;          // (Q, 6) covariances between the k-NN sweep and the eigen step
+    DevBuf<uint32_t> k_redo;       // [0] count, [1..] slots the four-queries-per-wave sweep left to the one-query-per-wave kernel
+    int knn_group = 0;             // SICP_KNN_GROUP = 1 / 4: queries per wave of the k-NN sweep (0: chosen per launch)
     long knn_batch = 0;            // SICP_KNN_BATCH: queries a wave of the one-sweep k-NN works through (0: chosen per launch)
     bool knn_sweep = true;         // SICP_KNN_SWEEP=0: k extraction rounds (k_grid_knn) + k_normals instead of the one-sweep kernel
     DevBuf<double> bound_p2, bound_d2;   // cold search: nearest subsample point per query (coordinates = the bound) + scratch
@@ -1038,10 +1040,11 @@ int knnk_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, in
                 order = c->k_order.p;
             }
             if (normals_out) CHK(c->k_cov.reserve((size_t)6 * Q));
+            CHK(c->k_redo.reserve((size_t)Q + 1));
             Timed t(c, SICP_K_KNNK);
             launch_grid_knn_sweep(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, order, Q, k, gr.g, gr.avg_per_cell, gr.cell_start.p,
                                   gr.rec.p, cl.rmax, cl.idx_base, d2_out, idx_out, c->k_cov.p, normals_out, planarity_out,
-                                  c->count_work ? c->match_work.p + 4 : nullptr, c->knn_batch);
+                                  c->count_work ? c->match_work.p + 4 : nullptr, c->knn_batch, c->k_redo.p, c->knn_group);
             if (fused) *fused = normals_out != nullptr;
         } else {
             Timed t(c, SICP_K_KNNK);
@@ -1172,6 +1175,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_ORDER_MIN_Q")) c->order_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_KNN_SWEEP")) c->knn_sweep = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_KNN_BATCH")) c->knn_batch = std::atol(e);
+    if (const char *e = std::getenv("SICP_KNN_GROUP")) c->knn_group = std::atoi(e);
     if (const char *e = std::getenv("SICP_NN16_MIN_Q")) c->nn16_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_COARSE_ITERS")) c->coarse_iters = std::atoi(e);
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
@@ -1206,7 +1210,7 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
     for (auto &p : c->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &cl : c->cloud) { cl.xyz.release(); cl.pl.release(); cl.grid.cell_start.release(); cl.grid.rec.release();
                                  cl.sub_xyz.release(); cl.sub_grid.cell_start.release(); cl.sub_grid.rec.release(); }
-    c->bound_p2.release(); c->bound_d2.release(); c->bound_idx.release(); c->q_order.release(); c->k_order.release(); c->k_sel.release(); c->k_nv.release(); c->k_pl.release(); c->k_cov.release(); c->g_ids.release(); c->g_counts.release(); c->g_cursor.release(); c->g_blk.release(); c->match_work.release(); c->rj_keys.release();
+    c->bound_p2.release(); c->bound_d2.release(); c->bound_idx.release(); c->q_order.release(); c->k_order.release(); c->k_sel.release(); c->k_nv.release(); c->k_pl.release(); c->k_cov.release(); c->k_redo.release(); c->g_ids.release(); c->g_counts.release(); c->g_cursor.release(); c->g_blk.release(); c->match_work.release(); c->rj_keys.release();
     c->stage.release(); c->part_d2.release(); c->part_idx.release(); c->kq.release(); c->k_d2.release();
     c->k_idx.release(); c->floor_d2.release(); c->floor_idx.release(); c->bound.release(); c->hit_cnt.release(); c->hit_list.release(); c->x_send.release(); c->x_recv.release(); c->q.release(); c->normals.release();
     c->planarity.release(); c->m_idx.release(); c->m_d2.release(); c->m_p2.release(); c->dist.release();

@@ -948,7 +948,9 @@ __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
     long Q, int k, int batch, GridGeom G, double rmax, double r_first, int64_t idx_base,
     double *__restrict__ d2_out /* nullable */, int64_t *__restrict__ idx_out /* nullable */,
     double *__restrict__ cov_out /* nullable: (Q, 6) by SLOT: upper triangle of every neighbourhood's sample covariance (NaN: fewer than k points) */,
-    unsigned long long *__restrict__ work /* nullable: [0] candidates read, [1] sweeps, [2] queries on the k-round path, [3] survivors */)
+    unsigned long long *__restrict__ work /* nullable: [0] candidates read, [1] sweeps, [2] queries on the k-round path, [3] survivors */,
+    const uint32_t *__restrict__ redo_list /* nullable: only the slots listed here (what k_grid_knn_sweep4 left for this kernel) */,
+    const unsigned *__restrict__ redo_count)
 {
     constexpr int CAP = 64 * NS;
     extern __shared__ double ks_lds[];
@@ -961,12 +963,24 @@ __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
     double *dk_slot = nbr + 3 * kpad;
 
     long blk = blockIdx.x;
-    if (order) blk = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);       // one contiguous eighth per XCD
-    const long slot0 = (blk * 4 + wid) * (long)batch;
-    if (slot0 >= Q) return;
-    const int nb = (int)((Q - slot0 < (long)batch) ? (Q - slot0) : (long)batch);
+    if (order && !redo_list) blk = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);       // one contiguous eighth per XCD
+    int nb;
+    uint32_t my_slot = 0;                             // lane b: the b-th slot this wave works on
+    if (redo_list) {
+        // the waves share the list: wave w takes entries w, w + W, w + 2 W, ... (at most 64: the launch has Q / 64 waves)
+        const long W = (long)gridDim.x * 4, wv = blk * 4 + wid, cnt = (long)*redo_count;
+        if (wv >= cnt) return;
+        const long mine = (cnt - wv + W - 1) / W;
+        nb = (int)(mine < 64 ? mine : 64);
+        if (lane < nb) my_slot = redo_list[wv + (long)lane * W];
+    } else {
+        const long slot0 = (blk * 4 + wid) * (long)batch;
+        if (slot0 >= Q) return;
+        nb = (int)((Q - slot0 < (long)batch) ? (Q - slot0) : (long)batch);
+        if (lane < nb) my_slot = (uint32_t)(slot0 + lane);
+    }
     uint32_t my_q = 0;
-    if (lane < nb) my_q = order ? order[slot0 + lane] : (uint32_t)(slot0 + lane);
+    if (lane < nb) my_q = order ? order[my_slot] : my_slot;
     const double inv_km1 = 1.0 / (double)(k - 1);
     unsigned long long n_cand = 0, n_sweeps = 0, n_slow = 0, n_surv = 0;
     const double etol = 1e-6 * G.h;
@@ -1205,7 +1219,8 @@ __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
                 } else {
                     cv = __builtin_nan("");
                 }
-                cov_out[6 * (slot0 + b) + lane] = cv;                  // (by SLOT: consecutive queries of the order write consecutive rows)
+                // (by SLOT: consecutive queries of the order write consecutive rows)
+                cov_out[6 * (long)(uint32_t)__builtin_amdgcn_readlane((int)my_slot, b) + lane] = cv;
             }
         }
         wave_lds_sync();                              // (the next sweep overwrites the survivors)
@@ -1213,6 +1228,201 @@ __global__ __launch_bounds__(256, 4) void k_grid_knn_sweep(
     if (work) {
         n_cand = wsum_u64(n_cand);
         if (lane == 0) { atomicAdd(work, n_cand); atomicAdd(work + 1, n_sweeps); atomicAdd(work + 2, n_slow); atomicAdd(work + 3, n_surv); }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// The same sweep with FOUR queries per wave (16 lanes each), for the common case only.  k_grid_knn_sweep above spends ~690
+// vector instructions per query, most of them bookkeeping that 64 lanes execute for ONE query (a ball holds ~90 candidates in
+// ~5 rows, ~19 of them inside); here a group of 16 lanes owns a query -- rows one per lane, a row's records 16 at a time,
+// survivors compacted by the group's 16 bits of the ballot, ranked by the group in lock step with the other three, mean and
+// covariance on its lanes 0..5 -- and the wave pays that bookkeeping once for four.  A group handles exactly what needs no loop
+// around it: ONE pass at its starting radius whose ball spans at most 16 rows, not the whole grid, and holds between k and 64
+// points.  Anything else (0.5 % of the queries of a typical cloud: a ball that came out short; dense clusters; coincident points;
+// tiny clouds) is written to a list and done by k_grid_knn_sweep in a second launch -- same arithmetic, same answers.
+// k <= 32.  LDS of a group: 64 survivors (key 16 B + coordinates 24 B), the k winners in rank order, the k-th distance.
+// ------------------------------------------------------------------------------------
+constexpr int KG_CAP = 64, KG_MAXK = 32;
+__host__ __device__ constexpr int kg_group_doubles(int kpad) { return 2 * KG_CAP + 3 * kpad + 2; }
+
+__global__ __launch_bounds__(256, 5) void k_grid_knn_sweep4(
+    const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
+    const uint32_t *__restrict__ order, const uint32_t *__restrict__ cell_start, const double4 *__restrict__ rec,
+    long Q, int k, int batch /* <= 16 */, GridGeom G, double rmax, double r_first, int64_t idx_base,
+    double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ cov_out,
+    uint32_t *__restrict__ redo_list, unsigned *__restrict__ redo_count, unsigned long long *__restrict__ work)
+{
+    extern __shared__ double ks_lds[];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, gl = lane & 15, gi = lane >> 4, gbase = lane & 48;
+    const int kpad = (k + 7) & ~7;
+    double *wbase = ks_lds + (size_t)(wid * 4 + gi) * kg_group_doubles(kpad);
+    KnnKey *keys = (KnnKey *)wbase;               // (.pad: the candidate's record -- the k winners fetch their coordinates again, from L1 / L2;
+    double *nbr = wbase + 2 * KG_CAP;             //  coordinates of all 64 survivors in LDS would cost two of five waves per SIMD)
+    double *dk_slot = nbr + 3 * kpad;
+
+    long blk = blockIdx.x;
+    if (order) blk = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);       // one contiguous eighth per XCD
+    const long slot0 = ((blk * 4 + wid) * 4 + gi) * (long)batch;                            // this GROUP's first slot
+    const int nb = slot0 >= Q ? 0 : (int)((Q - slot0 < (long)batch) ? (Q - slot0) : (long)batch);
+    if (!__any(nb > 0)) return;
+    uint32_t my_q = 0;
+    if (gl < nb) my_q = order ? order[slot0 + gl] : (uint32_t)(slot0 + gl);
+    const double inv_km1 = 1.0 / (double)(k - 1);
+    const double etol = 1e-6 * G.h;
+    double dk_est = (r_first * r_first) * (1.0 / (1.35 * 1.35));
+    unsigned long long n_cand = 0, n_act = 0, n_defer = 0, n_surv = 0;
+
+    for (int b = 0; b < batch; ++b) {
+        const bool active = b < nb;
+        const long q = active ? (long)(uint32_t)__shfl((int)my_q, gbase + b) : 0;
+        const double ax = qx[q], ay = qy[q], az = qz[q];
+        const double scale = rmax + (fabs(ax) + fabs(ay) + fabs(az)) + 1.0;
+        const double slack = 1e-12 * scale;
+        const double c3[3] = {ax, ay, az};
+        double r = (double)(1.35f * sqrtf((float)dk_est)) + slack;
+        if (!(r >= 0.25 * r_first)) r = 0.25 * r_first;
+        int lo[3], hi[3];
+        bool all = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double fl = floor((c3[a] - r - G.mn[a]) * G.inv_h - 1e-6);
+            const double fh = floor((c3[a] + r - G.mn[a]) * G.inv_h + 1e-6);
+            lo[a] = fl < 0.0 ? 0 : (fl > (double)(G.dim[a] - 1) ? G.dim[a] - 1 : (int)fl);
+            hi[a] = fh < 0.0 ? 0 : (fh > (double)(G.dim[a] - 1) ? G.dim[a] - 1 : (int)fh);
+            all = all && (fl <= 0.0) && (fh >= (double)(G.dim[a] - 1));
+        }
+        const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
+        const long nrows = (long)ny * nz;
+        bool mine = active && !all && nrows <= 16;                 // this group does the query itself (so far)
+        const double r_eff = (r - slack) * (1.0 - 1.5e-12);
+        const double thr = r_eff > 0.0 ? r_eff * r_eff : -1.0;
+        const double r2 = r * r;
+        // ---- rows: lane gl takes row gl of the ball's (ny x nz) block ----
+        uint32_t rbeg = 0, rlen = 0;
+        if (mine && gl < (int)nrows) {
+            int oy, oz;
+            row_split((long)gl, ny, 1.0f / (float)ny, true, oy, oz);
+            const int cy = lo[1] + oy, cz = lo[2] + oz;
+            const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
+            int xl = lo[0], xh = hi[0];
+            const double yl = G.mn[1] + (double)cy * G.h, zl = G.mn[2] + (double)cz * G.h;
+            const double dy = fmax(fmax(yl - etol - ay, ay - (yl + G.h + etol)), 0.0);
+            const double dz = fmax(fmax(zl - etol - az, az - (zl + G.h + etol)), 0.0);
+            const double rem = r2 - fma(dy, dy, dz * dz);
+            if (rem >= 0.0) {
+                const double hw = (rem < 1e-30 ? 1e-15 : (double)(sqrtf((float)rem) * 1.000001f)) + etol;
+                const double fl = floor((ax - hw - G.mn[0]) * G.inv_h - 1e-6);
+                const double fh = floor((ax + hw - G.mn[0]) * G.inv_h + 1e-6);
+                const int tl = fl < 0.0 ? 0 : (fl > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fl);
+                const int th = fh < 0.0 ? 0 : (fh > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fh);
+                xl = tl > xl ? tl : xl; xh = th < xh ? th : xh;
+            } else {
+                xh = xl - 1;
+            }
+            if (xh >= xl) {
+                rbeg = cell_start[row + xl];
+                rlen = cell_start[row + xh + 1] - rbeg;
+            }
+        }
+        // ---- sweep: the group's non-empty rows one after the other, 16 records at a time; survivors compacted into its LDS ----
+        unsigned todo = (unsigned)(__ballot(rlen > 0) >> gbase) & 0xffffu;
+        unsigned ns = 0;
+        while (__any(todo != 0u)) {
+            const bool has = todo != 0u;
+            const int j = has ? __ffs((int)todo) - 1 : 0;
+            todo &= todo - 1u;                                                  // (0 stays 0)
+            const uint32_t vb = (uint32_t)__shfl((int)rbeg, gbase + j);
+            const uint32_t vl = has ? (uint32_t)__shfl((int)rlen, gbase + j) : 0u;
+            for (uint32_t o = 0; __any(o < vl); o += 16) {
+                const bool ok = o + (uint32_t)gl < vl;
+                const double4 P = rec[ok ? vb + o + (uint32_t)gl : 0u];
+                const double dx = P.x - ax, dy = P.y - ay, dz = P.z - az;
+                const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                const bool sv = ok && d2 <= thr;
+                const unsigned long long m = __ballot(sv);
+                if (m) {
+                    const unsigned mg = (unsigned)(m >> gbase) & 0xffffu;
+                    const unsigned pos = ns + (unsigned)__popc(mg & ((1u << gl) - 1u));
+                    if (sv && pos < (unsigned)KG_CAP) {
+                        keys[pos].d2 = d2; keys[pos].idx = (uint32_t)__double_as_longlong(P.w); keys[pos].pad = vb + o + (uint32_t)gl;
+                    }
+                    ns += (unsigned)__popc(mg);
+                }
+                if (work) n_cand += ok ? 1 : 0;
+            }
+        }
+        mine = mine && ns >= (unsigned)k && ns <= (unsigned)KG_CAP;
+        if (active && !mine && gl == 0) {
+            // not a one-pass case: the one-query-per-wave kernel does this slot in the next launch
+            redo_list[atomicAdd(redo_count, 1u)] = (uint32_t)(slot0 + b);
+        }
+        if (work && gl == 0) { n_act += active ? 1 : 0; n_defer += (active && !mine) ? 1 : 0; n_surv += mine ? ns : 0; }
+        // ---- rank by counting inside the group (entries gl, gl + 16, gl + 32, gl + 48), the four groups in lock step ----
+        wave_lds_sync();
+        const unsigned nsm = mine ? ns : 0u;
+        unsigned nmax = nsm;
+        { unsigned o = lane_xor32<16>(nmax); nmax = o > nmax ? o : nmax; o = lane_xor32<32>(nmax); nmax = o > nmax ? o : nmax; }
+        nmax = (unsigned)__builtin_amdgcn_readfirstlane((int)nmax);
+        double md[4]; uint32_t mi[4], mp[4]; unsigned rk[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned e = (unsigned)gl + 16u * t;
+            const bool hs = e < nsm;
+            md[t] = hs ? keys[e].d2 : __builtin_inf();
+            mi[t] = hs ? keys[e].idx : 0xffffffffu;
+            mp[t] = hs ? keys[e].pad : 0u;
+            rk[t] = 0;
+        }
+        if (nmax <= 32u) {
+            for (unsigned j = 0; j < nmax; ++j) {
+                const double od = keys[j].d2; const uint32_t oi = keys[j].idx;      // (one address per group)
+                const unsigned in = j < nsm ? 1u : 0u;
+                rk[0] += in & (unsigned)((od < md[0]) | ((od == md[0]) & (oi < mi[0])));
+                rk[1] += in & (unsigned)((od < md[1]) | ((od == md[1]) & (oi < mi[1])));
+            }
+        } else {
+            for (unsigned j = 0; j < nmax; ++j) {
+                const double od = keys[j].d2; const uint32_t oi = keys[j].idx;
+                const unsigned in = j < nsm ? 1u : 0u;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) rk[t] += in & (unsigned)((od < md[t]) | ((od == md[t]) & (oi < mi[t])));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned e = (unsigned)gl + 16u * t;
+            if (e < nsm && rk[t] < (unsigned)k) {
+                const unsigned rr = rk[t];
+                const double4 W = rec[mp[t]];
+                nbr[3 * rr] = W.x; nbr[3 * rr + 1] = W.y; nbr[3 * rr + 2] = W.z;
+                if (rr == (unsigned)(k - 1)) *dk_slot = md[t];
+                if (idx_out) idx_out[q * k + rr] = idx_base + (int64_t)mi[t];
+                if (d2_out) d2_out[q * k + rr] = md[t];
+            }
+        }
+        wave_lds_sync();
+        if (mine) dk_est = 0.75 * dk_est + 0.25 * *dk_slot;
+        if (cov_out) {
+            double mean = 0.0;
+            if (gl < 3 && mine) {
+                for (int s = 0; s < k; ++s) mean += nbr[3 * s + gl];
+                mean /= (double)k;
+            }
+            const double m0 = __shfl(mean, gbase), m1 = __shfl(mean, gbase + 1), m2 = __shfl(mean, gbase + 2);
+            if (gl < 6 && mine) {
+                const int a = gl < 3 ? 0 : (gl < 5 ? 1 : 2);
+                const int c = gl < 3 ? gl : (gl < 5 ? gl - 2 : 2);
+                const double ma = a == 0 ? m0 : (a == 1 ? m1 : m2), mc = c == 0 ? m0 : (c == 1 ? m1 : m2);
+                double cv = 0.0;
+                for (int s = 0; s < k; ++s) cv = fma(nbr[3 * s + a] - ma, nbr[3 * s + c] - mc, cv);
+                cov_out[6 * (slot0 + b) + gl] = cv * inv_km1;
+            }
+        }
+        wave_lds_sync();
+    }
+    if (work) {
+        n_cand = wsum_u64(n_cand); n_act = wsum_u64(n_act); n_defer = wsum_u64(n_defer); n_surv = wsum_u64(n_surv);
+        if (lane == 0) { atomicAdd(work, n_cand); atomicAdd(work + 1, n_act - n_defer); atomicAdd(work + 3, n_surv); }
     }
 }
 
@@ -1490,7 +1700,8 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int bi = 16 * tid + j;
-            h[j] = __hip_atomic_load(&S->whist[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (zoned flush: bins outside the zones were never added to -- 256 blocks need not ask the memory side for 3 700 zeros each)
+            h[j] = (!zoned || h3_region(bi) < 0) ? __hip_atomic_load(&S->whist[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             if (zoned) {
                 const int rg = bi == H3_ZL_LO - 1 ? 0 : (bi == H3_ZM_LO - 1 ? 1 : (bi == H3_ZR_LO - 1 ? 2 : -1));
                 if (rg >= 0) h[j] += __hip_atomic_load(&S->wcoarse[rg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2067,21 +2278,38 @@ bool grid_knn_sweep_handles(int k) { return k >= 1 && k <= KS_MAXK; }
 void launch_grid_knn_sweep(hipStream_t s, const double *qx, const double *qy, const double *qz, const uint32_t *order, long Q, int k,
                            const GridGeom &G, double avg_per_cell, const uint32_t *cell_start, const void *rec, double rmax,
                            int64_t idx_base, double *d2_out, int64_t *idx_out, double *cov, float *normals, float *planarity,
-                           unsigned long long *work, long batch_override)
+                           unsigned long long *work, long batch_override, uint32_t *redo /* Q + 1 words of scratch, or null */, int group)
 {
-    // a wave stays with a neighbourhood for a few queries once there are enough waves to fill the machine several times over
-    long batch = batch_override > 0 ? batch_override : (Q >= 131072 ? 8 : (Q >= 32768 ? 4 : 1));
-    batch = batch < 1 ? 1 : (batch > 64 ? 64 : batch);
     const double ppc = avg_per_cell >= 1.0 ? avg_per_cell : 1.0;
     double r_first = 1.35 * G.h * std::sqrt((double)k / (3.141592653589793 * ppc));
     if (!(r_first > 0.0) || !std::isfinite(r_first)) r_first = G.h;
-    unsigned g = cdiv(Q, 4 * batch);
-    if (order) g = (g + 7u) & ~7u;
     const int kpad = (k + 7) & ~7;
     double *cov_out = normals ? cov : nullptr;
+    // four queries per wave for the common case + the one-query-per-wave kernel for what it leaves (k <= 32, enough queries to
+    // fill the machine with groups); otherwise the one-query-per-wave kernel for everything
+    const bool four = redo && k <= KG_MAXK && (group == 4 || (group == 0 && Q >= 32768));
+    const uint32_t *redo_list = nullptr;
+    const unsigned *redo_count = nullptr;
+    if (four) {
+        long batch = batch_override > 0 ? batch_override : 4;            // (measured at 1 M queries: 4 -> 0.93 ms, 8 -> 0.99, 16 -> 1.05)
+        batch = batch < 1 ? 1 : (batch > 16 ? 16 : batch);
+        unsigned g4 = cdiv(Q, 16 * batch);
+        if (order) g4 = (g4 + 7u) & ~7u;
+        (void)hipMemsetAsync(redo, 0, sizeof(uint32_t), s);
+        hipLaunchKernelGGL(k_grid_knn_sweep4, dim3(g4), dim3(256), 16 * kg_group_doubles(kpad) * sizeof(double), s, qx, qy, qz, order, cell_start,
+                           (const double4 *)rec, Q, k, (int)batch, G, rmax, r_first, idx_base, d2_out, idx_out, cov_out, redo + 1,
+                           (unsigned *)redo, work);
+        redo_list = redo + 1; redo_count = (const unsigned *)redo;
+    }
+    // a wave stays with a neighbourhood for a few queries once there are enough waves to fill the machine several times over
+    long batch = batch_override > 0 ? batch_override : (Q >= 131072 ? 8 : (Q >= 32768 ? 4 : 1));
+    batch = batch < 1 ? 1 : (batch > 64 ? 64 : batch);
+    unsigned g = four ? cdiv(Q, 256) : cdiv(Q, 4 * batch);                 // (redo: Q / 64 waves cover the list whatever its length)
+    if (order && !four) g = (g + 7u) & ~7u;
 #define SICP_KS_LAUNCH(NS)                                                                                                     \
     hipLaunchKernelGGL((k_grid_knn_sweep<NS>), dim3(g), dim3(256), 4 * ks_wave_doubles(64 * NS, kpad) * sizeof(double), s, qx, qy, qz, order, \
-                       cell_start, (const double4 *)rec, Q, k, (int)batch, G, rmax, r_first, idx_base, d2_out, idx_out, cov_out, work)
+                       cell_start, (const double4 *)rec, Q, k, (int)batch, G, rmax, r_first, idx_base, d2_out, idx_out, cov_out, work,   \
+                       redo_list, redo_count)
     if (k <= 32) SICP_KS_LAUNCH(2);
     else if (k <= 64) SICP_KS_LAUNCH(4);
     else SICP_KS_LAUNCH(8);

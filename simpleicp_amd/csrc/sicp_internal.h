@@ -133,7 +133,8 @@ bool grid_knn_sweep_handles(int k);
 void launch_grid_knn_sweep(hipStream_t s, const double *qx, const double *qy, const double *qz, const uint32_t *order, long Q, int k,
                            const GridGeom &G, double avg_per_cell, const uint32_t *cell_start, const void *rec, double rmax,
                            int64_t idx_base, double *d2_out, int64_t *idx_out, double *cov /* (Q, 6) scratch when normals are asked for */,
-                           float *normals, float *planarity, unsigned long long *work, long batch_override = 0);
+                           float *normals, float *planarity, unsigned long long *work, long batch_override = 0,
+                           uint32_t *redo = nullptr /* Q + 1 words: enables the four-queries-per-wave kernel */, int group = 0 /* 0 auto, 1, 4 */);
 
 void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec);
 void launch_pack_idx(hipStream_t s, const int64_t *idx, long cnt, long per, double *out);

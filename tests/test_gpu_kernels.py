@@ -669,12 +669,15 @@ def _knn_cases():
 
 
 @pytest.mark.parametrize("case", list(_knn_cases()))
-@pytest.mark.parametrize("batch,ordered", [("0", False), ("64", True), ("5", True)])
-def test_knn_sweep_equals_rounds_and_oracle(case, batch, ordered):
-    """sicp_knn(k > 1) and sicp_estimate_normals through the one-sweep kernel -- one query per wave, and batches of 5 / 64 queries in
-    cell order whose starting radius is the previous query's k-th distance -- against the k-round search + k_normals
-    (SICP_KNN_SWEEP=0) and the oracle: indices and squared distances bit for bit, normals / planarity bit for bit against the
-    other kernel pair and to 1 ulp(f32) against the oracle (pointcloud.py:185-203)."""
+@pytest.mark.parametrize("batch,ordered,group", [("0", False, "1"), ("64", True, "1"), ("5", True, "1"), ("0", True, "4"), ("16", False, "4"),
+                                                 ("3", True, "4")])
+def test_knn_sweep_equals_rounds_and_oracle(case, batch, ordered, group):
+    """sicp_knn(k > 1) and sicp_estimate_normals through the one-sweep kernels -- one query per wave (batches of 1 / 5 / 64 queries in
+    cell order whose starting radius follows the k-th distances met so far), and FOUR queries per wave (16 lanes each: the common
+    case; what it leaves -- short balls, dense clusters, coincident points, k > 32 -- goes through the one-query-per-wave kernel in
+    a second launch) -- against the k-round search + k_normals (SICP_KNN_SWEEP=0) and the oracle: indices and squared distances
+    bit for bit, normals / planarity bit for bit against the other kernel pair and to 1 ulp(f32) against the oracle
+    (pointcloud.py:185-203)."""
     import os
     from simpleicp_amd import _lib
     P, k = _knn_cases()[case]
@@ -683,7 +686,8 @@ def test_knn_sweep_equals_rounds_and_oracle(case, batch, ordered):
     sel = np.sort(rng.choice(n, min(n, 700), replace=False))
     out = {}
     for sweep in ("1", "0"):
-        env = {"SICP_KNN1": "grid", "SICP_KNN_SWEEP": sweep, "SICP_KNN_BATCH": batch, "SICP_ORDER_MIN_Q": "1" if ordered else "0"}
+        env = {"SICP_KNN1": "grid", "SICP_KNN_SWEEP": sweep, "SICP_KNN_BATCH": batch, "SICP_ORDER_MIN_Q": "1" if ordered else "0",
+               "SICP_KNN_GROUP": group}
         os.environ.update(env)
         try:
             c = _lib.Context(0)
