@@ -656,17 +656,20 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
            "solver": {"final_n_kept": int(last.n_kept), "final_res_std": last.res_std}}
     # SURVEY 8(d), normals (one-off): bytes_alg = N_f * 3 * 8 + Q * (3 * 8 + k * 8 + 16); reported as Q * k neighbours / s as well
     nms = float(np.median(nrm_ms))
-    rn = roof("k_grid_knn_sweep", nms, Nf * 24 + nq * (24 + k * 8 + 16),
-              "estimate_normals' kernels (k_grid_knn_sweep: one sweep over the ball's cells per query, survivors ranked in LDS, mean + "
-              "covariance from the coordinates it holds; k_cov_normals: Jacobi eigen-solver, one lane per query) on the resident grid; "
-              "bytes_alg is SURVEY 8(d)'s brute-force figure (the whole cloud once + per-query terms) -- the pruned search reads "
-              "`bytes_read_tallied` instead; VALU-issue-bound (~690 vector instructions per query)",
+    nkern = "k_grid_knn_sweep4" if (k <= 32 and nq >= 32768) else "k_grid_knn_sweep"
+    rn = roof(nkern, nms, Nf * 24 + nq * (24 + k * 8 + 16),
+              "estimate_normals' kernels (k_grid_knn_sweep4: one sweep over the ball's cells per query, four queries per wave, survivors "
+              "ranked in LDS, mean + covariance from the winners' coordinates; k_grid_knn_sweep: the same one query per wave, for what "
+              "the first leaves (~0.2 % of the queries) and for small query sets; k_cov_normals: Jacobi eigen-solver, one lane per "
+              "query) on the resident grid; bytes_alg is SURVEY 8(d)'s brute-force figure (the whole cloud once + per-query terms) -- "
+              "the pruned search reads `bytes_read_tallied` instead; bound by vector-instruction issue and latency (~270 instructions per query)",
               {"neighbours_per_s": nq * k / (nms * 1e-3) if nms > 0 else None,
                "candidates_per_query": knn_work["candidates"] / nq, "sweeps_per_query": knn_work["sweeps"] / nq,
                "queries_on_k_round_path": knn_work["slow_queries"],
                "bytes_read_tallied": int(knn_work["candidates"] * 32 + nq * (24 + 48 + 16)), "kernel_ms_all": nrm_ms})
-    if rn["traffic"] is not None and pmc.get("k_cov_normals" + tag) is not None:
-        rn["traffic"] += pmc["k_cov_normals" + tag]               # both kernels of the call
+    for other in ("k_cov_normals", "k_grid_knn_sweep"):            # every kernel of the call
+        if rn["traffic"] is not None and other != nkern and pmc.get(other + tag) is not None:
+            rn["traffic"] += pmc[other + tag]
     if rn["traffic"] is not None and nms > 0:
         rn["frac_on_pmc_traffic"] = rn["traffic"] / (nms * 1e-3) / 1e9 / HBM_PEAK_GBS
     out["roofline_normals"] = rn
