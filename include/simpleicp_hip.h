@@ -118,7 +118,8 @@ int sicp_select_in_range(sicp_ctx *ctx, int query_slot, int search_slot, const i
  * symmetric eigen-decomposition in fp64; normal = eigenvector of the smallest eigenvalue
  * with its largest-magnitude component made positive (np.linalg.eig's sign is arbitrary),
  * planarity = (l_mid - l_min) / l_max; both stored as float32 like the reference.
- *   normals_out (Q,3) float32, planarity_out (Q) float32, nn_idx_out (Q,k) int64 or NULL. */
+ *   normals_out (Q,3) float32, planarity_out (Q) float32, nn_idx_out (Q,k) int64 or NULL (on a binned cloud the neighbour
+ *   lists are not even formed in memory unless asked for: one sweep per query, covariance from the winners' coordinates). */
 int sicp_estimate_normals(sicp_ctx *ctx, int slot, const int64_t *sel_idx, int64_t Q, int k,
                           float *normals_out, float *planarity_out, int64_t *nn_idx_out);
 
@@ -310,7 +311,7 @@ int sicp_xyz_write(const char *path, const double *data, int64_t n, int cols, in
 int sicp_timing_enable(sicp_ctx *ctx, int on);   /* 0 off, 1 kernel timing, 2 timing + the grid search's work tallies (sicp_match_work) */
 /* which 1-NN flavour the last sicp_knn(k=1) / sicp_icp_iterate used: 0 exact scan, 1 filtered scan
  * with inline verification, 2 grid search, 3 filtered scan (VALU filter) with recorded candidates + fix-up kernel,
- * 4 the same with the filter on the FP32 matrix pipe, 5 grid search with four queries per wave (all return identical
+ * (4: the matrix-pipe filter of ABI <= 3, removed), 5 grid search with four / eight queries per wave (all return identical
  * results) */
 int sicp_last_match_kernel(sicp_ctx *ctx, int *kind_out);
 int sicp_timing_reset(sicp_ctx *ctx);
