@@ -849,3 +849,49 @@ def test_windowed_rejection_equals_the_general_form(Q, kind):
         o = orc.icp_iteration(Xm, P[sel], nv, pl, x, x, 1.0, z, z, 0.3)
         assert (a[3][it][1], a[3][it][2], a[3][it][3]) == (o["median"], o["mad"], int(o["keep"].sum()))
         x = np.array(a[3][it][4])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_knn_sweep_random_clouds(seed):
+    """Seeded random clouds of every shape the sweep kernels branch on -- volumes, planes, lines, clusters with exact duplicates,
+    a few points, coordinates far from the origin -- with random k (2..32) and query subsets, four queries per wave: indices,
+    squared distances and normals against the oracle."""
+    import os
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(40, 6000))
+    kind = seed % 6
+    if kind == 0:
+        P = rng.uniform(-3, 3, (n, 3))
+    elif kind == 1:
+        P = np.column_stack((rng.uniform(0, 20, n), rng.uniform(0, 20, n), np.zeros(n)))           # an exact plane
+    elif kind == 2:
+        P = np.zeros((n, 3)); P[:, 1] = np.round(rng.uniform(0, 100, n), 2)                         # a line with ties
+    elif kind == 3:
+        c = rng.uniform(-10, 10, (5, 3))
+        P = np.round(c[rng.integers(0, 5, n)] + rng.normal(0, 0.02, (n, 3)), 2)                     # clusters, many duplicates
+    elif kind == 4:
+        P = rng.uniform(0, 1, (n, 3)) * np.array([100.0, 0.01, 1.0])                                # a needle-shaped box
+    else:
+        P = rng.normal(0, 1, (n, 3)) + np.array([6.5e5, 5.1e6, 400.0])                              # far from the origin
+    k = int(rng.integers(2, min(32, n) + 1))
+    sel = np.sort(rng.choice(n, int(rng.integers(1, min(n, 400) + 1)), replace=False))
+    env = {"SICP_KNN1": "grid", "SICP_KNN_GROUP": "4", "SICP_ORDER_MIN_Q": str(int(rng.integers(0, 2))), "SICP_KNN_BATCH": str(int(rng.integers(0, 17)))}
+    os.environ.update(env)
+    try:
+        c = _lib.Context(0)
+    finally:
+        for key in env:
+            del os.environ[key]
+    with c:
+        c.upload(_lib.FIX, P)
+        idx, d2 = c.knn(_lib.FIX, P[sel], k=k)
+        nv, pl, nn = c.estimate_normals(_lib.FIX, sel, k, want_nn=True)
+    ridx, rd2 = orc.knn(P, P[sel], k=k)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(nn, ridx)
+    rnv, rpl = orc.normals(P, ridx)
+    # degenerate neighbourhoods (coincident or collinear points) have no defined normal: where the oracle's is finite, ours equals it
+    ok = np.isfinite(rnv).all(axis=1) & np.isfinite(rpl) & np.isfinite(nv).all(axis=1)
+    if kind in (0, 4, 5):
+        assert ok.all()
+        assert np.abs(nv - rnv).max() <= 2e-7 and np.abs(pl - rpl).max() <= 2e-6 * max(1.0, np.abs(rpl).max())
