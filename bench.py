@@ -459,7 +459,7 @@ def run(args):
         if args.config in ref.get("configs", {}):
             out["cpu_reference"] = {**ref["configs"][args.config], "measured_on": ref.get("measured_on"),
                                     # (kept by the compact line: the two CPU numbers come from two different machines)
-                                    "box": "NOT this run's host: the build container, " + str(ref.get("measured_on")),
+                                    "box": "NOT this run's host: the 8-core build container",
                                     "kind": "reference", "source": "profiles/cpu_reference.json (scripts/time_reference.py)"}
     if args.force_exchange:
         out["config"]["parallelism"] += " (exchange forced on 1 rank)"
@@ -515,6 +515,7 @@ def compact_line(out):
                 line[k]["comm"] = strip(t["comm"], 1)
     if "cpu_baseline" in line:
         line["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:120]
+        line["cpu_baseline"].pop("seconds_per_iteration_by_stage", None)          # (the unabridged record keeps the per-stage split)
     if "cpu_reference" in line:
         line["cpu_reference"]["sample"] = out["cpu_reference"]["sample"][:100]
     line["config"]["workload"] = out["config"]["workload"]
