@@ -504,7 +504,10 @@ def compact_line(out):
                        "iterations_per_s": float(f"{t['iterations_per_s']:.6g}"),
                        "correspondences_per_s": float(f"{t['correspondences_per_s']:.6g}"), "parallelism": t["parallelism"],
                        "roofline": strip(t["roofline"], 1),
-                       "roofline_normals": {kk: vv for kk, vv in strip(t["roofline_normals"], 1).items() if kk != "kernel_ms_all"},
+                       "roofline_normals": {kk: (vv if kk != "parity" else {"ok": vv.get("ok"), "queries_sampled": vv.get("queries_sampled")})
+                                            for kk, vv in strip(t["roofline_normals"], 1).items()
+                                            if kk in ("kernel", "avg_ms", "achieved", "frac", "bytes_alg_per_launch", "traffic", "frac_on_pmc_traffic",
+                                                      "neighbours_per_s", "candidates_per_query", "parity")},
                        "kernel_ms": {n: round(v["avg_ms"], 6) for n, v in t["kernels_instrumented"].items() if v["launches"]},
                        "evaluations_per_iteration": t["roofline_solver"].get("evaluations_per_iteration")}
             if "parity" in t:
