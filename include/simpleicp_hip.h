@@ -38,8 +38,8 @@ extern "C" {
 
 /* 1: round 1.  2: + sicp_corr_*, sicp_estimate_parameters, sicp_comm_*, sicp_set_partition, sicp_cloud_set_planarity,
  * sicp_cloud_download_columns, sicp_match_work; sicp_timing_enable(ctx, 2); every upload resets the slot's planarity
- * column.  3: + sicp_comm_activate, sicp_comm_info, sicp_device_memory; SICP_K_XCHG; sicp_comm_init bounded + handshake.  4: + sicp_knn_work, sicp_cloud_download_both; sicp_estimate_normals runs the one-sweep k-NN + covariance kernel.  A binding checks sicp_abi_version() against the header it was written for. */
-#define SICP_ABI_VERSION 4
+ * column.  3: + sicp_comm_activate, sicp_comm_info, sicp_device_memory; SICP_K_XCHG; sicp_comm_init bounded + handshake.  4: + sicp_knn_work, sicp_cloud_download_both; sicp_estimate_normals runs the one-sweep k-NN + covariance kernel.  5: + sicp_match_deferred; kind 6 of sicp_last_match_kernel.  A binding checks sicp_abi_version() against the header it was written for. */
+#define SICP_ABI_VERSION 5
 
 #define SICP_OK               0
 #define SICP_ERR_INVALID     -1   /* bad argument / wrong call order                         */
@@ -311,14 +311,19 @@ int sicp_xyz_write(const char *path, const double *data, int64_t n, int cols, in
 int sicp_timing_enable(sicp_ctx *ctx, int on);   /* 0 off, 1 kernel timing, 2 timing + the grid search's work tallies (sicp_match_work) */
 /* which 1-NN flavour the last sicp_knn(k=1) / sicp_icp_iterate used: 0 exact scan, 1 filtered scan
  * with inline verification, 2 grid search, 3 filtered scan (VALU filter) with recorded candidates + fix-up kernel,
- * (4: the matrix-pipe filter of ABI <= 3, removed), 5 grid search with four / eight queries per wave (all return identical
- * results) */
+ * (4: the matrix-pipe filter of ABI <= 3, removed), 5 grid search with four / eight queries per wave, exact arithmetic on every
+ * candidate, 6 grid search with four / eight queries per wave through the float32 filter (+ the exact kernel for what the filter
+ * cannot decide) -- all return identical results */
 int sicp_last_match_kernel(sicp_ctx *ctx, int *kind_out);
 int sicp_timing_reset(sicp_ctx *ctx);
 /* Work the pruned grid search did in its launches since sicp_timing_reset, counted by the kernel itself while
  * sicp_timing_enable(ctx, 2) is in force: out3[0] candidates evaluated (one 32-byte record read each), out3[1] non-empty grid rows
  * visited (two 4-byte offsets each), out3[2] launches -- the bytes the bench prices the search's roofline on. */
 int sicp_match_work(sicp_ctx *ctx, uint64_t out3[3]);
+/* ... and how many queries the float32-filtered search (kind 6) left to the exact kernel in those launches: ties within the
+ * filter's margin and queries float32 cannot place.  (The filtered search reads a 16-byte record per candidate, plus the winner's
+ * 32-byte record per query and pass.) */
+int sicp_match_deferred(sicp_ctx *ctx, uint64_t *out);
 /* Work the one-sweep k-NN (sicp_estimate_normals, sicp_knn with k > 1 on a binned cloud) did since sicp_timing_reset, under
  * sicp_timing_enable(ctx, 2): out4[0] candidates read (one 32-byte record each), out4[1] sweeps (a query needs one when its first
  * ball holds k points), out4[2] queries that took the k-round extraction instead, out4[3] candidates inside their query's ball. */

@@ -21,9 +21,9 @@ OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_TOO_FEW, ERR_NUMERIC, ERR_EXCHANGE 
 XCHG_ALLGATHER_F64, XCHG_SUM_F64 = 1, 2
 PART_CLOUD, PART_QUERIES = 0, 1
 K_KNN1, K_KNNK, K_NORMALEQ, K_SELECT, K_XCHG = 0, 1, 2, 3, 4
-ABI_VERSION = 4          # include/simpleicp_hip.h SICP_ABI_VERSION this binding was written for
+ABI_VERSION = 5          # include/simpleicp_hip.h SICP_ABI_VERSION this binding was written for
 KERNEL_NAMES = {K_KNN1: "match", K_KNNK: "knnk_scan", K_NORMALEQ: "solve", K_SELECT: "reject_select", K_XCHG: "exchange"}
-MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1_frec", 5: "k_grid_nn16"}
+MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1_frec", 5: "k_grid_nn16", 6: "k_grid_nn16f"}
 
 EXPORTS = [
     "sicp_abi_version", "sicp_last_error", "sicp_device_count", "sicp_ctx_create", "sicp_ctx_destroy",
@@ -31,7 +31,7 @@ EXPORTS = [
     "sicp_cloud_download", "sicp_cloud_download_columns", "sicp_cloud_download_both", "sicp_cloud_set_planarity", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
     "sicp_corr_match", "sicp_corr_reject_planarity", "sicp_corr_reject_distances", "sicp_estimate_parameters",
-    "sicp_set_exchange", "sicp_comm_unique_id", "sicp_comm_init", "sicp_comm_destroy", "sicp_comm_activate", "sicp_comm_info", "sicp_device_memory", "sicp_set_partition", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_knn_work", "sicp_last_match_kernel",
+    "sicp_set_exchange", "sicp_comm_unique_id", "sicp_comm_init", "sicp_comm_destroy", "sicp_comm_activate", "sicp_comm_info", "sicp_device_memory", "sicp_set_partition", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_match_deferred", "sicp_knn_work", "sicp_last_match_kernel",
     "sicp_xyz_count", "sicp_xyz_read", "sicp_xyz_write",
 ]
 
@@ -124,6 +124,7 @@ def load():
     L.sicp_timing_enable.argtypes = [vp, cint]
     L.sicp_timing_reset.argtypes = [vp]
     L.sicp_match_work.argtypes = [vp, vp]
+    L.sicp_match_deferred.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.sicp_knn_work.argtypes = [vp, vp]
     L.sicp_last_match_kernel.argtypes = [vp, C.POINTER(cint)]
     L.sicp_xyz_count.argtypes = [C.c_char_p, C.POINTER(i64)]
@@ -498,7 +499,9 @@ class Context:
         """Work counters of the grid search since timing_reset (kept while timing is enabled)."""
         out = np.zeros(3, np.uint64)
         self._chk(self._L.sicp_match_work(self._h, _ptr(out)))
-        return {"candidates": int(out[0]), "rows": int(out[1]), "launches": int(out[2])}
+        d = C.c_uint64(0)
+        self._chk(self._L.sicp_match_deferred(self._h, C.byref(d)))
+        return {"candidates": int(out[0]), "rows": int(out[1]), "launches": int(out[2]), "deferred": int(d.value)}
 
     def knn_work(self):
         """Work counters of the one-sweep k-NN (normals) since timing_reset (kept while timing_enable(2) is in force)."""

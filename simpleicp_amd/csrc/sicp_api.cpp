@@ -98,6 +98,12 @@ struct Grid {
     bool cap_limited = false;        // the cell table's size limit, not the points-per-cell target, set the cell size
     DevBuf<uint32_t> cell_start;     // ncells + 1
     DevBuf<double> rec;              // the cloud in cell order: packed 32-byte records (x, y, z, local row as int64 bits)
+    // companions, built the first time a search wants them (grid_companions) and dropped with the grid:
+    DevBuf<float> recf;              // the cloud in cell order as 16-byte float32 records relative to c0 (the filtered many-queries search)
+    DevBuf<unsigned long long> cell_box;   // the cells' tight boxes + counts (far searches trim their rows by them)
+    bool recf_valid = false, box_valid = false;
+    double c0[3] = {0, 0, 0}, eps_p = 0;   // float32 frame: centre of the cloud's box; 6e-8 x the largest |coordinate - c0|
+    bool filter_ok = false;          // float32 can hold the cloud (half extents below 1e15)
 };
 
 struct Cloud {
@@ -283,7 +289,19 @@ struct sicp_ctx {
     int coarse_iters = 1;          // SICP_COARSE_ITERS: chained iterations (from a cold start) whose search is bounded by the subsample's
     long coarse_min_n = 262144;    // ... for clouds of at least this many points
     long nn16_min_q = 32768;       // SICP_NN16_MIN_Q: from this many queries per launch on the grid search runs four queries per wave
-    int last_match_kernel = 0;     // 0 exact scan, 1 filtered scan (inline), 2 grid, 3 filtered scan (record + fix-up), 4 matrix-pipe filter, 5 grid, four queries per wave
+    int nn16_filter = 2;           // SICP_NN16 = exact (0: k_grid_nn16) | far (1: the filtered search, one flavour) | near (2, default: the lean
+                                   // flavour first, the full one for what it leaves)
+    bool use_boxes = true;         // SICP_BOXES=0: far searches do not trim their rows by the cells' tight boxes
+    bool boxes_always = false;     // SICP_BOXES=2: ... and stand-alone searches of a handful of queries build them too (tests)
+    long box_min_q = 0;            // SICP_BOX_MIN_Q: build the boxes only for runs with at least this many correspondences
+    DevBuf<double> q_slot, p_slot; // filtered search: queries (x, y, z, index) and their last matches in SLOT order (32 bytes each)
+    long slot_lo = -1, slot_cnt = 0;
+    bool slot_ordered = false;
+    DevBuf<double> kq_slot, kp_slot;   // ... of a stand-alone search (sicp_knn k = 1, sicp_select_in_range, the operators): the run's stay untouched
+    DevBuf<uint8_t> nn_state;      // by slot: 1 = the lean flavour left this query to the full one
+    DevBuf<uint32_t> nn_redo;      // [0], [1] counters (alternating by launch), [2..] queries left to the exact kernel
+    int nn_parity = 0;
+    int last_match_kernel = 0;     // 0 exact scan, 1 filtered scan (inline), 2 grid, 3 filtered scan (record + fix-up), 5 grid, four queries per wave (exact), 6 grid, float32 filter
     // ICP state (selected fixed points and per-iteration products)
     int64_t Q = 0, qpad = 0;
     DevBuf<double> q;              // qx|qy|qz [qpad]
@@ -687,6 +705,7 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
 {
     if (gr.valid) return SICP_OK;
     gr.cap_limited = false;
+    gr.recf_valid = false; gr.box_valid = false;
     double mn[3], ex[3], vol = 1.0; int deff = 0;
     for (int a = 0; a < 3; ++a) {
         mn[a] = cl.bb_lo[a];
@@ -794,6 +813,35 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
     HIPCHK(hipGetLastError());
     CHK(sync(c));
     gr.valid = true;
+    return SICP_OK;
+}
+
+// The companions of a grid that exists: float32 records for the filtered search, tight boxes for far searches.  Each is one pass
+// (0.08 ms / 0.2 ms per 10 M points) paid by the first search that wants it.
+int grid_companions(sicp_ctx *c, const Cloud &cl, Grid &gr, long n, bool want_recf, bool want_box)
+{
+    if (!gr.valid) return fail(SICP_ERR_INVALID, "internal: grid companions before the grid");
+    if (want_recf && !gr.recf_valid) {
+        double half = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            gr.c0[a] = 0.5 * (cl.bb_lo[a] + cl.bb_hi[a]);
+            half = std::max(half, std::max(cl.bb_hi[a] - gr.c0[a], gr.c0[a] - cl.bb_lo[a]));
+        }
+        gr.filter_ok = std::isfinite(half) && half < 1.0e15;
+        gr.eps_p = 6.0e-8 * half;
+        if (gr.filter_ok) {
+            CHK(gr.recf.reserve((size_t)4 * n));
+            launch_recf(c->stream, gr.rec.p, n, gr.c0, gr.recf.p);
+            HIPCHK(hipGetLastError());
+        }
+        gr.recf_valid = true;
+    }
+    if (want_box && !gr.box_valid) {
+        CHK(gr.cell_box.reserve((size_t)gr.ncells));
+        launch_cell_boxes(c->stream, gr.cell_start.p, gr.rec.p, gr.ncells, gr.g, gr.cell_box.p);
+        HIPCHK(hipGetLastError());
+        gr.box_valid = true;
+    }
     return SICP_OK;
 }
 
@@ -918,11 +966,48 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
         CHK(grid_build(c, slot));
         Grid &gr = cl.grid;
         c->last_match_kernel = Q >= c->nn16_min_q ? 5 : 2;
+        // large query sets: through the float32 filter (sicp_gridf.hip), what it leaves (ties within its margin) through the exact
+        // kernel -- the same answers
+        if (Q >= c->nn16_min_q && c->nn16_filter != 0 && Q < (1L << 31)) {
+            CHK(grid_companions(c, cl, gr, cl.n, true, c->use_boxes));
+            if (gr.filter_ok) {
+                CHK(c->kq_slot.reserve((size_t)4 * Q)); CHK(c->kp_slot.reserve((size_t)4 * Q));
+                CHK(c->nn_state.reserve((size_t)Q));
+                if (c->nn_redo.cap < (size_t)Q + 2) {
+                    CHK(c->nn_redo.reserve((size_t)Q + 2));
+                    HIPCHK(hipMemsetAsync(c->nn_redo.p, 0, 2 * sizeof(uint32_t), c->stream));
+                }
+                launch_slot_queries(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, nullptr, prev_p2, Q, c->kq_slot.p, c->kp_slot.p);
+                const unsigned long long *cbox = c->use_boxes ? gr.cell_box.p : nullptr;
+                unsigned *tie_cnt = c->nn_redo.p + c->nn_parity, *tie_clear = c->nn_redo.p + (c->nn_parity ^ 1);
+                uint32_t *tie_list = c->nn_redo.p + 2;
+                unsigned long long *wk = c->count_work ? c->match_work.p : nullptr;
+                c->last_match_kernel = 6;
+                Timed t(c, SICP_K_KNN1);
+                const bool all_far = c->nn16_filter == 1;
+                if (!all_far)
+                    launch_grid_nn16f(c->stream, 16, false, nullptr, c->kq_slot.p, c->kp_slot.p, Q, gr.g, gr.c0, gr.eps_p, gr.cell_start.p,
+                                      gr.recf.p, gr.rec.p, nullptr, false, H, H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out,
+                                      idx_out, p2_out, wk, 0, c->nn_state.p, tie_list, tie_cnt);
+                launch_grid_nn16f(c->stream, 16, true, nullptr, c->kq_slot.p, c->kp_slot.p, Q, gr.g, gr.c0, gr.eps_p, gr.cell_start.p,
+                                  gr.recf.p, gr.rec.p, cbox, false, H, H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out,
+                                  p2_out, wk, 0, all_far ? nullptr : c->nn_state.p, tie_list, tie_cnt);
+                launch_grid_nn_redo(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, prev_p2, gr.g, gr.cell_start.p, gr.rec.p, nullptr, H,
+                                    H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out, p2_out, wk, 0, nullptr, cbox,
+                                    tie_list, tie_cnt, tie_clear);
+                c->nn_parity ^= 1;
+                HIPCHK(hipGetLastError());
+                return SICP_OK;
+            }
+        }
+        // (stand-alone searches of a few queries do not pay for the boxes of a cloud: SICP_BOXES=2 builds them anyway -- tests)
+        const bool boxes = c->use_boxes && (c->boxes_always || Q >= 4096);
+        if (boxes) CHK(grid_companions(c, cl, gr, cl.n, false, true));
         {
             Timed t(c, SICP_K_KNN1);
             launch_grid_nn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, prev_p2, gr.g, gr.cell_start.p, gr.rec.p, H,
                            H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out, p2_out,
-                           c->count_work ? c->match_work.p : nullptr, Q >= c->nn16_min_q);
+                           c->count_work ? c->match_work.p : nullptr, Q >= c->nn16_min_q, boxes ? gr.cell_box.p : nullptr);
         }
         HIPCHK(hipGetLastError());
         return SICP_OK;
@@ -1177,6 +1262,9 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_KNN_BATCH")) c->knn_batch = std::atol(e);
     if (const char *e = std::getenv("SICP_KNN_GROUP")) c->knn_group = std::atoi(e);
     if (const char *e = std::getenv("SICP_NN16_MIN_Q")) c->nn16_min_q = std::atol(e);
+    if (const char *e = std::getenv("SICP_NN16")) c->nn16_filter = !std::strcmp(e, "exact") ? 0 : !std::strcmp(e, "far") ? 1 : 2;
+    if (const char *e = std::getenv("SICP_BOXES")) { c->use_boxes = std::atoi(e) != 0; c->boxes_always = std::atoi(e) == 2; }
+    if (const char *e = std::getenv("SICP_BOX_MIN_Q")) c->box_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_COARSE_ITERS")) c->coarse_iters = std::atoi(e);
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
     if (const char *e = std::getenv("SICP_LM")) c->lm_one_launch = std::strcmp(e, "launches") != 0;
@@ -1713,22 +1801,78 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                     CHK(subsample_build(c, SICP_MOV));
                     CHK(c->bound_p2.reserve((size_t)3 * Q)); CHK(c->bound_d2.reserve(Q)); CHK(c->bound_idx.reserve(Q));
                 }
-                Timed t(c, SICP_K_KNN1);
-                if (coarse)
-                    launch_grid_nn_chained(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt, nullptr,
-                                           cl.sub_grid.g, cl.sub_grid.cell_start.p, cl.sub_grid.rec.p, c->icp_dev.p, cl.rmax, 0,
-                                           c->bound_d2.p + lo, c->bound_idx.p + lo, c->bound_p2.p + 3 * lo, nullptr,
-                                           ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q);
-                // without an exchange the match is final when its kernel ends: the winning lanes leave the point-to-plane
-                // distance and the planarity verdict too (what k_postmatch would re-read 72 bytes per correspondence for)
-                // (only in the one-wave-per-query flavour: with four queries per wave at the register limit the epilogue's late
-                // loads cost the search more than k_postmatch's launch -- match 693 -> 758 us at 1 M queries, measured)
-                post_done = !c->collective() && c->match_epilogue && cnt < c->nn16_min_q;
                 // EIGHT queries per wave (8 lanes each) once the query set is large and cells are small: twice the independent
                 // requests per wave in flight (0.69 -> 0.62 ms per 1 M queries on 10 M points); not with long rows (C5 sizes: the cell
                 // table's limit leaves 25 points per cell, 8 lanes need twice the steps: 2.07 -> 2.53 ms per step) nor below ~200 k
                 // queries (too few waves to fill the machine)
                 const bool eight = c->nn_group ? c->nn_group == 8 : (cnt >= 196608 && !cl.grid.cap_limited && cl.grid.avg_per_cell <= 20.0);
+                const bool many_q = cnt >= c->nn16_min_q;
+                // far searches (a run's first iterations) trim their rows by the tight boxes of the cells; large query sets are
+                // searched through the float32 filter (sicp_gridf.hip) when float32 can hold the cloud
+                const bool boxes = c->use_boxes && Q >= c->box_min_q && cnt > 0;
+                bool filt = many_q && c->nn16_filter != 0 && cnt > 0;
+                if (filt || boxes) CHK(grid_companions(c, cl, cl.grid, cl.n, filt, boxes));
+                if (filt && coarse) CHK(grid_companions(c, cl, cl.sub_grid, cl.sub_n, true, false));
+                if (filt && (!cl.grid.filter_ok || (coarse && !cl.sub_grid.filter_ok))) filt = false;
+                const unsigned long long *cbox = boxes ? cl.grid.cell_box.p : nullptr;
+                if (filt) {
+                    // queries and their last matches in slot order (once per setup: a new setup, a new cloud or another slice start afresh)
+                    if (!c->have_prev_match || c->slot_lo != lo || c->slot_cnt != cnt || c->slot_ordered != ordered) {
+                        CHK(c->q_slot.reserve((size_t)4 * cnt)); CHK(c->p_slot.reserve((size_t)4 * cnt));
+                        CHK(c->nn_state.reserve((size_t)cnt));
+                        if (c->nn_redo.cap < (size_t)cnt + 2) {
+                            CHK(c->nn_redo.reserve((size_t)cnt + 2));
+                            HIPCHK(hipMemsetAsync(c->nn_redo.p, 0, 2 * sizeof(uint32_t), c->stream));
+                        }
+                        launch_slot_queries(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo,
+                                            ordered ? c->q_order.p : nullptr, nullptr, cnt, c->q_slot.p, c->p_slot.p);
+                        HIPCHK(hipGetLastError());
+                        c->slot_lo = lo; c->slot_cnt = cnt; c->slot_ordered = ordered;
+                    }
+                    c->last_match_kernel = 6;
+                    const int lanes = eight ? 8 : 16;
+                    unsigned *tie_cnt = c->nn_redo.p + c->nn_parity, *tie_clear = c->nn_redo.p + (c->nn_parity ^ 1);
+                    uint32_t *tie_list = c->nn_redo.p + 2;
+                    unsigned long long *wk = c->count_work ? c->match_work.p : nullptr;
+                    const double inf = std::numeric_limits<double>::infinity();
+                    Timed t(c, SICP_K_KNN1);
+                    // cold: the subsample's nearest point (any point near the query: NN_APPROX) is left in the slot as the bound ...
+                    if (coarse)
+                        launch_grid_nn16f(c->stream, lanes, true, c->icp_dev.p, c->q_slot.p, c->p_slot.p, cnt, cl.sub_grid.g, cl.sub_grid.c0,
+                                          cl.sub_grid.eps_p, cl.sub_grid.cell_start.p, cl.sub_grid.recf.p, cl.sub_grid.rec.p, nullptr, ordered,
+                                          nullptr, nullptr, cl.rmax, inf, 0, nullptr, nullptr, nullptr, nullptr, NN_APPROX, nullptr,
+                                          tie_list, tie_cnt);
+                    // ... and the search proper goes straight to that radius (NN_TIGHT).  A cold search is a far search for every
+                    // query: the full flavour takes all slots.  Later the lean flavour goes first and marks what it cannot do.
+                    const bool all_far = coarse || c->nn16_filter == 1;
+                    if (!all_far)
+                        launch_grid_nn16f(c->stream, lanes, false, c->icp_dev.p, c->q_slot.p, c->p_slot.p, cnt, cl.grid.g, cl.grid.c0,
+                                          cl.grid.eps_p, cl.grid.cell_start.p, cl.grid.recf.p, cl.grid.rec.p, nullptr, ordered, nullptr, nullptr,
+                                          cl.rmax, inf, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo, c->m_p2.p + 3 * lo, wk, 0,
+                                          c->nn_state.p, tie_list, tie_cnt);
+                    launch_grid_nn16f(c->stream, lanes, true, c->icp_dev.p, c->q_slot.p, c->p_slot.p, cnt, cl.grid.g, cl.grid.c0,
+                                      cl.grid.eps_p, cl.grid.cell_start.p, cl.grid.recf.p, cl.grid.rec.p, cbox, ordered, nullptr, nullptr,
+                                      cl.rmax, inf, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo, c->m_p2.p + 3 * lo, wk,
+                                      coarse ? NN_TIGHT : 0, all_far ? nullptr : c->nn_state.p, tie_list, tie_cnt);
+                    // ties within the filter's margin (and queries float32 cannot place): the exact kernel, from the by-query
+                    // arrays (the previous match bounds them; in a cold iteration nothing does: they search outwards)
+                    launch_grid_nn_redo(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt,
+                                        (prev && !coarse) ? prev + 3 * lo : nullptr, cl.grid.g, cl.grid.cell_start.p, cl.grid.rec.p,
+                                        c->icp_dev.p, nullptr, nullptr, cl.rmax, inf, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo,
+                                        c->m_p2.p + 3 * lo, wk, 0, nullptr, cbox, tie_list, tie_cnt, tie_clear);
+                    c->nn_parity ^= 1;
+                } else {
+                Timed t(c, SICP_K_KNN1);
+                if (coarse)
+                    launch_grid_nn_chained(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt, nullptr,
+                                           cl.sub_grid.g, cl.sub_grid.cell_start.p, cl.sub_grid.rec.p, c->icp_dev.p, cl.rmax, 0,
+                                           c->bound_d2.p + lo, c->bound_idx.p + lo, c->bound_p2.p + 3 * lo, nullptr,
+                                           ordered ? c->q_order.p : nullptr, many_q, NN_APPROX);
+                // without an exchange the match is final when its kernel ends: the winning lanes leave the point-to-plane
+                // distance and the planarity verdict too (what k_postmatch would re-read 72 bytes per correspondence for)
+                // (only in the one-wave-per-query flavour: with four queries per wave at the register limit the epilogue's late
+                // loads cost the search more than k_postmatch's launch -- match 693 -> 758 us at 1 M queries, measured)
+                post_done = !c->collective() && c->match_epilogue && !many_q;
                 // behind a cloud-shard exchange the winning lanes leave the exchange's packed record instead (no k_pack_best launch)
                 // (query shards: the slim record, the matched index alone -- no k_pack_idx launch)
                 const bool pack = c->collective() && !qshard, pack_idx = c->collective() && qshard;
@@ -1742,7 +1886,9 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                                            coarse ? c->bound_p2.p + 3 * lo : (prev ? prev + 3 * lo : nullptr), cl.grid.g,
                                            cl.grid.cell_start.p, cl.grid.rec.p, c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p + lo,
                                            c->m_idx.p + lo, c->m_p2.p + 3 * lo, c->count_work ? c->match_work.p : nullptr,
-                                           ordered ? c->q_order.p : nullptr, cnt >= c->nn16_min_q, coarse, (post_done || pack || pack_idx) ? &pm : nullptr, eight);
+                                           ordered ? c->q_order.p : nullptr, many_q, coarse ? NN_TIGHT : 0,
+                                           (post_done || pack || pack_idx) ? &pm : nullptr, eight, cbox);
+                }
             } else if (qshard) {
                 return fail(SICP_ERR_INVALID, "query shards need the grid search (SICP_KNN1 forces another kernel)");
             } else {
@@ -2481,6 +2627,13 @@ SICP_EXPORT int sicp_match_work(sicp_ctx *c, uint64_t out3[3])
     if (!c || !out3) return fail(SICP_ERR_INVALID, "null argument");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(out3, c->match_work.p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    return sync(c);
+}
+SICP_EXPORT int sicp_match_deferred(sicp_ctx *c, uint64_t *out)
+{
+    if (!c || !out) return fail(SICP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(out, c->match_work.p + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     return sync(c);
 }
 SICP_EXPORT int sicp_knn_work(sicp_ctx *c, uint64_t out4[4])

@@ -27,6 +27,7 @@
 
 #include "sicp_internal.h"
 #include "sicp_lanes.h"
+#include "sicp_grid_dev.h"
 #include "sicp_normals.h"
 
 namespace sicp {
@@ -99,19 +100,6 @@ __global__ __launch_bounds__(256) void k_cloud_stats(const double *__restrict__ 
             atomicMax(out + 6, (unsigned long long)__double_as_longlong(v));
         }
     }
-}
-
-__device__ __forceinline__ int cell_coord(double v, double mn, double inv_h, int dim)
-{
-    int c = (int)floor((v - mn) * inv_h);
-    return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
-}
-__device__ __forceinline__ uint32_t cell_of(const GridGeom &G, double x, double y, double z)
-{
-    const int cx = cell_coord(x, G.mn[0], G.inv_h, G.dim[0]);
-    const int cy = cell_coord(y, G.mn[1], G.inv_h, G.dim[1]);
-    const int cz = cell_coord(z, G.mn[2], G.inv_h, G.dim[2]);
-    return ((uint32_t)cz * G.dim[1] + cy) * G.dim[0] + cx;
 }
 
 // cell id of every point + histogram; OCC: also count the cells that receive their first point (needs the
@@ -285,43 +273,6 @@ __global__ __launch_bounds__(256) void k_scatter_order(const uint32_t *__restric
 // ------------------------------------------------------------------------------------
 // one wave per query
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ void xf(const Xf &H, double x, double y, double z, double &ox, double &oy, double &oz)
-{
-    double t;
-    t = H.m[0] * x;  t = fma(H.m[1], y, t);  t = fma(H.m[2], z, t);   ox = t + H.m[3];
-    t = H.m[4] * x;  t = fma(H.m[5], y, t);  t = fma(H.m[6], z, t);   oy = t + H.m[7];
-    t = H.m[8] * x;  t = fma(H.m[9], y, t);  t = fma(H.m[10], z, t);  oz = t + H.m[11];
-}
-
-// row rr of a ny-wide block of grid rows -> (rr % ny, rr / ny) without the 64-bit integer division the plain expressions compile
-// to (~150 instructions per lane and pass: a tenth of the four-queries-per-wave search's issue budget).  Exact for rr < 2^22
-// (float quotient within one of the truth, then corrected); balls with more rows take the division.
-__device__ __forceinline__ void row_split(long rr, int ny, float inv_ny, bool small, int &oy, int &oz)
-{
-    if (small) {
-        unsigned q = (unsigned)(((float)(unsigned)rr + 0.5f) * inv_ny);
-        int r = (int)(unsigned)rr - (int)(q * (unsigned)ny);
-        if (r < 0) { q -= 1u; r += ny; } else if (r >= ny) { q += 1u; r -= ny; }
-        oy = r; oz = (int)q;
-    } else {
-        oy = (int)(rr % ny); oz = (int)(rr / ny);
-    }
-}
-
-// What k_postmatch computes (sicp_kernels.hip), by the lane that holds the winner: signed point-to-plane distance of the matched
-// point under H, contract (P), and the planarity verdict of both clouds -- the same expressions, so the same bits.
-__device__ __forceinline__ void post_match(const PostMatch &post, const Xf &H, long q, int64_t m, double px, double py, double pz,
-                                           double ax, double ay, double az, float nx, float ny, float nz, float pl)
-{
-    double X, Y, Z;
-    xf(H, px, py, pz, X, Y, Z);
-    const double a = (X - ax) * (double)nx, b = (Y - ay) * (double)ny, c = (Z - az) * (double)nz;
-    post.dist[q] = (a + b) + c;
-    bool f = m >= 0 && pl >= post.min_planarity;
-    if (f && post.pl2) f = m < post.pl2_n && post.pl2[m] >= post.min_planarity;          // corrpts.py:158-163 (NaN fails)
-    post.flag[q] = f ? 1 : 0;
-}
-
 // CHAINED: the launch belongs to a run whose iterations are enqueued back to back -- H and its inverse come from
 // the device-resident loop state the previous tail launch left (sicp_tail.hip), and the launch exits at once
 // when that tail declared the run over.
@@ -343,21 +294,20 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     long Q, GridGeom G, Xf H, Xf Hinv, double rmax, double max_d2, int64_t idx_base,
     double *__restrict__ d2_out, int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
     unsigned long long *__restrict__ work /* nullable: [0] candidates, [1] rows, [2] launches */,
-    int tight /* prev_p2 is a bound to search in one go (the nearest point of a subsample), not an old match */,
+    int flags /* NN_TIGHT: prev_p2 is a bound to search in one go (the nearest point of a subsample), not an old match;
+                 NN_APPROX: the first hit is good enough (the caller wants A cloud point near the query -- a bound --, not the nearest) */,
     PostMatch post /* chained match of an ICP iteration: the winning lane also leaves the point-to-plane distance and the
-                      planarity verdict (corrpts.py:139-163,195-211) -- it holds the matched point, the query and H already */)
+                      planarity verdict (corrpts.py:139-163,195-211) -- it holds the matched point, the query and H already */,
+    const unsigned long long *__restrict__ cell_box /* nullable: the cells' tight boxes (sicp_grid_dev.h) -- far searches trim their rows */,
+    const uint32_t *__restrict__ redo_list /* nullable: ONLY the queries listed here (what the filtered many-queries kernel left) */,
+    const unsigned *__restrict__ redo_count /* entries of redo_list */,
+    unsigned *__restrict__ redo_clear /* nullable: the counter the NEXT search's kernels add to -- cleared here (nobody touches it
+                                         before that search is launched: stream order) */)
 {
     const int lane = threadIdx.x & 63;
-    long q = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (order) {
-        // workgroups are dealt round-robin to the 8 XCDs: give each XCD one contiguous eighth of the ordered queries, so that
-        // the rows a neighbourhood of queries shares are fetched into ONE L2
-        const long per_xcd = gridDim.x >> 3;
-        q = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        if (q >= Q) return;
-        q = order[q];
-    }
-    if (q >= Q) return;                                   // whole wave leaves together
+    const int tight = flags & NN_TIGHT;
+    const bool approx = (flags & NN_APPROX) != 0;
+  auto one = [&](const long q) {
     const double ax = qx[q], ay = qy[q], az = qz[q];      // (issued before the loop state is waited for)
     double px0 = 0, py0 = 0, pz0 = 0;
     if (prev_p2) { px0 = prev_p2[3 * q]; py0 = prev_p2[3 * q + 1]; pz0 = prev_p2[3 * q + 2]; }
@@ -442,39 +392,46 @@ __global__ __launch_bounds__(256) void k_grid_nn(
         double cull2 = __builtin_inf();                           // rows farther than this cannot hold the answer (set by hits)
         const float inv_ny = 1.0f / (float)ny;
         const bool few_rows = nrows < (1L << 22);
+        // row rr of the pass's block -> its cells [xl, xh] within the ball (the hit's, once there is one), its record range
+        auto row_range = [&](long rr, uint32_t &b, uint32_t &len, double &lb2, long &row, int &cy, int &cz, int &xl, int &xh) {
+            b = 0; len = 0;
+            int oy, oz;
+            row_split(rr, ny, inv_ny, few_rows, oy, oz);
+            cy = lo[1] + oy; cz = lo[2] + oz;
+            row = ((long)cz * G.dim[1] + cy) * G.dim[0];
+            xl = lo[0]; xh = hi[0];
+            lb2 = 0.0;
+            if (!all) {
+                const double yl = G.mn[1] + (double)cy * G.h, zl = G.mn[2] + (double)cz * G.h;
+                const double dy = fmax(fmax(yl - etol - cyq, cyq - (yl + G.h + etol)), 0.0);
+                const double dz = fmax(fmax(zl - etol - czq, czq - (zl + G.h + etol)), 0.0);
+                lb2 = fma(dy, dy, dz * dz);
+                const double rem = fmin(r2, cull2) - lb2;
+                if (rem >= 0.0) {
+                    // half-width along x, rounded up (float sqrt + margin; the cell tolerance covers the rest)
+                    const double hw = (rem < 1e-30 ? 1e-15 : (double)(sqrtf((float)rem) * 1.000001f)) + etol;
+                    const double fl = floor((cxq - hw - G.mn[0]) * G.inv_h - 1e-6);
+                    const double fh = floor((cxq + hw - G.mn[0]) * G.inv_h + 1e-6);
+                    const int tl = fl < 0.0 ? 0 : (fl > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fl);
+                    const int th = fh < 0.0 ? 0 : (fh > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fh);
+                    xl = tl > xl ? tl : xl; xh = th < xh ? th : xh;
+                } else {
+                    xh = xl - 1;                                  // outside the ball
+                }
+            }
+            if (xh >= xl && lb2 <= cull2) {
+                b = cell_start[row + xl];
+                len = cell_start[row + xh + 1] - b;
+            }
+        };
         for (long rb = 0; rb < nrows; rb += 64) {
             uint32_t b = 0, len = 0;
             double lb2 = __builtin_inf();
+            long row = 0; int cy = 0, cz = 0, xl = 0, xh = -1;
             if (rb + lane < nrows) {
-                const long rr = rb + lane;
-                int oy, oz;
-                row_split(rr, ny, inv_ny, few_rows, oy, oz);
-                const int cy = lo[1] + oy, cz = lo[2] + oz;
-                const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
-                int xl = lo[0], xh = hi[0];
-                lb2 = 0.0;
-                if (!all) {
-                    const double yl = G.mn[1] + (double)cy * G.h, zl = G.mn[2] + (double)cz * G.h;
-                    const double dy = fmax(fmax(yl - etol - cyq, cyq - (yl + G.h + etol)), 0.0);
-                    const double dz = fmax(fmax(zl - etol - czq, czq - (zl + G.h + etol)), 0.0);
-                    lb2 = fma(dy, dy, dz * dz);
-                    const double rem = r2 - lb2;
-                    if (rem >= 0.0) {
-                        // half-width along x, rounded up (float sqrt + margin; the cell tolerance covers the rest)
-                        const double hw = (rem < 1e-30 ? 1e-15 : (double)(sqrtf((float)rem) * 1.000001f)) + etol;
-                        const double fl = floor((cxq - hw - G.mn[0]) * G.inv_h - 1e-6);
-                        const double fh = floor((cxq + hw - G.mn[0]) * G.inv_h + 1e-6);
-                        const int tl = fl < 0.0 ? 0 : (fl > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fl);
-                        const int th = fh < 0.0 ? 0 : (fh > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fh);
-                        xl = tl > xl ? tl : xl; xh = th < xh ? th : xh;
-                    } else {
-                        xh = xl - 1;                                  // outside the ball
-                    }
-                }
-                if (xh >= xl && lb2 <= cull2) {
-                    b = cell_start[row + xl];
-                    len = cell_start[row + xh + 1] - b;
-                }
+                row_range(rb + lane, b, len, lb2, row, cy, cz, xl, xh);
+                // (a later batch of a far search: an earlier batch's hit already bounds the answer)
+                if (cell_box && cull2 < __builtin_inf() && len > 0) box_trim_row(cell_box, G, row, cy, cz, xl, xh, cxq, cyq, czq, cull2, etol, b, len);
             }
             unsigned long long todo = __ballot(len > 0);          // rows of this batch that hold points
             if (work && len > 0) n_rows += 1;                     // (per-lane tallies, summed once at the end)
@@ -497,8 +454,16 @@ __global__ __launch_bounds__(256) void k_grid_nn(
                   o = lane_xor_f64<2>(wb);  wb = o < wb ? o : wb;  o = lane_xor_f64<1>(wb);  wb = o < wb ? o : wb; }
                 if (wb < __builtin_inf()) {
                     const double rbnd = sqrt(wb) * (1.0 + 1e-12) + slack;
-                    cull2 = rbnd * rbnd;
-                    todo &= __ballot(lb2 <= cull2);
+                    const double c2 = rbnd * rbnd;
+                    if (c2 < cull2) {
+                        cull2 = c2;
+                        // the rows still to do: their cells within the HIT's ball, trimmed by the cells' tight boxes
+                        if (cell_box && ((todo >> lane) & 1ull)) {
+                            row_range(rb + lane, b, len, lb2, row, cy, cz, xl, xh);
+                            if (len > 0) box_trim_row(cell_box, G, row, cy, cz, xl, xh, cxq, cyq, czq, cull2, etol, b, len);
+                        }
+                    }
+                    todo &= __ballot(len > 0 && lb2 <= cull2);
                 }
             }
             while (todo) {
@@ -536,7 +501,8 @@ __global__ __launch_bounds__(256) void k_grid_nn(
         const double r_eff2 = r_eff > 0.0 ? r_eff * r_eff * (1.0 - 1e-15) : -1.0;
         const bool done = (found && best <= r_eff2)           // nothing outside the ball can beat or tie it
                           || all || r >= r_lim                // searched everything that may qualify
-                          || last;                            // this ball was sized to hold the previous pass's hit: it holds the answer
+                          || last                             // this ball was sized to hold the previous pass's hit: it holds the answer
+                          || (approx && found);               // any cloud point will do
         if (done) {
             const bool ok = found && (best < max_d2);
             if (winner || (!found && lane == 0)) {
@@ -566,8 +532,27 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     if (work) {
         n_cand = wsum_u64(n_cand); n_rows = wsum_u64(n_rows);
         if (lane == 0) { atomicAdd(work, n_cand); atomicAdd(work + 1, n_rows); }
-        if (q == 0 && lane == 0) atomicAdd(work + 2, 1ull);
+        if (q == 0 && lane == 0 && !redo_list) atomicAdd(work + 2, 1ull);
     }
+  };
+    if (redo_list) {
+        // the waves share the list: wave w takes entries w, w + W, ...  (the launch cannot know how long the list is)
+        const long cnt = (long)redo_count[0], nw = (long)gridDim.x * (blockDim.x >> 6);
+        for (long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < cnt; i += nw) one((long)redo_list[i]);
+        if (redo_clear && blockIdx.x == 0 && threadIdx.x == 0) *redo_clear = 0u;
+        return;
+    }
+    long q = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (order) {
+        // workgroups are dealt round-robin to the 8 XCDs: give each XCD one contiguous eighth of the ordered queries, so that
+        // the rows a neighbourhood of queries shares are fetched into ONE L2
+        const long per_xcd = gridDim.x >> 3;
+        q = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (q >= Q) return;
+        q = order[q];
+    }
+    if (q >= Q) return;                                   // whole wave leaves together
+    one(q);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1519,7 +1504,13 @@ __device__ __forceinline__ int h3_region(int b)      // 0..3: a coarse region, -
     if (b <= H3_ZR_HI) return -1;
     return 3;
 }
-constexpr int HS_MAXB = 2 * HS_PASSES + 3 + 2;
+// Barriers ONE launch may go through, counted on its longest road: a window that is tried, passes its analysis, collects, and then
+// misses on the keys (3: histogram, lists, the meeting before the wipe) + the general form after it (per statistic HS_PASSES digit
+// passes and one collecting sweep) + the keep / statistics sweep.  The host advances the barrier counter by exactly this much per
+// launch (barrier numbers are absolute): a launch that could take one more would leave the next launch's first barrier open.
+constexpr int HS_WINDOW_BARRIERS = 3, HS_STAT_BARRIERS = HS_PASSES + 1, HS_FINAL_BARRIERS = 1;
+constexpr int HS_MAXB = HS_WINDOW_BARRIERS + 2 * HS_STAT_BARRIERS + HS_FINAL_BARRIERS;
+static_assert(HS_MAXB == 18, "k_hsel_all's worst case: 3 (window tried and missed late) + 2 x (6 passes + 1) + 1");
 struct HselAll {
     GridBar bar;                   // (sicp_lanes.h) all zero when the buffer is new
     unsigned long long nxt[2];     // per statistic: smallest key above the prefix interval (~0 between launches; see hsel_state_init)
@@ -2049,6 +2040,7 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     SICP_TQ();
     grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb), absent);
+    if (nb > HS_MAXB && tid == 0) __hip_atomic_store(&S->bar.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (budget exceeded: never, by the count above HselAll)
     SICP_TQ();
 #ifdef SICP_HSEL_DEBUG
     if (blockIdx.x == 0 && tid == 0 && have)
@@ -2206,10 +2198,12 @@ void launch_scatter(hipStream_t s, const double *x, const double *y, const doubl
 void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                     const GridGeom &G, const uint32_t *cell_start, const void *rec, const Xf *H, const Xf *Hinv, double rmax,
                     double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
-                    bool four_per_wave)
+                    bool four_per_wave, const unsigned long long *cell_box)
 {
     const dim3 grid(cdiv(Q, 4)), block(256);
     Xf id = {};
+    const uint32_t *no_list = nullptr;
+    unsigned *no_count = nullptr;
     if (four_per_wave) {
         const dim3 g16(cdiv(Q, 16));
         if (H)
@@ -2220,17 +2214,18 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
     }
     if (H)
         hipLaunchKernelGGL((k_grid_nn<true, false>), grid, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, *H,
-                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{});
+                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{}, cell_box, no_list, no_count, no_count);
     else
         hipLaunchKernelGGL((k_grid_nn<false, false>), grid, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, id,
-                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{});
+                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{}, cell_box, no_list, no_count, no_count);
 }
 
 // the match of a chained iteration: transform taken from the loop state on the device
 void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                             const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
                             int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
-                            const uint32_t *order, bool four_per_wave, bool tight, const PostMatch *post, bool eight_per_wave)
+                            const uint32_t *order, bool four_per_wave, int flags, const PostMatch *post, bool eight_per_wave,
+                            const unsigned long long *cell_box)
 {
     Xf id = {};
     PostMatch pm = {};
@@ -2241,15 +2236,39 @@ void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, c
         if (eight_per_wave) {
             unsigned g8 = cdiv(Q, 32);
             if (order) g8 = (g8 + 7u) & ~7u;
-            hipLaunchKernelGGL((k_grid_nn16<true, true, 8>), dim3(g8), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, tight ? 1 : 0, pm);
+            hipLaunchKernelGGL((k_grid_nn16<true, true, 8>), dim3(g8), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, flags & NN_TIGHT, pm);
             return;
         }
-        hipLaunchKernelGGL((k_grid_nn16<true, true, 16>), dim3(g16), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, tight ? 1 : 0, pm);
+        hipLaunchKernelGGL((k_grid_nn16<true, true, 16>), dim3(g16), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, flags & NN_TIGHT, pm);
         return;
     }
     unsigned g = cdiv(Q, 4);
     if (order) g = (g + 7u) & ~7u;
-    hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, tight ? 1 : 0, pm);
+    hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, flags, pm,
+                       cell_box, (const uint32_t *)nullptr, (const unsigned *)nullptr, (unsigned *)nullptr);
+}
+
+// The exact one-wave-per-query search over a LIST of queries: what the filtered many-queries kernel (sicp_gridf.hip) would not
+// answer itself.  The launch cannot know how long the list is -- a few hundred waves share it; an empty list costs a launch that
+// exits at once.  st: the chain's loop state (then H, Hinv are ignored), else H (nullable: no transform).
+void launch_grid_nn_redo(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
+                         const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, const Xf *H, const Xf *Hinv,
+                         double rmax, double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out,
+                         unsigned long long *work, int flags, const PostMatch *post, const unsigned long long *cell_box,
+                         const uint32_t *redo_list, const unsigned *redo_count, unsigned *redo_clear)
+{
+    Xf id = {};
+    PostMatch pm = {};
+    if (post) pm = *post;
+    long want = Q / 256;                                   // ~1.5 % of the queries at one per wave before the waves loop
+    const unsigned g = (unsigned)(want < 8 ? 8 : (want > 1024 ? 1024 : want));
+    const uint32_t *no_order = nullptr;
+    if (st)
+        hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, redo_list, redo_count, redo_clear);
+    else if (H)
+        hipLaunchKernelGGL((k_grid_nn<true, false>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, *H, *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, redo_list, redo_count, redo_clear);
+    else
+        hipLaunchKernelGGL((k_grid_nn<false, false>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, redo_list, redo_count, redo_clear);
 }
 
 void launch_stride_sample(hipStream_t s, const double *x, const double *y, const double *z, long n, long stride, long m, long mpad,

@@ -114,15 +114,35 @@ void launch_grid_scan(hipStream_t s, const uint32_t *in, long n, uint32_t *block
 void launch_scatter(hipStream_t s, const double *x, const double *y, const double *z, const uint32_t *ids, long n,
                     uint32_t *cursor, void *rec);
 // rec: the cloud in cell order as packed 32-byte records (x, y, z, original row as int64 bits)
+// cell_box (nullable): the cells' tight boxes (sicp_grid_dev.h): far searches trim their rows by them
+constexpr int NN_TIGHT = 1;      // prev_p2 is a bound to search in one go (the nearest point of a subsample), not an old match
+constexpr int NN_APPROX = 2;     // the first hit is good enough: the caller wants a cloud point NEAR the query (a bound), not the nearest
 void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                     const GridGeom &G, const uint32_t *cell_start, const void *rec, const Xf *H, const Xf *Hinv, double rmax,
                     double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
-                    bool four_per_wave);
+                    bool four_per_wave, const unsigned long long *cell_box = nullptr);
 void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                             const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
                             int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
-                            const uint32_t *order, bool four_per_wave, bool tight = false, const PostMatch *post = nullptr,
-                            bool eight_per_wave = false);
+                            const uint32_t *order, bool four_per_wave, int flags = 0, const PostMatch *post = nullptr,
+                            bool eight_per_wave = false, const unsigned long long *cell_box = nullptr);
+void launch_grid_nn_redo(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
+                         const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, const Xf *H, const Xf *Hinv,
+                         double rmax, double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out,
+                         unsigned long long *work, int flags, const PostMatch *post, const unsigned long long *cell_box,
+                         const uint32_t *redo_list, const unsigned *redo_count, unsigned *redo_clear);
+// sicp_gridf.hip: the grid's lazily built companions and the filtered many-queries search
+void launch_recf(hipStream_t s, const void *rec, long n, const double c0[3], void *recf);
+void launch_cell_boxes(hipStream_t s, const uint32_t *cell_start, const void *rec, long ncells, const GridGeom &G, unsigned long long *cell_box);
+void launch_slot_queries(hipStream_t s, const double *qx, const double *qy, const double *qz, const uint32_t *order, const double *prev_p2,
+                         long Q, void *qrec, void *pslot);
+// far: the flavour with row batches, hit-driven culling and box trimming (a run's first iterations); otherwise the lean flavour,
+// which marks the queries it cannot do in `state` (1) for a launch of the other flavour over the same slots
+void launch_grid_nn16f(hipStream_t s, int lanes_per_query, bool far, const IcpDev *st, const void *qrec, void *pslot, long Q,
+                       const GridGeom &G, const double c0[3], double eps_p, const uint32_t *cell_start,
+                       const void *recf, const void *rec, const unsigned long long *cell_box, bool xcd_order, const Xf *H,
+                       const Xf *Hinv, double rmax, double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out,
+                       unsigned long long *work, int flags, uint8_t *state, uint32_t *redo_list, unsigned *redo_count);
 void launch_stride_sample(hipStream_t s, const double *x, const double *y, const double *z, long n, long stride, long m, long mpad,
                           double *out);
 void launch_scatter_order(hipStream_t s, const uint32_t *ids, long n, uint32_t *cursor, uint32_t *order);

@@ -265,17 +265,19 @@ def test_too_few_correspondences(ctx):
 
 
 # ---- filtered scan (FP32 conservative filter + exact FP64 verification) == plain brute force ----
-@pytest.fixture(scope="module", params=["filter", "grid", "grid16"])
+@pytest.fixture(scope="module", params=["filter", "grid", "grid16", "grid16far", "grid16exact"])
 def ctx_filter(request):
-    """Contexts that FORCE the filtered brute-force scan / the grid search (one query per wave, or four: the flavour large
-    query sets get) even for small clouds."""
+    """Contexts that FORCE the filtered brute-force scan / the grid search (one query per wave with the cells' tight boxes, or the
+    flavours large query sets get: the float32 filter -- lean kernel first, full kernel for what it leaves, exact kernel for the ties;
+    the full kernel alone; the exact four-per-wave kernel) even for small clouds."""
     import os
     from simpleicp_amd import _lib
-    env = {"SICP_KNN1": "grid" if request.param == "grid16" else request.param}
-    if request.param == "grid16":
+    env = {"SICP_KNN1": "grid" if request.param.startswith("grid") else request.param, "SICP_BOXES": "2"}
+    if request.param.startswith("grid16"):
         env["SICP_NN16_MIN_Q"] = "1"
         env["SICP_ORDER_MIN_Q"] = "1"        # ... and the iteration's queries in cell order, one eighth per XCD
         env["SICP_COARSE_MIN_N"] = "1"       # ... and a cold iteration bounded by the subsample's nearest point whatever the cloud size
+        env["SICP_NN16"] = {"grid16": "near", "grid16far": "far", "grid16exact": "exact"}[request.param]
     os.environ.update(env)
     try:
         c = _lib.Context(0)
@@ -849,6 +851,51 @@ def test_windowed_rejection_equals_the_general_form(Q, kind):
         o = orc.icp_iteration(Xm, P[sel], nv, pl, x, x, 1.0, z, z, 0.3)
         assert (a[3][it][1], a[3][it][2], a[3][it][3]) == (o["median"], o["mad"], int(o["keep"].sum()))
         x = np.array(a[3][it][4])
+
+
+def test_rejection_longest_barrier_road_over_chained_launches():
+    """The one-launch rejection's LONGEST road, several launches in a row (barrier numbers are absolute: a launch that goes
+    through more barriers than the host books for it leaves the next launch's first barrier open).  Distances are exact values:
+    1 500 equal keys at the median (the window's analysis accepts the bin, but one block alone finds more of them than its list
+    holds: the window misses after its SECOND sweep, three barriers), and 1 400 equal keys at the MAD's rank -- so the general
+    form that follows walks all six digit passes for both statistics (more than 256 equal keys never fit the candidate list):
+    3 + 2 x 7 + 1 = 18 barriers per launch from the third launch of a run on.  All parameters fixed (infinite weights): every
+    iteration sees the same distances, so every launch must return the oracle's numbers."""
+    from simpleicp_amd import _lib
+    Q = 40_000
+    rng = np.random.default_rng(4242)
+    g = np.arange(300) * 5.0                                       # lattice spacing 5: a point's nearest neighbour is its own copy
+    P = np.column_stack([a.ravel() for a in np.meshgrid(g, g)] + [np.zeros(90_000)])
+    sel = np.sort(rng.choice(len(P), Q, replace=False))
+    c, D = 0.5, 0.1875
+    off = np.empty(Q)
+    n_bulk = Q - 1500 - 1400
+    off[:1500] = c
+    off[1500:2200] = c - D
+    off[2200:2900] = c + D
+    off[2900:2900 + n_bulk // 2] = c - rng.uniform(1e-3, 0.4, n_bulk // 2)
+    off[2900 + n_bulk // 2:] = c + rng.uniform(1e-3, 0.4, n_bulk - n_bulk // 2)
+    rng.shuffle(off)
+    zoff = np.full(len(P), 0.25); zoff[sel] = off
+    Xm = P + np.column_stack((np.full(len(P), 0.003), np.full(len(P), 0.002), zoff))
+    nv = np.tile(np.array([[0, 0, 1]], dtype=np.float32), (Q, 1))
+    pl = np.ones(Q, dtype=np.float32)
+    z6, fixed = np.zeros(6), np.full(6, np.inf)
+    o = orc.icp_iteration(Xm, P[sel], nv, pl, z6, z6, 1.0, z6, fixed, 0.3)
+    assert o["median"] == c and o["mad"] == D and np.array_equal(o["dist"], off)        # the construction is what it claims
+    with _lib.Context(0) as ctx:
+        ctx.upload(_lib.FIX, P); ctx.upload(_lib.MOV, Xm)
+        ctx.icp_setup(sel, nv, pl)
+        whole = ctx.icp_run(z6, z6, fixed, 0.3, 1.0, max_iterations=8, min_change=0.0)
+        assert len(whole) == 8
+        for R in whole:
+            assert (R.median, R.mad, R.n_kept) == (o["median"], o["mad"], o["n"])
+        idx, dist, keep, _ = ctx.icp_state()
+        assert np.array_equal(idx, o["nn"]) and np.array_equal(dist, o["dist"]) and np.array_equal(keep, o["keep"])
+        # ... and host-driven launches on the same state buffer right behind them
+        for it in range(3):
+            R = ctx.icp_iterate(z6, z6, fixed, 0.3, 1.0)
+            assert (R.median, R.mad, R.n_kept) == (o["median"], o["mad"], o["n"])
 
 
 @pytest.mark.parametrize("seed", range(12))
