@@ -111,6 +111,19 @@ def load_workload(name, points=None, correspondences=None):
     return Xf, Xm, H_true, Q, cfg["k"], cfg["kwargs"], desc
 
 
+GRID_KERNELS = ("k_grid_nn", "k_grid_nn16", "k_grid_nn16f")
+
+
+def match_bytes(kernel, per, nq):
+    """Bytes the pruned search itself needs per launch, from its own tallies.  Exact kernels: a 32-B record per
+    candidate, two 4-B offsets per non-empty grid row, per query its coordinates, the previous match and the 48-B result.  Filtered
+    kernel (k_grid_nn16f): a 16-B float record per candidate, the same offsets, per query its 32-B slot record, the 32-B bound it reads
+    and the 32-B bound it leaves, the winner's 32-B record and the 40-B result."""
+    if kernel == "k_grid_nn16f":
+        return per["candidates"] * 16 + per["rows"] * 8 + nq * (32 + 32 + 32 + 32 + 40)
+    return per["candidates"] * 32 + per["rows"] * 8 + nq * (24 + 24 + 48)
+
+
 def csrc_hash():
     """sha256 over the kernel sources (name + bytes, sorted): what a committed PMC summary is valid for."""
     import hashlib
@@ -308,7 +321,7 @@ def run(args):
     match_kernel = ctx.last_match_kernel()
     # ... and one more with the grid search tallying the candidates / rows it touches (the bytes its roofline is priced on)
     work = None
-    if match_kernel in ("k_grid_nn", "k_grid_nn16") and not args.no_work_pass:
+    if match_kernel in GRID_KERNELS and not args.no_work_pass:
         ctx.timing_enable(True, count_work=True)
         ctx.timing_reset()
         cold()
@@ -363,13 +376,13 @@ def run(args):
             d.update(extra)
         return d
 
-    if match_kernel in ("k_grid_nn", "k_grid_nn16"):
+    if match_kernel in GRID_KERNELS:
         # the pruned search's OWN bytes: every candidate it evaluates is one packed 32-B record (x, y, z, index),
         # every non-empty grid row two 4-B offsets, every query its coordinates, the previous match (bound) and the
         # 48-B result -- tallied by the kernel itself in a separate pass
         if work and work["launches"]:
             per = {kk: v / max(1, work["launches"]) for kk, v in work.items() if kk != "launches"}
-            bytes_match = per["candidates"] * 32 + per["rows"] * 8 + nq * (24 + 24 + 48)
+            bytes_match = match_bytes(match_kernel, per, nq)
             extra = {"candidates_per_query": per["candidates"] / nq, "grid_rows_per_query": per["rows"] / nq}
         else:
             bytes_match = pmc.get(match_kernel) or bytes_bruteforce
@@ -617,7 +630,7 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
     avg = {name: v["ms"] / max(1, v["launches"]) for name, v in timing.items()}
     nq_local = (nq + world - 1) // world if exchange else nq
     per = {kk: v / max(1, work["launches"]) for kk, v in work.items() if kk != "launches"}
-    bytes_match = per["candidates"] * 32 + per["rows"] * 8 + nq_local * (24 + 24 + 48)
+    bytes_match = match_bytes(kern, per, nq_local)
     pmc, pmc_src = load_pmc()
     tag = f"@Q{Qt}"
     if args.config != "C4" or args.points:
@@ -643,10 +656,12 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
                             "timed_region": "K steps from the cold state (icp_setup just called), min_change=0, events off"},
            "parallelism": f"query shards x{world}, movable cloud replicated" if exchange else "1 GPU",
            "roofline": roof(kern, avg["match"], bytes_match,
-                            "exact 1-NN on the static grid, four or eight cell-ordered queries per wave; bytes = the candidates (32-B records) and "
-                            "grid rows the search itself TALLIED + 96 B per query (they include what neighbouring queries share in L2: "
+                            "exact 1-NN on the static grid, four or eight cell-ordered queries per wave, candidates through a float32 filter in the "
+                            "cloud's frame (16-B records), the winner re-evaluated exactly, ties left to the exact kernel; bytes = the candidates and "
+                            "grid rows the search itself TALLIED + 168 B per query (they include what neighbouring queries share in L2: "
                             "`frac_on_pmc_traffic` prices the same time on the HBM counters' bytes); issue- and latency-bound", {"candidates_per_query": per["candidates"] / max(1, nq_local),
                                            "grid_rows_per_query": per["rows"] / max(1, nq_local),
+                                           "left_to_exact_kernel_per_launch": per.get("deferred"),
                                            "pruning_ratio": (Nm * 24 + nq_local * 40) / max(1.0, bytes_match)}),
            "roofline_solver": roof("k_lm_eval" if exchange else "k_lm_all", avg["solve"], int(last.n_kept) * 72 * evals,
                                    "the iteration's whole minimisation (one launch: evaluations as phases between grid barriers, then the "

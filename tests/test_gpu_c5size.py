@@ -66,7 +66,7 @@ def test_two_iterations_at_c5_size(c5, c5_normals):
     x = z.copy()
     for it in range(2):
         R = c.icp_iterate(x, z, z, 0.3, 1.0)
-        assert c.last_match_kernel() == "k_grid_nn16"
+        assert c.last_match_kernel() == "k_grid_nn16f"
         check_large_q_iteration(c, Xf, Xm, sel, nv, pl, x, R, SAMPLE)
         x = np.array(R.x[:])
 

@@ -279,7 +279,7 @@ def test_large_q_iterations_equal_oracle_at_full_size(data, big_q):
     x = z.copy()
     for it in range(3):
         R = c.icp_iterate(x, z, z, 0.3, 1.0)
-        assert c.last_match_kernel() == "k_grid_nn16"
+        assert c.last_match_kernel() == "k_grid_nn16f"
         check_large_q_iteration(c, Xf, Xm, sel, nv, pl, x, R, 3000)
         x = np.array(R.x[:])
     # the chained loop lands on the same estimates

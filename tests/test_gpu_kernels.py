@@ -612,10 +612,12 @@ def test_one_launch_forms_equal_launch_per_phase_forms(Q, quantised):
 
 
 @pytest.mark.parametrize("quantised", [False, True])
-def test_eight_queries_per_wave_equals_four(quantised):
-    """The many-queries search with 8 lanes per query (chosen for very large query sets on finely binned clouds) against the
-    16-lane form and the oracle: same indices, same distances, bit for bit, over chained iterations (cold, loosely and
-    tightly bounded searches), on a cloud with exact ties."""
+def test_many_queries_search_flavours_agree(quantised):
+    """The many-queries search in every flavour -- through the float32 filter (lean kernel + full kernel + exact kernel for the
+    ties; the full kernel alone), 16 or 8 lanes per query, with and without the cells' tight boxes, and the exact four-per-wave
+    kernel it replaced -- against each other and the oracle: same indices, same distances, bit for bit, over chained iterations
+    (cold, loosely and tightly bounded searches), on a cloud with exact ties (quantised: every query ties -- the exact kernel
+    answers them all)."""
     import os
     from simpleicp_amd import _lib
     rng = np.random.default_rng(99)
@@ -628,12 +630,15 @@ def test_eight_queries_per_wave_equals_four(quantised):
     sel = np.sort(rng.choice(n, Q, replace=False))
     z = np.zeros(6)
     out = {}
-    for gs in ("16", "8"):
-        os.environ["SICP_NN_GROUP"] = gs
+    flavours = [("near", "16", "1"), ("near", "8", "1"), ("far", "16", "1"), ("far", "8", "0"), ("near", "16", "0"), ("exact", "16", "1"), ("exact", "8", "1")]
+    for mode, gs, boxes in flavours:
+        env = {"SICP_NN_GROUP": gs, "SICP_NN16": mode, "SICP_BOXES": boxes}
+        os.environ.update(env)
         try:
             c = _lib.Context(0)
         finally:
-            os.environ.pop("SICP_NN_GROUP", None)
+            for k in env:
+                os.environ.pop(k, None)
         with c:
             c.upload(_lib.FIX, P); c.upload(_lib.MOV, Xm)
             nv, pl = c.estimate_normals(_lib.FIX, sel, 10)
@@ -641,14 +646,22 @@ def test_eight_queries_per_wave_equals_four(quantised):
             x, rec = z.copy(), []
             for it in range(4):
                 R = c.icp_iterate(x, z, z, 0.3, 1.0)
-                assert c.last_match_kernel() == "k_grid_nn16"
+                assert c.last_match_kernel() == ("k_grid_nn16" if mode == "exact" else "k_grid_nn16f")
                 idx, dist, keep, _ = c.icp_state(residual=False)
                 rec.append((x.copy(), idx, dist, keep, np.array(R.x[:])))
                 x = np.array(R.x[:])
-        out[gs] = rec
-    for a, b in zip(out["16"], out["8"]):
-        assert all(np.array_equal(u, v) for u, v in zip(a, b))
-    for x, idx, dist, keep, xn in out["8"][:2]:
+            # ... and the chained loop (iterations enqueued back to back: the slots' bounds travel from launch to launch)
+            c.icp_setup(sel, nv, pl)
+            whole = c.icp_run(z, z, z, 0.3, 1.0, max_iterations=6, min_change=0.0)
+            idx, dist, keep, _ = c.icp_state(residual=False)
+            rec.append((tuple(tuple(w.x[:]) for w in whole), idx, dist, keep))
+        out[(mode, gs, boxes)] = rec
+    ref = out[("exact", "16", "1")]
+    for key, rec in out.items():
+        for a, b in zip(ref[:4], rec[:4]):
+            assert all(np.array_equal(u, v) for u, v in zip(a, b)), key
+        assert ref[4][0] == rec[4][0] and all(np.array_equal(u, v) for u, v in zip(ref[4][1:], rec[4][1:])), key
+    for x, idx, dist, keep, xn in ref[:2]:
         nn, _ = orc.knn(Xm, P[sel], k=1, H=orc.params_to_H(x))
         assert np.array_equal(idx, nn[:, 0])
 
