@@ -2,7 +2,7 @@
 """bench.py -- ICP iterations/s (+ kNN correspondences/s) on the BASELINE.json workloads.
 
     python bench.py                          # C4, 1 GPU, 20 steps, 3 warm-up steps
-    python bench.py --config C3              # C1 | C2 | C3 | C4 | C5size
+    python bench.py --config C3              # C1 | C2 | C3 | C4 | C5size | T
     python bench.py --gpus 2                 # spawns the ranks itself when not started by torchrun
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -14,6 +14,7 @@ Workloads (BASELINE.json `configs`):
   C4      synthetic 10 M-vs-10 M surface (two independent samplings + known rigid perturbation), Q = 1000
           -- the configuration the metric is quoted on, and the default
   C5size  100 M-vs-100 M, Q = 1 M on ONE GPU (the 8-GPU config's sizes; ~12 GB of the 288 GB)
+  T       1.25 M-vs-1.25 M terrestrial-scan-like stand-in (density ~ 1/r^2: the reference's Terrestrial Lidar pair is missing upstream), Q = 10 000
 
 A "step" is ONE full ICP iteration through the C ABI (exact 1-NN match of the Q selected fixed points in
 the movable cloud under the current H, point-to-plane distances, planarity + raw-MAD rejection, Levenberg-
@@ -65,6 +66,7 @@ CONFIGS = {
     "C3": dict(kind="synthetic", n=1_340_000, Q=10_000, k=10, kwargs={}),
     "C4": dict(kind="synthetic", n=10_000_000, Q=1000, k=10, kwargs={}),
     "C5size": dict(kind="synthetic", n=100_000_000, Q=1_000_000, k=10, kwargs={}),
+    "T": dict(kind="terrestrial", n=1_250_000, Q=10_000, k=10, kwargs={}),
 }
 
 
@@ -93,6 +95,54 @@ def synthetic_pair(n, seed_fix=0, seed_mov=1):
     return np.ascontiguousarray(Xf), np.ascontiguousarray(Xm), H_true
 
 
+def terrestrial_pair(n, seed_fix=10, seed_mov=11):
+    """A terrestrial-laser-scan-like pair: a STAND-IN for the reference's Terrestrial Lidar set (README.md:174, 1250 k points each;
+    tests/test_simpleicp.py:54-63), whose files are missing upstream (.MISSING_LARGE_BLOBS).  One scene -- ground plane, the four
+    walls of a yard, a few block-shaped buildings -- scanned from two nearby stand points with uniform ANGULAR sampling, so the point
+    density on a surface falls like 1 / r^2 (x the incidence angle) between 2 m and 80 m: a few thousand points per m^2 at the scanner's
+    feet, a handful at the far walls.  Each cloud is given in its own scanner frame; H_true maps the movable frame to the fixed one."""
+    boxes = np.array([  # xmin, xmax, ymin, ymax, zmax (from the ground up)
+        [-60.0, 60.0, 44.0, 45.0, 14.0], [-60.0, 60.0, -45.0, -44.0, 14.0], [59.0, 60.0, -45.0, 45.0, 14.0], [-60.0, -59.0, -45.0, 45.0, 14.0],
+        [12.0, 24.0, 8.0, 20.0, 9.0], [-30.0, -18.0, -22.0, -6.0, 6.0], [-14.0, -8.0, 14.0, 30.0, 11.0], [30.0, 36.0, -30.0, -12.0, 4.0],
+        [3.0, 4.2, -6.0, -4.8, 2.4],
+    ])
+
+    def scan(origin, yaw, seed, want):
+        rng = np.random.default_rng(seed)
+        out = []
+        have = 0
+        while have < want:
+            m = int((want - have) * 1.6) + 1024
+            az = rng.uniform(0, 2 * np.pi, m)
+            el = rng.uniform(np.deg2rad(-55.0), np.deg2rad(35.0), m)
+            d = np.column_stack((np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)))
+            t = np.full(m, np.inf)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                tg = np.where(d[:, 2] < 0, -origin[2] / d[:, 2], np.inf)                      # the ground, z = 0
+                t = np.minimum(t, tg)
+                for b in boxes:                                                                   # slab test per block
+                    lo = np.array([b[0], b[2], 0.0]); hi = np.array([b[1], b[3], b[4]])
+                    t0 = (lo - origin) / d; t1 = (hi - origin) / d
+                    tn = np.nanmax(np.minimum(t0, t1), axis=1); tf = np.nanmin(np.maximum(t0, t1), axis=1)
+                    hit = (tn <= tf) & (tn > 0)
+                    t = np.where(hit, np.minimum(t, tn), t)
+            ok = (t >= 2.0) & (t <= 80.0)
+            P = origin + d[ok] * (t[ok] + rng.normal(0, 0.004, ok.sum()))[:, None]             # range noise, 4 mm
+            out.append(P); have += len(P)
+        P = np.concatenate(out)[:want]
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        R = np.array([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
+        return (P - origin) @ R, R                                                               # scanner frame: R^T (P - origin)
+
+    of, om = np.array([0.0, 0.0, 1.8]), np.array([0.45, -0.30, 1.85])
+    Xf, _ = scan(of, 0.0, seed_fix, n)
+    Xm, Rm = scan(om, np.deg2rad(1.0), seed_mov, n)
+    H_true = np.eye(4)
+    H_true[:3, :3] = Rm
+    H_true[:3, 3] = om - of
+    return np.ascontiguousarray(Xf), np.ascontiguousarray(Xm), H_true
+
+
 def load_workload(name, points=None, correspondences=None):
     """(Xf, Xm, H_true or None, Q, k, kwargs, description)"""
     cfg = dict(CONFIGS[name])
@@ -104,6 +154,11 @@ def load_workload(name, points=None, correspondences=None):
         desc = f"{name} {cfg['fix']} vs {cfg['mov']} (bundled data, {len(Xf)} / {len(Xm)} points)"
         return Xf, Xm, None, Q, cfg["k"], cfg["kwargs"], desc
     n = points or cfg["n"]
+    if cfg["kind"] == "terrestrial":
+        Xf, Xm, H_true = terrestrial_pair(n)
+        desc = (f"{name} terrestrial-scan-like {n}-vs-{n}: ground + walls + blocks, uniform angular sampling from two stand points "
+                "(density ~ 1/r^2 over 2-80 m) -- a STAND-IN for the reference's Terrestrial Lidar pair (missing upstream)")
+        return Xf, Xm, H_true, Q, cfg["k"], cfg["kwargs"], desc
     Xf, Xm, H_true = synthetic_pair(n)
     desc = f"{name} synthetic {n}-vs-{n} surface (SURVEY 8d generator)"
     if name == "C3":

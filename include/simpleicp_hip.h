@@ -38,7 +38,7 @@ extern "C" {
 
 /* 1: round 1.  2: + sicp_corr_*, sicp_estimate_parameters, sicp_comm_*, sicp_set_partition, sicp_cloud_set_planarity,
  * sicp_cloud_download_columns, sicp_match_work; sicp_timing_enable(ctx, 2); every upload resets the slot's planarity
- * column.  3: + sicp_comm_activate, sicp_comm_info, sicp_device_memory; SICP_K_XCHG; sicp_comm_init bounded + handshake.  4: + sicp_knn_work, sicp_cloud_download_both; sicp_estimate_normals runs the one-sweep k-NN + covariance kernel.  5: + sicp_match_deferred; kind 6 of sicp_last_match_kernel.  A binding checks sicp_abi_version() against the header it was written for. */
+ * column.  3: + sicp_comm_activate, sicp_comm_info, sicp_device_memory; SICP_K_XCHG; sicp_comm_init bounded + handshake.  4: + sicp_knn_work, sicp_cloud_download_both; sicp_estimate_normals runs the one-sweep k-NN + covariance kernel.  5: + sicp_match_deferred, sicp_tail_cycles; kind 6 of sicp_last_match_kernel.  A binding checks sicp_abi_version() against the header it was written for. */
 #define SICP_ABI_VERSION 5
 
 #define SICP_OK               0
@@ -324,6 +324,11 @@ int sicp_match_work(sicp_ctx *ctx, uint64_t out3[3]);
  * filter's margin and queries float32 cannot place.  (The filtered search reads a 16-byte record per candidate, plus the winner's
  * 32-byte record per query and pass.) */
 int sicp_match_deferred(sicp_ctx *ctx, uint64_t *out);
+/* The single-workgroup tail's own clock (shader cycles) over the phases of the LAST iteration it ran (Q <= 2048): out5[0] loading the
+ * distances and verdicts the match left, [1] median + MAD selection, [2] keep mask + statistics, [3] the minimisation (residual +
+ * Jacobian evaluations, 6x6 solves), [4] statistics of the residuals, convergence test, the record.  What the bench's latency model
+ * (kernel boundaries + dependent memory round trips + these on-chip phases) is built from.  Zeros before the first such iteration. */
+int sicp_tail_cycles(sicp_ctx *ctx, double out5[5]);
 /* Work the one-sweep k-NN (sicp_estimate_normals, sicp_knn with k > 1 on a binned cloud) did since sicp_timing_reset, under
  * sicp_timing_enable(ctx, 2): out4[0] candidates read (one 32-byte record each), out4[1] sweeps (a query needs one when its first
  * ball holds k points), out4[2] queries that took the k-round extraction instead, out4[3] candidates inside their query's ball. */

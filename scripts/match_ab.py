@@ -20,6 +20,7 @@ ref = None
 for var in VARIANTS:
     name, _, envs = var.partition(":")
     env = dict(e.split("=") for e in envs.split(",") if e)
+    env.setdefault("SICP_NN16F_MIN_Q", "1")          # (the flavour asked for, whatever Q)
     os.environ.update(env)
     try:
         c = _lib.Context(0)

@@ -31,7 +31,7 @@ EXPORTS = [
     "sicp_cloud_download", "sicp_cloud_download_columns", "sicp_cloud_download_both", "sicp_cloud_set_planarity", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
     "sicp_corr_match", "sicp_corr_reject_planarity", "sicp_corr_reject_distances", "sicp_estimate_parameters",
-    "sicp_set_exchange", "sicp_comm_unique_id", "sicp_comm_init", "sicp_comm_destroy", "sicp_comm_activate", "sicp_comm_info", "sicp_device_memory", "sicp_set_partition", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_match_deferred", "sicp_knn_work", "sicp_last_match_kernel",
+    "sicp_set_exchange", "sicp_comm_unique_id", "sicp_comm_init", "sicp_comm_destroy", "sicp_comm_activate", "sicp_comm_info", "sicp_device_memory", "sicp_set_partition", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_match_deferred", "sicp_tail_cycles", "sicp_knn_work", "sicp_last_match_kernel",
     "sicp_xyz_count", "sicp_xyz_read", "sicp_xyz_write",
 ]
 
@@ -125,6 +125,7 @@ def load():
     L.sicp_timing_reset.argtypes = [vp]
     L.sicp_match_work.argtypes = [vp, vp]
     L.sicp_match_deferred.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.sicp_tail_cycles.argtypes = [vp, vp]
     L.sicp_knn_work.argtypes = [vp, vp]
     L.sicp_last_match_kernel.argtypes = [vp, C.POINTER(cint)]
     L.sicp_xyz_count.argtypes = [C.c_char_p, C.POINTER(i64)]
@@ -502,6 +503,12 @@ class Context:
         d = C.c_uint64(0)
         self._chk(self._L.sicp_match_deferred(self._h, C.byref(d)))
         return {"candidates": int(out[0]), "rows": int(out[1]), "launches": int(out[2]), "deferred": int(d.value)}
+
+    def tail_cycles(self):
+        """k_icp_tail's own clock over its phases in the last iteration it ran (shader cycles)."""
+        out = np.zeros(5)
+        self._chk(self._L.sicp_tail_cycles(self._h, _ptr(out)))
+        return dict(zip(("load", "select", "keep", "lm", "final"), (float(v) for v in out)))
 
     def knn_work(self):
         """Work counters of the one-sweep k-NN (normals) since timing_reset (kept while timing_enable(2) is in force)."""

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>          // types and prototypes only: librccl is loaded on demand (sicp_comm_init), never linked
 #include <dlfcn.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -291,6 +292,11 @@ struct sicp_ctx {
     long nn16_min_q = 32768;       // SICP_NN16_MIN_Q: from this many queries per launch on the grid search runs four queries per wave
     int nn16_filter = 2;           // SICP_NN16 = exact (0: k_grid_nn16) | far (1: the filtered search, one flavour) | near (2, default: the lean
                                    // flavour first, the full one for what it leaves)
+    double sub_target = 0.0;       // SICP_SUB_TARGET: points per cell of the subsample's grid (0: the cloud grid's default)
+    long nn16f_min_q = 262144;     // SICP_NN16F_MIN_Q: from this many queries per launch on the many-queries search goes through the float32 filter
+                                   // (below: its two extra launches cost more than the filter saves on a machine that is not full)
+    double far_move = 0.75;        // SICP_FAR_MOVE: the lean flavour goes first once the estimate moves by less than this many cells per iteration
+    bool upload_staged = true;     // SICP_UPLOAD_STAGED=0: every upload is a DMA straight out of the caller's arrays (A/B)
     bool use_boxes = true;         // SICP_BOXES=0: far searches do not trim their rows by the cells' tight boxes
     bool boxes_always = false;     // SICP_BOXES=2: ... and stand-alone searches of a handful of queries build them too (tests)
     long box_min_q = 0;            // SICP_BOX_MIN_Q: build the boxes only for runs with at least this many correspondences
@@ -320,6 +326,7 @@ struct sicp_ctx {
     DevBuf<float> corr_pl;         // per-correspondence planarity columns handed to sicp_corr_reject_planarity: pc1 [Q] | pc2 [Q]
     double last_x[6] = {0}, last_w = 1.0, last_obs[6] = {0}, last_ow[6] = {0};
     double last_ne[30] = {0};      // normal equations at last_x (fused path caches them)
+    double last_tail_cycles[5] = {0};   // k_icp_tail's own clock over its phases, last iteration (sicp_tail_cycles)
     bool have_last_ne = false;
     int solve_mode = 0;            // SICP_SOLVE = fused | host (A/B + tests); 0 = auto
     bool grid_target_forced = false;   // SICP_GRID_TARGET given: every grid uses it
@@ -670,17 +677,19 @@ double key_to_double(unsigned long long k)
 // bins the cloud of `slot` once (own frame); see sicp_grid.hip
 int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const double *Y, const double *Z, long n, Grid &gr, double target = 0.0);
 
-int grid_build(sicp_ctx *c, int slot)
+// icp_queries: how many queries per launch the MATCH of an ICP run is about to send (its caller passes the rank's own count); -1: any
+// other search (sicp_knn, sicp_select_in_range, normals, the operators) -- those take the grid as it is and never rebuild one.
+int grid_build(sicp_ctx *c, int slot, long icp_queries = -1)
 {
     Cloud &cl = c->cloud[slot];
+    if (icp_queries < 0 && cl.grid.valid) return SICP_OK;
     // Points per occupied cell.  Large query sets pay for candidates (the machine is full: 1 M queries in 10 M points take 0.61 ms
     // per match at 16 per cell, 0.51 at 8, 0.62 at 4), the one-wave-per-query search of a few queries pays for round trips
-    // and likes its rows long -- so the movable cloud of a run with many correspondences is binned finer.  (Decided when the grid
-    // is first needed: a grid that exists is kept.)
+    // and likes its rows long -- so the movable cloud of a run with many correspondences is binned finer.
     double target = c->grid_target;
-    if (!c->grid_target_forced && slot == SICP_MOV && c->Q >= c->nn16_min_q && c->nn16_min_q > 0) target = 0.5 * target;
+    if (!c->grid_target_forced && slot == SICP_MOV && icp_queries >= c->nn16_min_q && c->nn16_min_q > 0) target = 0.5 * target;
     // a grid binned for the other regime (the same clouds first registered with 1000 correspondences, then with a million) is
-    // rebuilt: ~1 ms per 10 M points once, against 0.1 ms per iteration of a million queries
+    // rebuilt -- by the ICP match only: ~1 ms per 10 M points once, against 0.1 ms per iteration of a million queries
     if (cl.grid.valid && cl.grid.target_used > 0 && cl.grid.target_used != target) cl.grid.valid = false;
     cl.grid.target_used = target;
     return grid_build_arrays(c, cl, cl.x(), cl.y(), cl.z(), cl.n, cl.grid, target);
@@ -697,7 +706,7 @@ int subsample_build(sicp_ctx *c, int slot)
     CHK(cl.sub_xyz.reserve((size_t)3 * cl.sub_npad));
     launch_stride_sample(c->stream, cl.x(), cl.y(), cl.z(), cl.n, SUB_STRIDE, cl.sub_n, cl.sub_npad, cl.sub_xyz.p);
     HIPCHK(hipGetLastError());
-    return grid_build_arrays(c, cl, cl.sub_xyz.p, cl.sub_xyz.p + cl.sub_npad, cl.sub_xyz.p + 2 * cl.sub_npad, cl.sub_n, cl.sub_grid);
+    return grid_build_arrays(c, cl, cl.sub_xyz.p, cl.sub_xyz.p + cl.sub_npad, cl.sub_xyz.p + 2 * cl.sub_npad, cl.sub_n, cl.sub_grid, c->sub_target);
 }
 
 // bins n points (columns X, Y, Z, inside cl's bounding box) once; see sicp_grid.hip
@@ -719,6 +728,15 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
     // pay 48): six cells per point, at most 2^30 (4 GiB of offsets + as much again of build scratch, on a 288 GB device).
     long cap = 1L << 27;
     if (6 * n > cap) cap = std::min<long>(6 * n, 1L << 30);
+    {
+        // ... and never more than the device can spare: a cell costs 12 bytes of table + build scratch (+ 8 of tight boxes when a far
+        // search asks for them) -- a quarter of what is free, at least 2^22 cells (ranks sharing a device, smaller devices)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const long fit = (long)(free_b / 4 / 20);
+            cap = std::max<long>(1L << 22, std::min(cap, fit));
+        }
+    }
     double h = deff ? std::pow(vol * target / (double)n, 1.0 / deff) : 1.0;
     if (!(h > 0) || !std::isfinite(h)) h = 1.0;
     unsigned long long *d_cnt = (unsigned long long *)(c->small.p + 54);      // 2 u64
@@ -968,7 +986,7 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
         c->last_match_kernel = Q >= c->nn16_min_q ? 5 : 2;
         // large query sets: through the float32 filter (sicp_gridf.hip), what it leaves (ties within its margin) through the exact
         // kernel -- the same answers
-        if (Q >= c->nn16_min_q && c->nn16_filter != 0 && Q < (1L << 31)) {
+        if (Q >= c->nn16_min_q && Q >= c->nn16f_min_q && c->nn16_filter != 0 && Q < (1L << 31)) {
             CHK(grid_companions(c, cl, gr, cl.n, true, c->use_boxes));
             if (gr.filter_ok) {
                 CHK(c->kq_slot.reserve((size_t)4 * Q)); CHK(c->kp_slot.reserve((size_t)4 * Q));
@@ -1102,7 +1120,9 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
 // does the k-NN of Q queries in this cloud go through the grid?  (the grid build hands 32-bit item counts to its scans)
 bool knnk_uses_grid(const sicp_ctx *c, const Cloud &cl, long Q)
 {
-    const bool big = (cl.n > 65536 || (double)cl.n * (double)Q > 1.0e9) && cl.n < (1LL << 31);
+    // (the brute-force k-NN keeps a sorted list per lane: 1000 queries x 44 k points x k = 40 -- the Webots pair -- took it 20.8 ms, the
+    // binning of such a cloud plus the one-sweep search take well under a millisecond: only clouds of a few thousand points stay there)
+    const bool big = (cl.n >= 4096 || (double)cl.n * (double)Q > 1.0e9) && cl.n < (1LL << 31);
     return c->knn1_mode == 3 || (c->knn1_mode == 0 && big);
 }
 
@@ -1265,6 +1285,10 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_NN16")) c->nn16_filter = !std::strcmp(e, "exact") ? 0 : !std::strcmp(e, "far") ? 1 : 2;
     if (const char *e = std::getenv("SICP_BOXES")) { c->use_boxes = std::atoi(e) != 0; c->boxes_always = std::atoi(e) == 2; }
     if (const char *e = std::getenv("SICP_BOX_MIN_Q")) c->box_min_q = std::atol(e);
+    if (const char *e = std::getenv("SICP_UPLOAD_STAGED")) c->upload_staged = std::atoi(e) != 0;
+    if (const char *e = std::getenv("SICP_SUB_TARGET")) { const double t = std::atof(e); if (t >= 0.25 && t <= 1024) c->sub_target = t; }
+    if (const char *e = std::getenv("SICP_NN16F_MIN_Q")) c->nn16f_min_q = std::atol(e);
+    if (const char *e = std::getenv("SICP_FAR_MOVE")) { const double t = std::atof(e); if (t >= 0) c->far_move = t; }
     if (const char *e = std::getenv("SICP_COARSE_ITERS")) c->coarse_iters = std::atoi(e);
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
     if (const char *e = std::getenv("SICP_LM")) c->lm_one_launch = std::strcmp(e, "launches") != 0;
@@ -1362,6 +1386,40 @@ int cloud_stats(sicp_ctx *c, int slot)
     return SICP_OK;
 }
 int upload_end(sicp_ctx *c, int slot) { return cloud_stats(c, slot); }
+
+// Small and medium clouds go through the library's own pinned double buffer: a DMA straight out of the caller's pageable array makes
+// the runtime pin that address range first, and for a range it has not seen before that costs 10-20 ms whatever the size (measured:
+// Webots' two 1 MB uploads took 13-22 ms on fresh arrays, 0.2 ms on recycled addresses).  A host copy into pinned memory costs
+// ~0.1 ms per MB and always the same.  Rows are transposed (or columns copied) by the host on the way, chunk ch + 1 while chunk ch
+// is on the link.  Above UPLOAD_STAGED_MAX points the pinning is the smaller price.
+constexpr int64_t UPLOAD_STAGED_MAX = 1 << 19;       // (one chunk: ~1.5 ms of host copy at most)
+int upload_staged(sicp_ctx *c, Cloud &cl, const double *xyz, const double *x, const double *y, const double *z, int64_t n)
+{
+    const long CH = 1L << 19;                                 // (the download's buffers: 2 x 3 x 512 Ki doubles)
+    if (!c->h_dl) HIPCHK(hipHostMalloc((void **)&c->h_dl, (size_t)2 * 3 * CH * sizeof(double), hipHostMallocDefault));
+    if (!c->dl_ev[0]) { HIPCHK(hipEventCreateWithFlags(&c->dl_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->dl_ev[1], hipEventDisableTiming)); }
+    const long nchunks = (n + CH - 1) / CH;
+    for (long ch = 0; ch < nchunks; ++ch) {
+        const long lo = ch * CH, m = std::min<long>(CH, n - lo);
+        double *b = c->h_dl + (size_t)(ch & 1) * 3 * CH;
+        if (ch >= 2) HIPCHK(hipEventSynchronize(c->dl_ev[ch & 1]));       // the DMA that last read this buffer
+        if (xyz) {
+            const double *src = xyz + 3 * lo;
+            for (long i = 0; i < m; ++i) { b[i] = src[3 * i]; b[CH + i] = src[3 * i + 1]; b[2 * CH + i] = src[3 * i + 2]; }
+        } else {
+            std::memcpy(b, x + lo, (size_t)m * sizeof(double));
+            std::memcpy(b + CH, y + lo, (size_t)m * sizeof(double));
+            std::memcpy(b + 2 * CH, z + lo, (size_t)m * sizeof(double));
+        }
+        HIPCHK(hipMemcpyAsync(cl.x() + lo, b, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(cl.y() + lo, b + CH, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(cl.z() + lo, b + 2 * CH, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipEventRecord(c->dl_ev[ch & 1], c->stream));
+    }
+    launch_pad_fill(c->stream, cl.x(), cl.y(), cl.z(), n, cl.npad);
+    HIPCHK(hipGetLastError());
+    return SICP_OK;
+}
 }  // namespace
 
 SICP_EXPORT int sicp_cloud_upload(sicp_ctx *c, int slot, const double *xyz, int64_t n, int64_t index_base)
@@ -1369,6 +1427,10 @@ SICP_EXPORT int sicp_cloud_upload(sicp_ctx *c, int slot, const double *xyz, int6
     if (!xyz) return fail(SICP_ERR_INVALID, "xyz is null");
     CHK(upload_begin(c, slot, n, index_base));
     Cloud &cl = c->cloud[slot];
+    if (n <= UPLOAD_STAGED_MAX && c->upload_staged) {
+        CHK(upload_staged(c, cl, xyz, nullptr, nullptr, nullptr, n));
+        return upload_end(c, slot);
+    }
     CHK(c->stage.reserve((size_t)3 * n));
     HIPCHK(hipMemcpyAsync(c->stage.p, xyz, (size_t)3 * n * sizeof(double), hipMemcpyDefault, c->stream));
     launch_aos_to_soa(c->stream, c->stage.p, n, cl.npad, cl.x(), cl.y(), cl.z());
@@ -1382,6 +1444,10 @@ SICP_EXPORT int sicp_cloud_upload_columns(sicp_ctx *c, int slot, const double *x
     if (!x || !y || !z) return fail(SICP_ERR_INVALID, "x / y / z is null");
     CHK(upload_begin(c, slot, n, index_base));
     Cloud &cl = c->cloud[slot];
+    if (n <= UPLOAD_STAGED_MAX && c->upload_staged) {
+        CHK(upload_staged(c, cl, nullptr, x, y, z, n));
+        return upload_end(c, slot);
+    }
     // the device layout is column-wise already: three copies straight into place, no staging, no transpose
     HIPCHK(hipMemcpyAsync(cl.x(), x, (size_t)n * sizeof(double), hipMemcpyDefault, c->stream));
     HIPCHK(hipMemcpyAsync(cl.y(), y, (size_t)n * sizeof(double), hipMemcpyDefault, c->stream));
@@ -1487,8 +1553,24 @@ SICP_EXPORT int sicp_cloud_download_both(sicp_ctx *c, int slot, double *xyz_out,
     if (!c->h_dl) HIPCHK(hipHostMalloc((void **)&c->h_dl, (size_t)2 * 3 * CH * sizeof(double), hipHostMallocDefault));
     if (!c->dl_ev[0]) { HIPCHK(hipEventCreateWithFlags(&c->dl_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->dl_ev[1], hipEventDisableTiming)); }
     const long nchunks = (n + CH - 1) / CH;
-    unsigned T = std::thread::hardware_concurrency();
-    T = T < 2 ? 1 : (T > 8 ? 8 : T);
+    // host threads that fan a chunk out: as many as this process may actually run on (cgroup / affinity limits, not the machine's
+    // core count), at most 8, and none for clouds that are one chunk's worth of microseconds
+    unsigned T = 1;
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0) T = (unsigned)CPU_COUNT(&set);
+        else T = std::thread::hardware_concurrency();
+        T = T < 2 ? 1 : (T > 8 ? 8 : T);
+        if (n < (1L << 16)) T = 1;
+    }
+    // waiting: a few polite spins, then sleep -- a spinner must not starve the thread it waits for in a one-CPU container
+    auto wait_until = [](auto &&cond) {
+        for (int spins = 0; !cond(); ++spins) {
+            if (spins < 256) std::this_thread::yield();
+            else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    };
     auto enqueue = [&](long ch) -> int {
         const long lo = ch * CH, m = std::min(CH, n - lo);
         double *b = c->h_dl + (size_t)(ch & 1) * 3 * CH;
@@ -1503,7 +1585,8 @@ SICP_EXPORT int sicp_cloud_download_both(sicp_ctx *c, int slot, double *xyz_out,
     std::atomic<bool> quit{false};
     auto work = [&](unsigned t) {
         for (long ch = 0; ch < nchunks; ++ch) {
-            while (ready.load(std::memory_order_acquire) < ch) { if (quit.load()) return; std::this_thread::yield(); }
+            wait_until([&] { return ready.load(std::memory_order_acquire) >= ch || quit.load(); });
+            if (quit.load()) return;
             const long lo = ch * CH, m = std::min(CH, n - lo);
             const long a = m * t / T, e = m * (t + 1) / T;
             const double *b = c->h_dl + (size_t)(ch & 1) * 3 * CH;
@@ -1520,11 +1603,21 @@ SICP_EXPORT int sicp_cloud_download_both(sicp_ctx *c, int slot, double *xyz_out,
         }
     };
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
+    try {
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
+    } catch (...) {
+        // no thread to be had (resource limits): nothing has been copied yet -- send the ones that started home and do it alone
+        // (an exception must not cross the C ABI)
+        quit.store(true);
+        for (auto &th : pool) th.join();
+        pool.clear();
+        quit.store(false);
+        T = 1;
+    }
     int rc = nchunks > 0 ? enqueue(0) : SICP_OK;
     for (long ch = 0; ch < nchunks && rc == SICP_OK; ++ch) {
         // the buffer chunk ch + 1 lands in was chunk ch - 1's: every worker must be through with it
-        while (done.load(std::memory_order_acquire) < (long)(T - 1) * ch) std::this_thread::yield();
+        wait_until([&] { return done.load(std::memory_order_acquire) >= (long)(T - 1) * ch; });
         if (ch + 1 < nchunks) rc = enqueue(ch + 1);
         if (rc == SICP_OK && hipEventSynchronize(c->dl_ev[ch & 1]) != hipSuccess) rc = fail(SICP_ERR_HIP, "hipEventSynchronize failed");
         if (rc != SICP_OK) break;
@@ -1545,7 +1638,7 @@ SICP_EXPORT int sicp_cloud_download_both(sicp_ctx *c, int slot, double *xyz_out,
             }
         }
         // (the next round's wait covers the other workers; after the last chunk the joins do)
-        while (ch + 1 == nchunks && done.load(std::memory_order_acquire) < (long)(T - 1) * nchunks) std::this_thread::yield();
+        if (ch + 1 == nchunks) wait_until([&] { return done.load(std::memory_order_acquire) >= (long)(T - 1) * nchunks; });
     }
     if (rc != SICP_OK) quit.store(true);
     for (auto &th : pool) th.join();
@@ -1737,7 +1830,11 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
     c->resid_sharded = false;
     // the pruned exact search on the static grid serves every rigid H, i.e. every H(x) of the loop
     const bool grid = (c->knn1_mode == 0 || c->knn1_mode == 3) && cl.n < (1LL << 31);
-    if (grid) CHK(grid_build(c, SICP_MOV));
+    if (grid) {
+        long lo0 = 0, cnt0 = Q;
+        if (c->collective() && c->partition == SICP_PART_QUERIES) cnt0 = query_slice(c, Q, &lo0);      // (this rank's share selects the kernel)
+        CHK(grid_build(c, SICP_MOV, cnt0));
+    }
     const bool small_q = Q <= SOLVE_MAX_Q;
     const int depth = !grid ? 1 : small_q ? c->chain_depth : std::min(c->chain_depth, 2);
 
@@ -1773,6 +1870,9 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
 
     double seqs[REC_RING];
     double xcur[6]; std::memcpy(xcur, P0->x, sizeof xcur);
+    // how far the last completed iteration moved the estimate, as a displacement at the cloud's edge (translation + rotation x radius);
+    // unknown (= far) until a cold run's first record is in, zero for a run that continues from an earlier match
+    double last_move = c->have_prev_match ? 0.0 : std::numeric_limits<double>::infinity();
     int64_t launched = 0, completed = 0;
     const bool cold_start = !c->have_prev_match;      // no earlier match of these queries to bound the first searches
     bool over = false;
@@ -1810,7 +1910,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 // far searches (a run's first iterations) trim their rows by the tight boxes of the cells; large query sets are
                 // searched through the float32 filter (sicp_gridf.hip) when float32 can hold the cloud
                 const bool boxes = c->use_boxes && Q >= c->box_min_q && cnt > 0;
-                bool filt = many_q && c->nn16_filter != 0 && cnt > 0;
+                bool filt = many_q && c->nn16_filter != 0 && cnt > 0 && cnt >= c->nn16f_min_q;
                 if (filt || boxes) CHK(grid_companions(c, cl, cl.grid, cl.n, filt, boxes));
                 if (filt && coarse) CHK(grid_companions(c, cl, cl.sub_grid, cl.sub_n, true, false));
                 if (filt && (!cl.grid.filter_ok || (coarse && !cl.sub_grid.filter_ok))) filt = false;
@@ -1844,7 +1944,9 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                                           tie_list, tie_cnt);
                     // ... and the search proper goes straight to that radius (NN_TIGHT).  A cold search is a far search for every
                     // query: the full flavour takes all slots.  Later the lean flavour goes first and marks what it cannot do.
-                    const bool all_far = coarse || c->nn16_filter == 1;
+                    // (the estimate still moves by a cell or so per iteration: most searches are wide -- the lean flavour would only find
+                    // that out and hand them on; judged from the last iterations the host has seen: the chain runs ahead of it)
+                    const bool all_far = coarse || c->nn16_filter == 1 || !(last_move <= c->far_move * cl.grid.g.h);
                     if (!all_far)
                         launch_grid_nn16f(c->stream, lanes, false, c->icp_dev.p, c->q_slot.p, c->p_slot.p, cnt, cl.grid.g, cl.grid.c0,
                                           cl.grid.eps_p, cl.grid.cell_start.p, cl.grid.recf.p, cl.grid.rec.p, nullptr, ordered, nullptr, nullptr,
@@ -2009,6 +2111,11 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
         R.res_mean = o[16]; R.res_std = o[17];
         params_to_H12(R.x, R.H);
         R.H[12] = 0; R.H[13] = 0; R.H[14] = 0; R.H[15] = 1;
+        {
+            double dt = 0, da = 0;
+            for (int j = 0; j < 3; ++j) { da += (R.x[j] - xcur[j]) * (R.x[j] - xcur[j]); dt += (R.x[3 + j] - xcur[3 + j]) * (R.x[3 + j] - xcur[3 + j]); }
+            last_move = std::sqrt(dt) + std::sqrt(da) * cl.rmax;
+        }
         std::memcpy(xcur, R.x, sizeof xcur);
         c->last_w = R.weight_used;
         std::memcpy(c->last_obs, P0->obs, sizeof c->last_obs);
@@ -2016,6 +2123,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
         std::memcpy(c->last_ne, o + 20, sizeof c->last_ne);
         c->have_last_ne = true;
         c->resid_slot = small_q ? 0 : (int)o[REC_RESID_SLOT];
+        if (small_q) std::memcpy(c->last_tail_cycles, o + 50, 5 * sizeof(double));
         if (c->solve_trace && small_q)
             std::fprintf(stderr, "[tail] cycles: load+dist %.0f select %.0f (median %.0f in %.0f rounds, MAD %.0f in %.0f) keep %.0f lm %.0f "
                                  "(%lld evals %.0f, %lld steps, solves %.0f, accept %.0f) final %.0f\n",
@@ -2635,6 +2743,12 @@ SICP_EXPORT int sicp_match_deferred(sicp_ctx *c, uint64_t *out)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(out, c->match_work.p + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     return sync(c);
+}
+SICP_EXPORT int sicp_tail_cycles(sicp_ctx *c, double out5[5])
+{
+    if (!c || !out5) return fail(SICP_ERR_INVALID, "null argument");
+    std::memcpy(out5, c->last_tail_cycles, sizeof c->last_tail_cycles);
+    return SICP_OK;
 }
 SICP_EXPORT int sicp_knn_work(sicp_ctx *c, uint64_t out4[4])
 {

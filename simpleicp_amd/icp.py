@@ -138,9 +138,12 @@ class SimpleICP:
             return self._run_uploaded(ctx, sharded, msel, n_search, upload_movable, t_start, obs, ow, H,
                                       correspondences, neighbors, min_planarity, max_overlap_distance, min_change,
                                       max_iterations, distance_weights, debug_dirpath)
-        except _lib.BackendError:
+        except BaseException:
+            # ANY way out of a sharded run that is not its normal end (a backend error, a host-side exception between two
+            # collectives, KeyboardInterrupt, MemoryError) may leave this rank out of step with its peers: never revive the
+            # communicator such a run used
             if sharded:
-                dist.forget(ctx)       # never revive a communicator a failed run used
+                dist.forget(ctx)
             raise
         finally:
             # the exchange lives on the process-wide context: a later standalone PointCloud operator must not issue a

@@ -56,6 +56,7 @@ def build_calls():
         "sicp_timing_get": lambda: L.sicp_timing_get(None, 0, C.byref(d), C.byref(i64)),
         "sicp_match_work": lambda: L.sicp_match_work(None, buf),
         "sicp_match_deferred": lambda: L.sicp_match_deferred(None, C.cast(buf, C.POINTER(C.c_uint64))),
+        "sicp_tail_cycles": lambda: L.sicp_tail_cycles(None, buf),
         "sicp_knn_work": lambda: L.sicp_knn_work(None, buf),
         "sicp_last_match_kernel": lambda: L.sicp_last_match_kernel(None, C.byref(ci)),
         "sicp_xyz_count": lambda: L.sicp_xyz_count(None, C.byref(i64)),

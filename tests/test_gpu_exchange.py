@@ -209,4 +209,4 @@ def test_bench_two_ranks_self_launched(partition, launcher):
     # the throughput leg ran under query shards on both ranks and met the oracle
     tp = d["throughput_point"]
     assert tp["n_gpus"] == 2 and tp["comm"]["partition"] == "queries" and tp["comm"]["queries_this_rank"] == (tp["correspondences"] + 1) // 2
-    assert tp["parity"]["ok"] is True and tp["roofline"]["kernel"] in ("k_grid_nn", "k_grid_nn16"), tp
+    assert tp["parity"]["ok"] is True and tp["roofline"]["kernel"] in ("k_grid_nn", "k_grid_nn16", "k_grid_nn16f"), tp

@@ -278,6 +278,8 @@ def ctx_filter(request):
         env["SICP_ORDER_MIN_Q"] = "1"        # ... and the iteration's queries in cell order, one eighth per XCD
         env["SICP_COARSE_MIN_N"] = "1"       # ... and a cold iteration bounded by the subsample's nearest point whatever the cloud size
         env["SICP_NN16"] = {"grid16": "near", "grid16far": "far", "grid16exact": "exact"}[request.param]
+        env["SICP_NN16F_MIN_Q"] = "1"        # ... through the float32 filter whatever the query count
+        env["SICP_FAR_MOVE"] = "1e9"         # ... the lean flavour first in every iteration but the cold one
     os.environ.update(env)
     try:
         c = _lib.Context(0)
@@ -630,9 +632,11 @@ def test_many_queries_search_flavours_agree(quantised):
     sel = np.sort(rng.choice(n, Q, replace=False))
     z = np.zeros(6)
     out = {}
-    flavours = [("near", "16", "1"), ("near", "8", "1"), ("far", "16", "1"), ("far", "8", "0"), ("near", "16", "0"), ("exact", "16", "1"), ("exact", "8", "1")]
-    for mode, gs, boxes in flavours:
-        env = {"SICP_NN_GROUP": gs, "SICP_NN16": mode, "SICP_BOXES": boxes}
+    # (mode, lanes per query, boxes, cells the estimate may move per iteration before every search goes to the full flavour)
+    flavours = [("near", "16", "1", "1e9"), ("near", "8", "1", "1e9"), ("near", "8", "1", "0.75"), ("far", "16", "1", "0.75"), ("far", "8", "0", "0.75"),
+                ("near", "16", "0", "1e9"), ("exact", "16", "1", "0.75"), ("exact", "8", "1", "0.75")]
+    for mode, gs, boxes, far_move in flavours:
+        env = {"SICP_NN_GROUP": gs, "SICP_NN16": mode, "SICP_BOXES": boxes, "SICP_NN16F_MIN_Q": "1", "SICP_FAR_MOVE": far_move}
         os.environ.update(env)
         try:
             c = _lib.Context(0)
@@ -655,8 +659,8 @@ def test_many_queries_search_flavours_agree(quantised):
             whole = c.icp_run(z, z, z, 0.3, 1.0, max_iterations=6, min_change=0.0)
             idx, dist, keep, _ = c.icp_state(residual=False)
             rec.append((tuple(tuple(w.x[:]) for w in whole), idx, dist, keep))
-        out[(mode, gs, boxes)] = rec
-    ref = out[("exact", "16", "1")]
+        out[(mode, gs, boxes, far_move)] = rec
+    ref = out[("exact", "16", "1", "0.75")]
     for key, rec in out.items():
         for a, b in zip(ref[:4], rec[:4]):
             assert all(np.array_equal(u, v) for u, v in zip(a, b)), key
