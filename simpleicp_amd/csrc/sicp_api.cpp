@@ -298,6 +298,7 @@ struct sicp_ctx {
     double far_move = 0.75;        // SICP_FAR_MOVE: the lean flavour goes first once the estimate moves by less than this many cells per iteration
     bool upload_staged = true;     // SICP_UPLOAD_STAGED=0: every upload is a DMA straight out of the caller's arrays (A/B)
     bool use_boxes = true;         // SICP_BOXES=0: far searches do not trim their rows by the cells' tight boxes
+    bool box_eager = false;        // SICP_BOXES=3: every non-empty row of a far search is trimmed at the pass's radius, not only behind a first hit (A/B)
     bool boxes_always = false;     // SICP_BOXES=2: ... and stand-alone searches of a handful of queries build them too (tests)
     long box_min_q = 0;            // SICP_BOX_MIN_Q: build the boxes only for runs with at least this many correspondences
     DevBuf<double> q_slot, p_slot; // filtered search: queries (x, y, z, index) and their last matches in SLOT order (32 bytes each)
@@ -1283,7 +1284,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_KNN_GROUP")) c->knn_group = std::atoi(e);
     if (const char *e = std::getenv("SICP_NN16_MIN_Q")) c->nn16_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_NN16")) c->nn16_filter = !std::strcmp(e, "exact") ? 0 : !std::strcmp(e, "far") ? 1 : 2;
-    if (const char *e = std::getenv("SICP_BOXES")) { c->use_boxes = std::atoi(e) != 0; c->boxes_always = std::atoi(e) == 2; }
+    if (const char *e = std::getenv("SICP_BOXES")) { c->use_boxes = std::atoi(e) != 0; c->boxes_always = std::atoi(e) >= 2; c->box_eager = std::atoi(e) == 3; }
     if (const char *e = std::getenv("SICP_BOX_MIN_Q")) c->box_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_UPLOAD_STAGED")) c->upload_staged = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_SUB_TARGET")) { const double t = std::atof(e); if (t >= 0.25 && t <= 1024) c->sub_target = t; }
@@ -1955,13 +1956,13 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                     launch_grid_nn16f(c->stream, lanes, true, c->icp_dev.p, c->q_slot.p, c->p_slot.p, cnt, cl.grid.g, cl.grid.c0,
                                       cl.grid.eps_p, cl.grid.cell_start.p, cl.grid.recf.p, cl.grid.rec.p, cbox, ordered, nullptr, nullptr,
                                       cl.rmax, inf, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo, c->m_p2.p + 3 * lo, wk,
-                                      coarse ? NN_TIGHT : 0, all_far ? nullptr : c->nn_state.p, tie_list, tie_cnt);
+                                      (coarse ? NN_TIGHT : 0) | (c->box_eager ? NN_EAGER_BOX : 0), all_far ? nullptr : c->nn_state.p, tie_list, tie_cnt);
                     // ties within the filter's margin (and queries float32 cannot place): the exact kernel, from the by-query
                     // arrays (the previous match bounds them; in a cold iteration nothing does: they search outwards)
                     launch_grid_nn_redo(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt,
                                         (prev && !coarse) ? prev + 3 * lo : nullptr, cl.grid.g, cl.grid.cell_start.p, cl.grid.rec.p,
                                         c->icp_dev.p, nullptr, nullptr, cl.rmax, inf, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo,
-                                        c->m_p2.p + 3 * lo, wk, 0, nullptr, cbox, tie_list, tie_cnt, tie_clear);
+                                        c->m_p2.p + 3 * lo, wk, c->box_eager ? NN_EAGER_BOX : 0, nullptr, cbox, tie_list, tie_cnt, tie_clear);
                     c->nn_parity ^= 1;
                 } else {
                 Timed t(c, SICP_K_KNN1);
@@ -1988,7 +1989,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                                            coarse ? c->bound_p2.p + 3 * lo : (prev ? prev + 3 * lo : nullptr), cl.grid.g,
                                            cl.grid.cell_start.p, cl.grid.rec.p, c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p + lo,
                                            c->m_idx.p + lo, c->m_p2.p + 3 * lo, c->count_work ? c->match_work.p : nullptr,
-                                           ordered ? c->q_order.p : nullptr, many_q, coarse ? NN_TIGHT : 0,
+                                           ordered ? c->q_order.p : nullptr, many_q, (coarse ? NN_TIGHT : 0) | (c->box_eager ? NN_EAGER_BOX : 0),
                                            (post_done || pack || pack_idx) ? &pm : nullptr, eight, cbox);
                 }
             } else if (qshard) {

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
 {
     const int lane = threadIdx.x & 63;
     const int tight = flags & NN_TIGHT;
-    const bool approx = (flags & NN_APPROX) != 0;
+    const bool approx = (flags & NN_APPROX) != 0, eager = (flags & NN_EAGER_BOX) != 0;
   auto one = [&](const long q) {
     const double ax = qx[q], ay = qy[q], az = qz[q];      // (issued before the loop state is waited for)
     double px0 = 0, py0 = 0, pz0 = 0;
@@ -430,8 +430,10 @@ __global__ __launch_bounds__(256) void k_grid_nn(
             long row = 0; int cy = 0, cz = 0, xl = 0, xh = -1;
             if (rb + lane < nrows) {
                 row_range(rb + lane, b, len, lb2, row, cy, cz, xl, xh);
-                // (a later batch of a far search: an earlier batch's hit already bounds the answer)
-                if (cell_box && cull2 < __builtin_inf() && len > 0) box_trim_row(cell_box, G, row, cy, cz, xl, xh, cxq, cyq, czq, cull2, etol, b, len);
+                // (a later batch of a far search: an earlier batch's hit already bounds the answer; eager: the pass's radius does --
+                // a point beyond it neither ends the search nor is the answer of a pass that ends it by other means)
+                if (cell_box && len > 0 && (cull2 < __builtin_inf() || (eager && !all)))
+                    box_trim_row(cell_box, G, row, cy, cz, xl, xh, cxq, cyq, czq, fmin(r2, cull2), etol, b, len);
             }
             unsigned long long todo = __ballot(len > 0);          // rows of this batch that hold points
             if (work && len > 0) n_rows += 1;                     // (per-lane tallies, summed once at the end)

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
     bool active = slot < Q;
     if (FAR && state) active = active && state[active ? slot : 0] == (uint8_t)1;
     if (!__any(active)) return;
-    const bool tight = (flags & NN_TIGHT) != 0, approx = (flags & NN_APPROX) != 0;
+    const bool tight = (flags & NN_TIGHT) != 0, approx = (flags & NN_APPROX) != 0, eager = (flags & NN_EAGER_BOX) != 0;
     double cxq, cyq, czq, slack, r_lim;
     uint32_t q;
     {
@@ -335,6 +335,11 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
                 double lb2 = __builtin_inf();
                 long row = 0; int cy = 0, cz = 0, xl = 0, xh = -1;
                 if (rb + gl < nrows) row_range(rb + gl, b, len, lb2, row, cy, cz, xl, xh);
+                // (eager: a point beyond the pass's radius -- or the hit's, once there is one -- never ends the search nor is the answer
+                // of a pass that ends it by other means: `last`, `r >= r_lim` hold the answer inside r; `all` takes every cell)
+                if (eager && cell_box && !all && __any(len > 0)) {
+                    if (len > 0) box_trim_row(cell_box, G, row, cy, cz, xl, xh, cxq, cyq, czq, fmin(r2, cull2), etol, b, len);
+                }
                 unsigned todo = (unsigned)(__ballot(len > 0) >> gbase) & GMASK;      // this group's rows that hold points
                 if (work && len > 0) n_rows += 1u;
                 const bool many = __popc(todo) > 4;
@@ -365,7 +370,8 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
                         const bool shrunk = c2 < cull2;
                         if (shrunk) cull2 = c2;
                         if (((todo >> gl) & 1u) && rb + gl < nrows) {
-                            if (shrunk) row_range(rb + gl, b, len, lb2, row, cy, cz, xl, xh);
+                            // (a row is trimmed from its FULL range: re-ranged first when eager trimming already cut it at the pass's radius)
+                            if (shrunk || eager) row_range(rb + gl, b, len, lb2, row, cy, cz, xl, xh);
                             if (cell_box && len > 0 && lb2 <= cull2) box_trim_row(cell_box, G, row, cy, cz, xl, xh, cxq, cyq, czq, cull2, etol, b, len);
                         }
                     }

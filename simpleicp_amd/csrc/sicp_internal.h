@@ -117,6 +117,7 @@ void launch_scatter(hipStream_t s, const double *x, const double *y, const doubl
 // cell_box (nullable): the cells' tight boxes (sicp_grid_dev.h): far searches trim their rows by them
 constexpr int NN_TIGHT = 1;      // prev_p2 is a bound to search in one go (the nearest point of a subsample), not an old match
 constexpr int NN_APPROX = 2;     // the first hit is good enough: the caller wants a cloud point NEAR the query (a bound), not the nearest
+constexpr int NN_EAGER_BOX = 4;  // trim every non-empty row by its cells' tight boxes at the PASS's radius, not only behind a first hit
 void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                     const GridGeom &G, const uint32_t *cell_start, const void *rec, const Xf *H, const Xf *Hinv, double rmax,
                     double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
