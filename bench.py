@@ -179,6 +179,34 @@ def match_bytes(kernel, per, nq):
     return per["candidates"] * 32 + per["rows"] * 8 + nq * (24 + 24 + 48)
 
 
+def latency_model(steady_us, from_cold_us, tail_cycles):
+    """The bound a latency-bound iteration (Q <= 2048: match kernel + ONE single-workgroup tail) can be held against -- its HBM
+    roofline fraction (1e-3) says nothing.  Three terms, priced from MI355X_MICROARCH.md:
+      * dependent kernel boundaries: match -> tail -> next match, 2 per iteration x 1.45 us ("boundary" row of the price table);
+      * dependent global-memory round trips on the critical path, counted from the code, x the HBM-miss latency (~900 cycles at
+        2.4 GHz = 0.375 us): the match has 3 (query + previous match + loop state; cell offsets; records), the tail 2 (the distances and
+        verdicts the match left, with its other operands in flight beside them; the record it writes to host memory, waited for at the
+        kernel's end);
+      * the tail's on-chip phases -- median + MAD selection, keep mask, the minimisation, residual statistics -- from its OWN clock
+        (sicp_tail_cycles; its first phase, loading, is the round trip already counted) at the 2.4 GHz peak clock.
+    frac_of_floor = floor / measured steady iteration: what is NOT in the floor is the match's own arithmetic, launch ramps of 250
+    workgroups, clocks below peak, and host jitter."""
+    clock_ghz = 2.4
+    boundaries, boundary_us = 2, 1.45
+    trips = {"match": 3, "tail": 2}
+    trip_us = 900.0 / (clock_ghz * 1e3)
+    onchip_cycles = tail_cycles["select"] + tail_cycles["keep"] + tail_cycles["lm"] + tail_cycles["final"]
+    floor = boundaries * boundary_us + sum(trips.values()) * trip_us + onchip_cycles / (clock_ghz * 1e3)
+    return {"floor_us": floor, "steady_us": steady_us, "frac_of_floor": floor / steady_us if steady_us else None,
+            "from_cold_us_per_step": from_cold_us,
+            "terms_us": {"kernel_boundaries": boundaries * boundary_us, "global_round_trips": sum(trips.values()) * trip_us,
+                         "tail_on_chip": onchip_cycles / (clock_ghz * 1e3)},
+            "dependent_kernel_boundaries": boundaries, "boundary_us": boundary_us, "dependent_global_round_trips": trips,
+            "round_trip_us": trip_us, "tail_cycles": tail_cycles, "clock_ghz": clock_ghz,
+            "note": "floor = 2 kernel boundaries + 5 dependent HBM round trips + the tail's on-chip phases (its own cycle counters); "
+                    "steady = wall clock per iteration over 30 iterations after the estimate has settled"}
+
+
 def csrc_hash():
     """sha256 over the kernel sources (name + bytes, sorted): what a committed PMC summary is valid for."""
     import hashlib
@@ -366,6 +394,18 @@ def run(args):
     times = np.array(times)
     elapsed = float(np.median(times))
 
+    # steady state (a run's iterations from about its tenth on: the estimate has stopped moving, one LM step per iteration): 30 more
+    # iterations from where the K timed ones ended, events off, wall clock -- what the latency model below is held against
+    steady_us = None
+    if world == 1:
+        xs, _, _ = iterate(ctx, 12, x.copy(), obs, ow)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        iterate(ctx, 30, xs, obs, ow)
+        torch.cuda.synchronize()
+        steady_us = (time.perf_counter() - t0) / 30 * 1e6
+    tail_cycles = ctx.tail_cycles() if nq <= 2048 else None
+
     # instrumented pass: the same K steps with HIP events around every kernel class (perturbs the step, so it is
     # not the timed run)
     ctx.timing_enable(True)
@@ -502,6 +542,10 @@ def run(args):
     }
     if H_true is not None:
         out["accuracy"] = {"max_abs_H_minus_H_true": float(np.abs(H - H_true).max())}
+    if steady_us is not None:
+        out["steady_us_per_step"] = steady_us
+    if fused and tail_cycles is not None and steady_us and not exchange:
+        out["latency_model"] = latency_model(steady_us, elapsed / args.steps * 1e6, tail_cycles)
 
     if comm is not None:
         out["comm"] = comm
@@ -515,6 +559,14 @@ def run(args):
         if "_normals_parity_args" in tp:
             tp["roofline_normals"]["parity"] = normals_parity(Xf, *tp.pop("_normals_parity_args"))
         out["throughput_point" if i == 0 else f"throughput_point_q{tp['correspondences']}"] = tp
+    if tps:
+        # the headline is strong-scaled and latency-bound (1000 correspondences cannot use a second GPU): the number a 1 -> 8 GPU curve
+        # CAN raise is the largest throughput leg's, whose queries are sharded over the ranks
+        big = max(tps, key=lambda t: t["correspondences"])
+        out["scaling_relevant"] = {"metric": f"kNN correspondences/s, {big['correspondences']} correspondences per iteration, "
+                                             + ("query shards" if world > 1 else "1 GPU"),
+                                   "value": big["correspondences_per_s"], "unit": "correspondences/s", "n_gpus": world,
+                                   "ms_per_step": big["ms_per_step"]}
     if world == 1 and not args.no_end_to_end:
         out["run_end_to_end"] = end_to_end(Xf, Xm, Q, k, kw)
     if world == 1 and not args.no_bruteforce_leg and Nm * nq <= 2e11:

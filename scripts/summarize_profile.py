@@ -21,7 +21,7 @@ tag = sys.argv[1]
 dst = ROOT / "profiles" / tag
 dst.mkdir(parents=True, exist_ok=True)
 WATCH = ("grid_nn", "icp_tail", "knn1_f", "lm_eval", "lm_finish", "lm_advance", "lm_all", "k_reject", "k_scatter", "k_cell_ids", "k_cloud_stats",
-         "hsel", "keep_stats", "postmatch", "grid_knn", "knn_sweep", "cov_normals", "k_normals", "query_order", "pack_best", "lexmin")
+         "hsel", "keep_stats", "postmatch", "grid_knn", "knn_sweep", "cov_normals", "k_normals", "query_order", "pack_best", "lexmin", "slot_queries", "k_recf", "cell_boxes")
 
 
 def short(name):

@@ -97,6 +97,7 @@ struct Grid {
     double avg_per_cell = 0;
     double target_used = 0;          // points per occupied cell the build aimed at (grid_build: rebuilt when the regime changes)
     bool cap_limited = false;        // the cell table's size limit, not the points-per-cell target, set the cell size
+    double pointwise_occupancy = 0;  // sum c^2 / n over the cells: how many points share the cell of an average point
     DevBuf<uint32_t> cell_start;     // ncells + 1
     DevBuf<double> rec;              // the cloud in cell order: packed 32-byte records (x, y, z, local row as int64 bits)
     // companions, built the first time a search wants them (grid_companions) and dropped with the grid:
@@ -289,15 +290,19 @@ struct sicp_ctx {
     DevBuf<int64_t> bound_idx;
     int coarse_iters = 1;          // SICP_COARSE_ITERS: chained iterations (from a cold start) whose search is bounded by the subsample's
     long coarse_min_n = 262144;    // ... for clouds of at least this many points
-    long nn16_min_q = 32768;       // SICP_NN16_MIN_Q: from this many queries per launch on the grid search runs four queries per wave
+    long nn16_min_q = 8192;        // SICP_NN16_MIN_Q: from this many queries per launch on the grid search runs four queries per wave (measured on 10 M
+                                   // points: steady match 10.2 us against 35.7 at 16 384 queries, 19.9 / 69.7 at 32 768 -- one wave per query stops
+                                   // being latency-bound at ~4 000 queries; its fused distance epilogue is worth a launch, ~4 us)
     int nn16_filter = 2;           // SICP_NN16 = exact (0: k_grid_nn16) | far (1: the filtered search, one flavour) | near (2, default: the lean
                                    // flavour first, the full one for what it leaves)
+    bool grid_pointwise = true;    // SICP_GRID_POINTWISE=0: the cell size follows the average over occupied cells only (A/B)
     double sub_target = 0.0;       // SICP_SUB_TARGET: points per cell of the subsample's grid (0: the cloud grid's default)
-    long nn16f_min_q = 262144;     // SICP_NN16F_MIN_Q: from this many queries per launch on the many-queries search goes through the float32 filter
+    long nn16f_min_q = 196608;     // SICP_NN16F_MIN_Q: from this many queries per launch on the many-queries search goes through the float32 filter
                                    // (below: its two extra launches cost more than the filter saves on a machine that is not full)
     double far_move = 0.75;        // SICP_FAR_MOVE: the lean flavour goes first once the estimate moves by less than this many cells per iteration
     bool upload_staged = true;     // SICP_UPLOAD_STAGED=0: every upload is a DMA straight out of the caller's arrays (A/B)
-    bool use_boxes = true;         // SICP_BOXES=0: far searches do not trim their rows by the cells' tight boxes
+    bool use_boxes = false;        // SICP_BOXES=1: far searches trim their rows by the cells' tight boxes.  OFF by default: measured (profiles/r5), the
+                                   // boxes cut 14-30 % of the candidates and never a microsecond -- DESIGN.md section 4
     bool box_eager = false;        // SICP_BOXES=3: every non-empty row of a far search is trimmed at the pass's radius, not only behind a first hit (A/B)
     bool boxes_always = false;     // SICP_BOXES=2: ... and stand-alone searches of a handful of queries build them too (tests)
     long box_min_q = 0;            // SICP_BOX_MIN_Q: build the boxes only for runs with at least this many correspondences
@@ -308,6 +313,7 @@ struct sicp_ctx {
     DevBuf<uint8_t> nn_state;      // by slot: 1 = the lean flavour left this query to the full one
     DevBuf<uint32_t> nn_redo;      // [0], [1] counters (alternating by launch), [2..] queries left to the exact kernel
     int nn_parity = 0;
+    double last_move = 0.0;        // displacement at the cloud's edge the last completed iteration caused (far / lean flavour choice)
     int last_match_kernel = 0;     // 0 exact scan, 1 filtered scan (inline), 2 grid, 3 filtered scan (record + fix-up), 5 grid, four queries per wave (exact), 6 grid, float32 filter
     // ICP state (selected fixed points and per-iteration products)
     int64_t Q = 0, qpad = 0;
@@ -792,6 +798,7 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
     GridGeom G;
     long ncells = 1;
     for (int attempt = 0;; ++attempt) {
+        bool capped = false;
         for (;;) {
             ncells = 1;
             for (int a = 0; a < 3; ++a) {
@@ -802,22 +809,37 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
             }
             if (ncells <= cap) break;
             h *= std::cbrt((double)ncells / (double)cap) * 1.02;
-            gr.cap_limited = true;                       // cells are coarser than the target asked for
+            capped = true;
         }
+        gr.cap_limited = capped;                         // cells are coarser than the target asked for
         for (int a = 0; a < 3; ++a) G.mn[a] = mn[a];
         G.h = h; G.inv_h = 1.0 / h;
         CHK(c->g_counts.reserve((size_t)ncells + 1));
+        CHK(c->g_blk.reserve((size_t)grid_scan_blocks(ncells) + 1));
         HIPCHK(hipMemsetAsync(c->g_counts.p, 0, ((size_t)ncells + 1) * sizeof(uint32_t), c->stream));
-        HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), c->stream));
+        HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), c->stream));
         launch_cell_ids(c->stream, X, Y, Z, n, G, c->g_ids.p, c->g_counts.p, probed ? nullptr : d_cnt);
+        // first step of the offsets' scan; it also leaves sum c^2 over the cells: sum c^2 / n = the occupancy of the cell an average
+        // POINT lives in.  On a scan whose density falls like 1 / r^2 that is thousands where the average over occupied cells says 16
+        // -- and it is what a query, itself a point of such a cloud, pays for.  The cell size follows it (down to the table's limit).
+        launch_grid_scan_sums(c->stream, c->g_counts.p, ncells, c->g_blk.p, d_cnt + 1);
         HIPCHK(hipGetLastError());
-        if (probed) { gr.avg_per_cell = target; break; }
-        HIPCHK(hipMemcpyAsync(c->h_small + 54, d_cnt, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_small + 54, d_cnt, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         CHK(sync(c));
-        unsigned long long occ; std::memcpy(&occ, c->h_small + 54, sizeof occ);
-        gr.avg_per_cell = (double)n / (double)std::max<unsigned long long>(occ, 1);
+        unsigned long long res2[2]; std::memcpy(res2, c->h_small + 54, sizeof res2);
+        const double pw = (double)res2[1] / (double)std::max<long>(n, 1);
+        gr.avg_per_cell = probed ? target : (double)n / (double)std::max<unsigned long long>(res2[0], 1);
         // still far too coarse (small clouds are not probed; windows can mislead): shrink and bin again
-        if (gr.avg_per_cell > 3 * target && attempt < 4 && ncells < cap / 2) { h *= std::sqrt(target / gr.avg_per_cell); continue; }
+        if (!probed && gr.avg_per_cell > 3 * target && attempt < 4 && ncells < cap / 2) { h *= std::sqrt(target / gr.avg_per_cell); continue; }
+        // the points' own view: shrink until an average point shares its cell with a few times the target (occupancy ~ h^2 on a surface);
+        // not below the table's limit (a binning that was capped stands), at most six rounds
+        if (c->grid_pointwise && pw > 4.0 * target && !capped && attempt < 6) {
+            const double f = std::sqrt(2.0 * target / pw);
+            h *= f < 0.3 ? 0.3 : (f > 0.8 ? 0.8 : f);
+            probed = false;                              // (the window's evidence is overruled: measure the plain occupancy too from here on)
+            continue;
+        }
+        gr.pointwise_occupancy = pw;
         break;
     }
     gr.g = G; gr.ncells = ncells;
@@ -825,9 +847,8 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
     // point once, as a packed record, into its cell's range
     CHK(gr.cell_start.reserve((size_t)ncells + 1));
     CHK(c->g_cursor.reserve((size_t)ncells + 1));
-    CHK(c->g_blk.reserve((size_t)grid_scan_blocks(ncells) + 1));
     CHK(gr.rec.reserve((size_t)4 * n));
-    launch_grid_scan(c->stream, c->g_counts.p, ncells, c->g_blk.p, gr.cell_start.p, c->g_cursor.p);
+    launch_grid_scan_rest(c->stream, c->g_counts.p, ncells, c->g_blk.p, gr.cell_start.p, c->g_cursor.p);
     launch_scatter(c->stream, X, Y, Z, c->g_ids.p, n, c->g_cursor.p, gr.rec.p);
     HIPCHK(hipGetLastError());
     CHK(sync(c));
@@ -1011,9 +1032,9 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
                 launch_grid_nn16f(c->stream, 16, true, nullptr, c->kq_slot.p, c->kp_slot.p, Q, gr.g, gr.c0, gr.eps_p, gr.cell_start.p,
                                   gr.recf.p, gr.rec.p, cbox, false, H, H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out,
                                   p2_out, wk, 0, all_far ? nullptr : c->nn_state.p, tie_list, tie_cnt);
-                launch_grid_nn_redo(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, prev_p2, gr.g, gr.cell_start.p, gr.rec.p, nullptr, H,
-                                    H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out, p2_out, wk, 0, nullptr, cbox,
-                                    tie_list, tie_cnt, tie_clear);
+                launch_grid_nn_redo(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, p2_out ? p2_out : prev_p2, gr.g, gr.cell_start.p, gr.rec.p,
+                                    nullptr, H, H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out, p2_out, wk,
+                                    p2_out ? NN_TIGHT : 0, nullptr, cbox, tie_list, tie_cnt, tie_clear);
                 c->nn_parity ^= 1;
                 HIPCHK(hipGetLastError());
                 return SICP_OK;
@@ -1287,6 +1308,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_BOXES")) { c->use_boxes = std::atoi(e) != 0; c->boxes_always = std::atoi(e) >= 2; c->box_eager = std::atoi(e) == 3; }
     if (const char *e = std::getenv("SICP_BOX_MIN_Q")) c->box_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_UPLOAD_STAGED")) c->upload_staged = std::atoi(e) != 0;
+    if (const char *e = std::getenv("SICP_GRID_POINTWISE")) c->grid_pointwise = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_SUB_TARGET")) { const double t = std::atof(e); if (t >= 0.25 && t <= 1024) c->sub_target = t; }
     if (const char *e = std::getenv("SICP_NN16F_MIN_Q")) c->nn16f_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_FAR_MOVE")) { const double t = std::atof(e); if (t >= 0) c->far_move = t; }
@@ -1873,7 +1895,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
     double xcur[6]; std::memcpy(xcur, P0->x, sizeof xcur);
     // how far the last completed iteration moved the estimate, as a displacement at the cloud's edge (translation + rotation x radius);
     // unknown (= far) until a cold run's first record is in, zero for a run that continues from an earlier match
-    double last_move = c->have_prev_match ? 0.0 : std::numeric_limits<double>::infinity();
+    double last_move = c->have_prev_match ? c->last_move : std::numeric_limits<double>::infinity();
     int64_t launched = 0, completed = 0;
     const bool cold_start = !c->have_prev_match;      // no earlier match of these queries to bound the first searches
     bool over = false;
@@ -1959,10 +1981,11 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                                       (coarse ? NN_TIGHT : 0) | (c->box_eager ? NN_EAGER_BOX : 0), all_far ? nullptr : c->nn_state.p, tie_list, tie_cnt);
                     // ties within the filter's margin (and queries float32 cannot place): the exact kernel, from the by-query
                     // arrays (the previous match bounds them; in a cold iteration nothing does: they search outwards)
+                    // (the filtered kernels left every such query's approximate winner -- or "none" -- in the by-query match array)
                     launch_grid_nn_redo(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt,
-                                        (prev && !coarse) ? prev + 3 * lo : nullptr, cl.grid.g, cl.grid.cell_start.p, cl.grid.rec.p,
+                                        c->m_p2.p + 3 * lo, cl.grid.g, cl.grid.cell_start.p, cl.grid.rec.p,
                                         c->icp_dev.p, nullptr, nullptr, cl.rmax, inf, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo,
-                                        c->m_p2.p + 3 * lo, wk, c->box_eager ? NN_EAGER_BOX : 0, nullptr, cbox, tie_list, tie_cnt, tie_clear);
+                                        c->m_p2.p + 3 * lo, wk, NN_TIGHT | (c->box_eager ? NN_EAGER_BOX : 0), nullptr, cbox, tie_list, tie_cnt, tie_clear);
                     c->nn_parity ^= 1;
                 } else {
                 Timed t(c, SICP_K_KNN1);
@@ -2116,6 +2139,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
             double dt = 0, da = 0;
             for (int j = 0; j < 3; ++j) { da += (R.x[j] - xcur[j]) * (R.x[j] - xcur[j]); dt += (R.x[3 + j] - xcur[3 + j]) * (R.x[3 + j] - xcur[3 + j]); }
             last_move = std::sqrt(dt) + std::sqrt(da) * cl.rmax;
+            c->last_move = last_move;                    // (a host-driven loop -- one iteration per call -- carries it from call to call)
         }
         std::memcpy(xcur, R.x, sizeof xcur);
         c->last_w = R.weight_used;

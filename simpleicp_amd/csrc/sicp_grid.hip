@@ -193,15 +193,26 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *total)
     *total = wsum4[0] + wsum4[1] + wsum4[2] + wsum4[3];
     return before + incl - v;
 }
-__global__ __launch_bounds__(256) void k_scan_sums(const uint32_t *__restrict__ in, long n, uint32_t *__restrict__ block_sum)
+// (sumsq, nullable: += sum of the squares of the counts -- sum c^2 / n is the occupancy of the cell an average POINT lives in, what a
+// cloud whose density varies by orders of magnitude must be binned for: the plain average over occupied cells hides its dense core)
+__global__ __launch_bounds__(256) void k_scan_sums(const uint32_t *__restrict__ in, long n, uint32_t *__restrict__ block_sum,
+                                                   unsigned long long *__restrict__ sumsq)
 {
     const long base = (long)blockIdx.x * SCAN_ITEMS + (long)threadIdx.x * 8;
     unsigned s = 0;
+    unsigned long long q = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (base + k < n) s += in[base + k];
+    for (int k = 0; k < 8; ++k) if (base + k < n) { const unsigned v = in[base + k]; s += v; q += (unsigned long long)v * v; }
     unsigned total;
     (void)block_excl_scan(s, &total);
     if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
+    if (sumsq) {
+        __shared__ unsigned long long qs[4];
+        q = wsum_u64(q);
+        if ((threadIdx.x & 63) == 0) qs[threadIdx.x >> 6] = q;
+        __syncthreads();
+        if (threadIdx.x == 0) { const unsigned long long t = (qs[0] + qs[1]) + (qs[2] + qs[3]); if (t) atomicAdd(sumsq, t); }
+    }
 }
 __global__ __launch_bounds__(256) void k_scan_blocks(uint32_t *__restrict__ block_sum, long nblocks)      // ONE workgroup, in place -> exclusive
 {
@@ -2185,8 +2196,18 @@ long grid_scan_blocks(long n) { return (n + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS; }
 // out[0..n] = exclusive prefix sums of in[0..n) (entry n = total); block_off: grid_scan_blocks(n) words of scratch
 void launch_grid_scan(hipStream_t s, const uint32_t *in, long n, uint32_t *block_off, uint32_t *out, uint32_t *cursor)
 {
+    launch_grid_scan_sums(s, in, n, block_off, nullptr);
+    launch_grid_scan_rest(s, in, n, block_off, out, cursor);
+}
+// the same in two steps: the block sums first (with the sum of squares of the counts, for a caller that still has to decide whether
+// this binning stands), the rest once it does
+void launch_grid_scan_sums(hipStream_t s, const uint32_t *in, long n, uint32_t *block_off, unsigned long long *sumsq)
+{
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)grid_scan_blocks(n)), dim3(256), 0, s, in, n, block_off, sumsq);
+}
+void launch_grid_scan_rest(hipStream_t s, const uint32_t *in, long n, uint32_t *block_off, uint32_t *out, uint32_t *cursor)
+{
     const long nb = grid_scan_blocks(n);
-    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(256), 0, s, in, n, block_off);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, block_off, nb);
     hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(256), 0, s, in, n, (const uint32_t *)block_off, out, cursor);
 }

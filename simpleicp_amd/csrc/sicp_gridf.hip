@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
     }
     bool done = !active || defer, last = false;
     if (approx) defer = false;                // (a search for a bound answers nobody: such a query simply gets no bound)
+    const bool done_by_search = !defer;       // (false: left to the exact kernel before any search)
     bool far_defer = false;
     unsigned n_cand = 0, n_rows = 0;
     for (int pass = 0; pass < 4096 && __any(!done); ++pass) {
@@ -423,7 +424,10 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
             const bool fin = (found && best <= r_eff2) || all || r >= r_lim || last || (approx && found);
             if (fin) {
                 if (found && !alone && !approx) {
-                    defer = true;                           // a tie within the margin: the exact kernel answers this query
+                    // a tie within the margin: the exact kernel answers this query -- from the approximate winner, a cloud point
+                    // within the margin of the answer: its search goes straight to that radius
+                    defer = true;
+                    if (gl == 1 && p2_out) { p2_out[3 * (long)q] = W.x; p2_out[3 * (long)q + 1] = W.y; p2_out[3 * (long)q + 2] = W.z; }
                 } else {
                     const uint32_t bidx = found ? (uint32_t)(unsigned long long)__double_as_longlong(W.w) : 0u;
                     const bool ok = found && (best < max_d2);
@@ -445,6 +449,8 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
     }
     // (a query left to another kernel keeps its old bound in pslot: a cloud point still, so still a bound)
     if (!FAR && state && active && gl == 0) state[slot] = far_defer ? (uint8_t)1 : (uint8_t)0;
+    // (a query float32 cannot place goes to the exact kernel with no bound at all: x = inf says so)
+    if (defer && !done_by_search && gl == 1 && p2_out) p2_out[3 * (long)q] = __builtin_inf();
     {
         // the exact kernel's list: one addition per WAVE (data with coincident points defers every query: a million additions to
         // one word would cost milliseconds)

@@ -111,6 +111,8 @@ void launch_window_probe(hipStream_t s, const double *x, const double *y, const 
                          const double wmax[3], uint32_t *counts, unsigned long long *out2);
 long grid_scan_blocks(long n);
 void launch_grid_scan(hipStream_t s, const uint32_t *in, long n, uint32_t *block_off, uint32_t *out, uint32_t *cursor);
+void launch_grid_scan_sums(hipStream_t s, const uint32_t *in, long n, uint32_t *block_off, unsigned long long *sumsq);
+void launch_grid_scan_rest(hipStream_t s, const uint32_t *in, long n, uint32_t *block_off, uint32_t *out, uint32_t *cursor);
 void launch_scatter(hipStream_t s, const double *x, const double *y, const double *z, const uint32_t *ids, long n,
                     uint32_t *cursor, void *rec);
 // rec: the cloud in cell order as packed 32-byte records (x, y, z, original row as int64 bits)
