@@ -404,7 +404,7 @@ def run(args):
         iterate(ctx, 30, xs, obs, ow)
         torch.cuda.synchronize()
         steady_us = (time.perf_counter() - t0) / 30 * 1e6
-    tail_cycles = ctx.tail_cycles() if nq <= 2048 else None
+    tail_cycles = ctx.tail_cycles() if len(sel) <= 2048 else None
 
     # instrumented pass: the same K steps with HIP events around every kernel class (perturbs the step, so it is
     # not the timed run)

@@ -1027,10 +1027,10 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
                 const bool all_far = c->nn16_filter == 1;
                 if (!all_far)
                     launch_grid_nn16f(c->stream, 16, false, nullptr, c->kq_slot.p, c->kp_slot.p, Q, gr.g, gr.c0, gr.eps_p, gr.cell_start.p,
-                                      gr.recf.p, gr.rec.p, nullptr, false, H, H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out,
+                                      gr.recf.p, gr.rec.p, false, H, H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out,
                                       idx_out, p2_out, wk, 0, c->nn_state.p, tie_list, tie_cnt);
                 launch_grid_nn16f(c->stream, 16, true, nullptr, c->kq_slot.p, c->kp_slot.p, Q, gr.g, gr.c0, gr.eps_p, gr.cell_start.p,
-                                  gr.recf.p, gr.rec.p, cbox, false, H, H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out,
+                                  gr.recf.p, gr.rec.p, false, H, H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out,
                                   p2_out, wk, 0, all_far ? nullptr : c->nn_state.p, tie_list, tie_cnt);
                 launch_grid_nn_redo(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, p2_out ? p2_out : prev_p2, gr.g, gr.cell_start.p, gr.rec.p,
                                     nullptr, H, H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out, p2_out, wk,
@@ -1962,7 +1962,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                     // cold: the subsample's nearest point (any point near the query: NN_APPROX) is left in the slot as the bound ...
                     if (coarse)
                         launch_grid_nn16f(c->stream, lanes, true, c->icp_dev.p, c->q_slot.p, c->p_slot.p, cnt, cl.sub_grid.g, cl.sub_grid.c0,
-                                          cl.sub_grid.eps_p, cl.sub_grid.cell_start.p, cl.sub_grid.recf.p, cl.sub_grid.rec.p, nullptr, ordered,
+                                          cl.sub_grid.eps_p, cl.sub_grid.cell_start.p, cl.sub_grid.recf.p, cl.sub_grid.rec.p, ordered,
                                           nullptr, nullptr, cl.rmax, inf, 0, nullptr, nullptr, nullptr, nullptr, NN_APPROX, nullptr,
                                           tie_list, tie_cnt);
                     // ... and the search proper goes straight to that radius (NN_TIGHT).  A cold search is a far search for every
@@ -1972,11 +1972,11 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                     const bool all_far = coarse || c->nn16_filter == 1 || !(last_move <= c->far_move * cl.grid.g.h);
                     if (!all_far)
                         launch_grid_nn16f(c->stream, lanes, false, c->icp_dev.p, c->q_slot.p, c->p_slot.p, cnt, cl.grid.g, cl.grid.c0,
-                                          cl.grid.eps_p, cl.grid.cell_start.p, cl.grid.recf.p, cl.grid.rec.p, nullptr, ordered, nullptr, nullptr,
+                                          cl.grid.eps_p, cl.grid.cell_start.p, cl.grid.recf.p, cl.grid.rec.p, ordered, nullptr, nullptr,
                                           cl.rmax, inf, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo, c->m_p2.p + 3 * lo, wk, 0,
                                           c->nn_state.p, tie_list, tie_cnt);
                     launch_grid_nn16f(c->stream, lanes, true, c->icp_dev.p, c->q_slot.p, c->p_slot.p, cnt, cl.grid.g, cl.grid.c0,
-                                      cl.grid.eps_p, cl.grid.cell_start.p, cl.grid.recf.p, cl.grid.rec.p, cbox, ordered, nullptr, nullptr,
+                                      cl.grid.eps_p, cl.grid.cell_start.p, cl.grid.recf.p, cl.grid.rec.p, ordered, nullptr, nullptr,
                                       cl.rmax, inf, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo, c->m_p2.p + 3 * lo, wk,
                                       (coarse ? NN_TIGHT : 0) | (c->box_eager ? NN_EAGER_BOX : 0), all_far ? nullptr : c->nn_state.p, tie_list, tie_cnt);
                     // ties within the filter's margin (and queries float32 cannot place): the exact kernel, from the by-query

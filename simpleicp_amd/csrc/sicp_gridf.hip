@@ -21,8 +21,8 @@
 //     exact one-wave-per-query kernel, works off in the launch behind this one.  Same arithmetic as ever for those, so the same bits.
 // The point-to-plane distances and planarity verdicts of an ICP iteration are k_postmatch's here (a launch of its own: fused into a
 // search at its register limit they cost the search more than the launch, measured in round 4), as are the exchange's records.
-// Far searches (a run's first iterations) additionally trim every surviving row by the tight boxes of its cells once a first hit
-// bounds the answer (sicp_grid_dev.h).
+// (The cells' tight boxes, sicp_grid_dev.h, are NOT used here: with candidates this cheap -- 16 bytes, 13 instructions -- trimming rows
+// by them cut 14-30 % of the candidates of a cold search and made it slower, profiles/r5.  They remain an option of the exact kernel.)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <stdint.h>
@@ -151,14 +151,13 @@ void launch_slot_queries(hipStream_t s, const double *qx, const double *qy, cons
 // FAR = false: the flavour of a run's steady state -- a ball of a few rows, one batch of them, no hit-driven culling, no boxes; a
 //   query that turns out to need more (more rows than the group has lanes, more than four of them non-empty) is left to the exact
 //   kernel like a tie.  That is what the registers of five waves per SIMD pay for.
-// FAR = true: everything (a run's first iterations, searches with a distance limit): row batches, nearest row first, the hit's ball,
-//   the cells' tight boxes.
+// FAR = true: everything (a run's first iterations, searches with a distance limit): row batches, nearest row first, the hit's ball.
 template <int GS /* lanes per query: 16 (four queries per wave) or 8 (eight) */, bool FAR>
 __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) void k_grid_nn16f(
     const IcpDev *__restrict__ st, const double4 *__restrict__ qrec /* by slot: x, y, z, query index */,
     double4 *__restrict__ pslot /* by slot: in = a cloud point whose distance bounds the answer (x = inf: none); out = this search's match */,
     const uint32_t *__restrict__ cell_start, const float4 *__restrict__ recf, const double4 *__restrict__ rec,
-    long Q, GridGeom G, FilterGeom F, const unsigned long long *__restrict__ cell_box /* nullable: no trimming */,
+    long Q, GridGeom G, FilterGeom F,
     Xf H, Xf Hinv, int has_H /* without a chain state: is there a transform at all */, double rmax, double max_d2, int64_t idx_base,
     double *__restrict__ d2_out /* nullable with idx_out, p2_out: a search whose only product is the bound it leaves in pslot */,
     int64_t *__restrict__ idx_out, double *__restrict__ p2_out,
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
     bool active = slot < Q;
     if (FAR && state) active = active && state[active ? slot : 0] == (uint8_t)1;
     if (!__any(active)) return;
-    const bool tight = (flags & NN_TIGHT) != 0, approx = (flags & NN_APPROX) != 0, eager = (flags & NN_EAGER_BOX) != 0;
+    const bool tight = (flags & NN_TIGHT) != 0, approx = (flags & NN_APPROX) != 0;
     double cxq, cyq, czq, slack, r_lim;
     uint32_t q;
     {
@@ -277,13 +276,13 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
         const float inv_ny = 1.0f / (float)ny;
         const bool few_rows = nrows < (1L << 22);
         // row rr of the pass's block -> its cells [xl, xh] within the ball (cull2: the hit's ball), its record range
-        auto row_range = [&](long rr, uint32_t &b, uint32_t &len, double &lb2, long &row, int &cy, int &cz, int &xl, int &xh) {
+        auto row_range = [&](long rr, uint32_t &b, uint32_t &len, double &lb2) {
             b = 0; len = 0;
             int oy, oz;
             row_split(rr, ny, inv_ny, few_rows, oy, oz);
-            cy = lo[1] + oy; cz = lo[2] + oz;
-            row = ((long)cz * G.dim[1] + cy) * G.dim[0];
-            xl = lo[0]; xh = hi[0];
+            const int cy = lo[1] + oy, cz = lo[2] + oz;
+            const long row = ((long)cz * G.dim[1] + cy) * G.dim[0];
+            int xl = lo[0], xh = hi[0];
             lb2 = 0.0;
             if (!all) {
                 const double yl = G.mn[1] + (double)cy * G.h, zl = G.mn[2] + (double)cz * G.h;
@@ -312,8 +311,8 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
             uint32_t b = 0, len = 0;
             far_query = !done && nrows > (long)GS;
             if (!far_query && gl < (int)nrows) {
-                double lb2; long row; int cy, cz, xl, xh;
-                row_range((long)gl, b, len, lb2, row, cy, cz, xl, xh);
+                double lb2;
+                row_range((long)gl, b, len, lb2);
             }
             unsigned todo = (unsigned)(__ballot(len > 0) >> gbase) & GMASK;
             if (work && len > 0) n_rows += 1u;
@@ -331,29 +330,42 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
                 scan_rows(rbv, rlv);
             }
         } else {
-            for (long rb = 0; __any(rb < nrows); rb += GS) {
-                uint32_t b = 0, len = 0;
-                double lb2 = __builtin_inf();
-                long row = 0; int cy = 0, cz = 0, xl = 0, xh = -1;
-                if (rb + gl < nrows) row_range(rb + gl, b, len, lb2, row, cy, cz, xl, xh);
-                // (eager: a point beyond the pass's radius -- or the hit's, once there is one -- never ends the search nor is the answer
-                // of a pass that ends it by other means: `last`, `r >= r_lim` hold the answer inside r; `all` takes every cell)
-                if (eager && cell_box && !all && __any(len > 0)) {
-                    if (len > 0) box_trim_row(cell_box, G, row, cy, cz, xl, xh, cxq, cyq, czq, fmin(r2, cull2), etol, b, len);
+            // TWO rows per lane and batch: their offsets are in flight together -- a wide ball's cost is the number of dependent
+            // batches (offsets, then records, per batch), not its candidates (measured: 10 batches of 8 rows made the cold search of
+            // 1 M queries 1.7 ms where its candidates account for 1.2)
+            for (long rb = 0; __any(rb < nrows); rb += 2 * GS) {
+                uint32_t b[2] = {0u, 0u}, len[2] = {0u, 0u};
+                double lb2[2] = {__builtin_inf(), __builtin_inf()};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const long rr = rb + (long)u * GS + gl;
+                    if (rr < nrows) row_range(rr, b[u], len[u], lb2[u]);
                 }
-                unsigned todo = (unsigned)(__ballot(len > 0) >> gbase) & GMASK;      // this group's rows that hold points
-                if (work && len > 0) n_rows += 1u;
+                // bit j of the group's mask: row of lane j % GS, slot j / GS
+                unsigned todo = ((unsigned)(__ballot(len[0] > 0) >> gbase) & GMASK) | (((unsigned)(__ballot(len[1] > 0) >> gbase) & GMASK) << GS);
+                if (work) n_rows += (len[0] > 0 ? 1u : 0u) + (len[1] > 0 ? 1u : 0u);
+                // row j of the group -> its record range (two crossbar moves per slot: the slot is uniform per group, not per wave)
+                auto fetch = [&](int j, uint32_t &vb, uint32_t &vl) {
+                    const int src = gbase + (j & (GS - 1));
+                    const uint32_t b0 = (uint32_t)__shfl((int)b[0], src), b1 = (uint32_t)__shfl((int)b[1], src);
+                    const uint32_t l0 = (uint32_t)__shfl((int)len[0], src), l1 = (uint32_t)__shfl((int)len[1], src);
+                    vb = j >= GS ? b1 : b0; vl = j >= GS ? l1 : l0;
+                };
                 const bool many = __popc(todo) > 4;
                 if (__any(many)) {
-                    // groups with many rows (a far search): nearest row first, then drop the rows its hit rules out, shrink the others'
-                    // x ranges to the hit's ball and trim them by the tight boxes of their cells
-                    unsigned long long key = len > 0 ? (unsigned long long)__double_as_longlong(lb2) : ~0ull, mk = key;
+                    // groups with many rows (a far search): nearest row first, then drop the rows its hit rules out and shrink the
+                    // others' x ranges to the hit's ball
+                    const unsigned long long k0 = len[0] > 0 ? (unsigned long long)__double_as_longlong(lb2[0]) : ~0ull;
+                    const unsigned long long k1 = len[1] > 0 ? (unsigned long long)__double_as_longlong(lb2[1]) : ~0ull;
+                    unsigned long long mk = k0 < k1 ? k0 : k1;
                     { unsigned long long o;
                       if constexpr (GS == 16) { o = lane_xor64<8>(mk);  mk = o < mk ? o : mk; }  o = lane_xor64<4>(mk);  mk = o < mk ? o : mk;
                       o = lane_xor64<2>(mk);  mk = o < mk ? o : mk;  o = lane_xor64<1>(mk);  mk = o < mk ? o : mk; }
-                    const unsigned geq = (unsigned)(__ballot(len > 0 && key == mk) >> gbase) & GMASK;
+                    const unsigned geq = ((unsigned)(__ballot(len[0] > 0 && k0 == mk) >> gbase) & GMASK) |
+                                         (((unsigned)(__ballot(len[1] > 0 && k1 == mk) >> gbase) & GMASK) << GS);
                     const int j = (many && geq) ? __ffs((int)geq) - 1 : 0;
-                    const uint32_t vb = (uint32_t)__shfl((int)b, gbase + j), vl = (uint32_t)__shfl((int)len, gbase + j);
+                    uint32_t vb, vl;
+                    fetch(j, vb, vl);
                     const uint32_t rbv[2] = {many ? vb : 0u, 0u};
                     const uint32_t rlv[2] = {many ? vl : 0u, 0u};
                     if (many) todo &= ~(1u << j);
@@ -368,15 +380,17 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
                         // gb + T bounds the own-frame squared distance of a cloud point from above, with room for the difference
                         // between the frames on both sides (T = 2 E): nothing beyond it can beat or tie the answer
                         const double c2 = ((double)gb + (double)T) * (1.0 + 1e-6);
-                        const bool shrunk = c2 < cull2;
-                        if (shrunk) cull2 = c2;
-                        if (((todo >> gl) & 1u) && rb + gl < nrows) {
-                            // (a row is trimmed from its FULL range: re-ranged first when eager trimming already cut it at the pass's radius)
-                            if (shrunk || eager) row_range(rb + gl, b, len, lb2, row, cy, cz, xl, xh);
-                            if (cell_box && len > 0 && lb2 <= cull2) box_trim_row(cell_box, G, row, cy, cz, xl, xh, cxq, cyq, czq, cull2, etol, b, len);
+                        if (c2 < cull2) {
+                            cull2 = c2;
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const long rr = rb + (long)u * GS + gl;
+                                if (((todo >> (gl + u * GS)) & 1u) && rr < nrows) row_range(rr, b[u], len[u], lb2[u]);
+                            }
                         }
                     }
-                    todo &= (unsigned)(__ballot(len > 0 && lb2 <= cull2) >> gbase) & GMASK;
+                    todo &= ((unsigned)(__ballot(len[0] > 0 && lb2[0] <= cull2) >> gbase) & GMASK) |
+                            (((unsigned)(__ballot(len[1] > 0 && lb2[1] <= cull2) >> gbase) & GMASK) << GS);
                 }
                 while (__any(todo != 0u)) {
                     uint32_t rbv[2], rlv[2];
@@ -385,7 +399,8 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
                         const bool has = todo != 0u;
                         const int j = has ? __ffs((int)todo) - 1 : 0;
                         todo &= todo - 1u;
-                        const uint32_t vb = (uint32_t)__shfl((int)b, gbase + j), vl = (uint32_t)__shfl((int)len, gbase + j);
+                        uint32_t vb, vl;
+                        fetch(j, vb, vl);
                         rbv[u] = has ? vb : 0u; rlv[u] = has ? vl : 0u;
                     }
                     scan_rows(rbv, rlv);
@@ -472,7 +487,7 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
 
 void launch_grid_nn16f(hipStream_t s, int lanes_per_query, bool far, const IcpDev *st, const void *qrec, void *pslot, long Q,
                        const GridGeom &G, const double c0[3], double eps_p, const uint32_t *cell_start,
-                       const void *recf, const void *rec, const unsigned long long *cell_box, bool xcd_order, const Xf *H,
+                       const void *recf, const void *rec, bool xcd_order, const Xf *H,
                        const Xf *Hinv, double rmax, double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out,
                        unsigned long long *work, int flags, uint8_t *state, uint32_t *redo_list, unsigned *redo_count)
 {
@@ -485,7 +500,7 @@ void launch_grid_nn16f(hipStream_t s, int lanes_per_query, bool far, const IcpDe
     if (xcd_order) g = (g + 7u) & ~7u;
 #define SICP_NN16F_LAUNCH(GS_, FAR_)                                                                                                       \
     hipLaunchKernelGGL((k_grid_nn16f<GS_, FAR_>), dim3(g), dim3(256), 0, s, st, (const double4 *)qrec, (double4 *)pslot, cell_start,       \
-                       (const float4 *)recf, (const double4 *)rec, Q, G, F, cell_box, H ? *H : id, Hinv ? *Hinv : id, has_H, rmax, max_d2, \
+                       (const float4 *)recf, (const double4 *)rec, Q, G, F, H ? *H : id, Hinv ? *Hinv : id, has_H, rmax, max_d2, \
                        idx_base, d2_out, idx_out, p2_out, work, flags, xcd_order ? 1 : 0, state, redo_list, redo_count)
     if (lanes_per_query == 8) { if (far) SICP_NN16F_LAUNCH(8, true); else SICP_NN16F_LAUNCH(8, false); }
     else { if (far) SICP_NN16F_LAUNCH(16, true); else SICP_NN16F_LAUNCH(16, false); }

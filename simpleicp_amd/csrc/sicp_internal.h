@@ -143,7 +143,7 @@ void launch_slot_queries(hipStream_t s, const double *qx, const double *qy, cons
 // which marks the queries it cannot do in `state` (1) for a launch of the other flavour over the same slots
 void launch_grid_nn16f(hipStream_t s, int lanes_per_query, bool far, const IcpDev *st, const void *qrec, void *pslot, long Q,
                        const GridGeom &G, const double c0[3], double eps_p, const uint32_t *cell_start,
-                       const void *recf, const void *rec, const unsigned long long *cell_box, bool xcd_order, const Xf *H,
+                       const void *recf, const void *rec, bool xcd_order, const Xf *H,
                        const Xf *Hinv, double rmax, double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out,
                        unsigned long long *work, int flags, uint8_t *state, uint32_t *redo_list, unsigned *redo_count);
 void launch_stride_sample(hipStream_t s, const double *x, const double *y, const double *z, long n, long stride, long m, long mpad,
