@@ -98,6 +98,8 @@ struct Grid {
     double target_used = 0;          // points per occupied cell the build aimed at (grid_build: rebuilt when the regime changes)
     bool cap_limited = false;        // the cell table's size limit, not the points-per-cell target, set the cell size
     double pointwise_occupancy = 0;  // sum c^2 / n over the cells: how many points share the cell of an average point
+    bool nonuniform = false;         // the cell size was set by the points' own view (dense core), not by the average: wide balls cross
+                                     // thousands of its rows -- such a cloud gets a coarse twin (Cloud::coarse_grid)
     DevBuf<uint32_t> cell_start;     // ncells + 1
     DevBuf<double> rec;              // the cloud in cell order: packed 32-byte records (x, y, z, local row as int64 bits)
     // companions, built the first time a search wants them (grid_companions) and dropped with the grid:
@@ -120,6 +122,7 @@ struct Cloud {
     // point, so its distance bounds the answer -- one cheap search hands the real one a radius instead of a doubling ladder
     DevBuf<double> sub_xyz; int64_t sub_n = 0, sub_npad = 0;
     Grid sub_grid;
+    Grid coarse_grid;     // ALL points again in cells 8 x as wide, only for clouds whose grid is `nonuniform`: the exact search's wide passes
     const double *x() const { return xyz.p; }
     const double *y() const { return xyz.p + npad; }
     const double *z() const { return xyz.p + 2 * npad; }
@@ -288,7 +291,7 @@ struct sicp_ctx {
     bool knn_sweep = true;         // SICP_KNN_SWEEP=0: k extraction rounds (k_grid_knn) + k_normals instead of the one-sweep kernel
     DevBuf<double> bound_p2, bound_d2;   // cold search: nearest subsample point per query (coordinates = the bound) + scratch
     DevBuf<int64_t> bound_idx;
-    int coarse_iters = 1;          // SICP_COARSE_ITERS: chained iterations (from a cold start) whose search is bounded by the subsample's
+    int coarse_iters = 1;          // chained iterations (from a cold start) whose search is bounded by the subsample's (more than one helped nowhere)
     long coarse_min_n = 262144;    // ... for clouds of at least this many points
     long nn16_min_q = 8192;        // SICP_NN16_MIN_Q: from this many queries per launch on the grid search runs four queries per wave (measured on 10 M
                                    // points: steady match 10.2 us against 35.7 at 16 384 queries, 19.9 / 69.7 at 32 768 -- one wave per query stops
@@ -296,16 +299,13 @@ struct sicp_ctx {
     int nn16_filter = 2;           // SICP_NN16 = exact (0: k_grid_nn16) | far (1: the filtered search, one flavour) | near (2, default: the lean
                                    // flavour first, the full one for what it leaves)
     bool grid_pointwise = true;    // SICP_GRID_POINTWISE=0: the cell size follows the average over occupied cells only (A/B)
-    double sub_target = 0.0;       // SICP_SUB_TARGET: points per cell of the subsample's grid (0: the cloud grid's default)
     long nn16f_min_q = 196608;     // SICP_NN16F_MIN_Q: from this many queries per launch on the many-queries search goes through the float32 filter
                                    // (below: its two extra launches cost more than the filter saves on a machine that is not full)
     double far_move = 0.75;        // SICP_FAR_MOVE: the lean flavour goes first once the estimate moves by less than this many cells per iteration
     bool upload_staged = true;     // SICP_UPLOAD_STAGED=0: every upload is a DMA straight out of the caller's arrays (A/B)
     bool use_boxes = false;        // SICP_BOXES=1: far searches trim their rows by the cells' tight boxes.  OFF by default: measured (profiles/r5), the
                                    // boxes cut 14-30 % of the candidates and never a microsecond -- DESIGN.md section 4
-    bool box_eager = false;        // SICP_BOXES=3: every non-empty row of a far search is trimmed at the pass's radius, not only behind a first hit (A/B)
     bool boxes_always = false;     // SICP_BOXES=2: ... and stand-alone searches of a handful of queries build them too (tests)
-    long box_min_q = 0;            // SICP_BOX_MIN_Q: build the boxes only for runs with at least this many correspondences
     DevBuf<double> q_slot, p_slot; // filtered search: queries (x, y, z, index) and their last matches in SLOT order (32 bytes each)
     long slot_lo = -1, slot_cnt = 0;
     bool slot_ordered = false;
@@ -359,7 +359,6 @@ struct sicp_ctx {
     long hsel_run_launches = 0;    // chained rejection launches since the last setup (the window needs two of them behind it)
     bool hsel_dirty = false;
     int nn_group = 0;              // SICP_NN_GROUP=8|16: lanes per query of the many-queries search (0: chosen per launch)
-    bool match_epilogue = true;    // SICP_MATCH_EPILOGUE=0: distances + verdicts by k_postmatch even without an exchange (A/B)
     int chain_depth = 4;           // iterations enqueued ahead of the last record read (SICP_CHAIN_DEPTH)
     // exchange: an RCCL communicator of the library's own (sicp_comm_init) or a host callback (sicp_set_exchange)
     sicp_exchange_fn xfn = nullptr;
@@ -682,7 +681,8 @@ double key_to_double(unsigned long long k)
 }
 
 // bins the cloud of `slot` once (own frame); see sicp_grid.hip
-int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const double *Y, const double *Z, long n, Grid &gr, double target = 0.0);
+int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const double *Y, const double *Z, long n, Grid &gr, double target = 0.0,
+                      double h_forced = 0.0);
 
 // icp_queries: how many queries per launch the MATCH of an ICP run is about to send (its caller passes the rank's own count); -1: any
 // other search (sicp_knn, sicp_select_in_range, normals, the operators) -- those take the grid as it is and never rebuild one.
@@ -703,7 +703,7 @@ int grid_build(sicp_ctx *c, int slot, long icp_queries = -1)
 }
 
 // the cloud's subsample (every SUB_STRIDE-th point) and its grid
-static const long SUB_STRIDE = [] { const char *e = std::getenv("SICP_SUB_STRIDE"); const long v = e ? std::atol(e) : 0; return v >= 2 && v <= 4096 ? v : 64L; }();   // (A/B: SICP_SUB_STRIDE)
+constexpr long SUB_STRIDE = 64;       // (measured 64 / 16 / 8: 152 / 128 / 122 candidates per query of the cold search -- the subsample's own search pays the difference back)
 int subsample_build(sicp_ctx *c, int slot)
 {
     Cloud &cl = c->cloud[slot];
@@ -713,15 +713,29 @@ int subsample_build(sicp_ctx *c, int slot)
     CHK(cl.sub_xyz.reserve((size_t)3 * cl.sub_npad));
     launch_stride_sample(c->stream, cl.x(), cl.y(), cl.z(), cl.n, SUB_STRIDE, cl.sub_n, cl.sub_npad, cl.sub_xyz.p);
     HIPCHK(hipGetLastError());
-    return grid_build_arrays(c, cl, cl.sub_xyz.p, cl.sub_xyz.p + cl.sub_npad, cl.sub_xyz.p + 2 * cl.sub_npad, cl.sub_n, cl.sub_grid, c->sub_target);
+    return grid_build_arrays(c, cl, cl.sub_xyz.p, cl.sub_xyz.p + cl.sub_npad, cl.sub_xyz.p + 2 * cl.sub_npad, cl.sub_n, cl.sub_grid);      // (points per cell of this grid: 4 / 8 / 16 measured equal)
+}
+
+// the coarse twin of a nonuniform grid (all points, cells 8 x as wide); null when the cloud needs none
+int grid_coarse_level(sicp_ctx *c, int slot, GridLevel *lv, const GridLevel **out)
+{
+    Cloud &cl = c->cloud[slot];
+    *out = nullptr;
+    if (!cl.grid.valid || !cl.grid.nonuniform) return SICP_OK;
+    CHK(grid_build_arrays(c, cl, cl.x(), cl.y(), cl.z(), cl.n, cl.coarse_grid, 0.0, 8.0 * cl.grid.g.h));
+    lv->g = cl.coarse_grid.g; lv->cell_start = cl.coarse_grid.cell_start.p; lv->rec = cl.coarse_grid.rec.p;
+    *out = lv;
+    return SICP_OK;
 }
 
 // bins n points (columns X, Y, Z, inside cl's bounding box) once; see sicp_grid.hip
-int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const double *Y, const double *Z, long n, Grid &gr, double target_in)
+int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const double *Y, const double *Z, long n, Grid &gr, double target_in,
+                      double h_forced)
 {
     if (gr.valid) return SICP_OK;
     gr.cap_limited = false;
     gr.recf_valid = false; gr.box_valid = false;
+    gr.nonuniform = false;
     double mn[3], ex[3], vol = 1.0; int deff = 0;
     for (int a = 0; a < 3; ++a) {
         mn[a] = cl.bb_lo[a];
@@ -751,7 +765,8 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
     // the occupancy in a small central window of the box (1/8 of every extent) at the candidate cell size and
     // correct it -- a coalesced read of the cloud per probe instead of a full trial binning with random atomics.
     bool probed = false;                             // the window probes settled on this h: no full-cloud occupancy check
-    if (n >= 262144 && deff > 0) {
+    if (h_forced > 0.0) h = h_forced;                // (a coarse twin: the caller names the cell size, nothing is probed or adjusted)
+    if (n >= 262144 && deff > 0 && !(h_forced > 0.0)) {
         const long every = 4;                        // a quarter of the cloud: cells of ~16 points still hold ~4 sampled ones
         double wlo[3], whi[3];
         for (int a = 0; a < 3; ++a) {
@@ -830,6 +845,7 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
         const double pw = (double)res2[1] / (double)std::max<long>(n, 1);
         gr.avg_per_cell = probed ? target : (double)n / (double)std::max<unsigned long long>(res2[0], 1);
         // still far too coarse (small clouds are not probed; windows can mislead): shrink and bin again
+        if (h_forced > 0.0) { gr.pointwise_occupancy = pw; break; }
         if (!probed && gr.avg_per_cell > 3 * target && attempt < 4 && ncells < cap / 2) { h *= std::sqrt(target / gr.avg_per_cell); continue; }
         // the points' own view: shrink until an average point shares its cell with a few times the target (occupancy ~ h^2 on a surface);
         // not below the table's limit (a binning that was capped stands), at most six rounds
@@ -837,6 +853,7 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
             const double f = std::sqrt(2.0 * target / pw);
             h *= f < 0.3 ? 0.3 : (f > 0.8 ? 0.8 : f);
             probed = false;                              // (the window's evidence is overruled: measure the plain occupancy too from here on)
+            gr.nonuniform = true;
             continue;
         }
         gr.pointwise_occupancy = pw;
@@ -1005,7 +1022,11 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
     if (rigid && (c->knn1_mode == 3 || (c->knn1_mode == 0 && big))) {
         CHK(grid_build(c, slot));
         Grid &gr = cl.grid;
-        c->last_match_kernel = Q >= c->nn16_min_q ? 5 : 2;
+        GridLevel coarse_lv; const GridLevel *coarse = nullptr;
+        CHK(grid_coarse_level(c, slot, &coarse_lv, &coarse));
+        // (a nonuniform cloud: one wave per query -- 64 rows per batch and the coarse grid for wide passes -- until the filtered search takes over)
+        const bool four = Q >= c->nn16_min_q && !gr.nonuniform;
+        c->last_match_kernel = four ? 5 : 2;
         // large query sets: through the float32 filter (sicp_gridf.hip), what it leaves (ties within its margin) through the exact
         // kernel -- the same answers
         if (Q >= c->nn16_min_q && Q >= c->nn16f_min_q && c->nn16_filter != 0 && Q < (1L << 31)) {
@@ -1034,7 +1055,7 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
                                   p2_out, wk, 0, all_far ? nullptr : c->nn_state.p, tie_list, tie_cnt);
                 launch_grid_nn_redo(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, p2_out ? p2_out : prev_p2, gr.g, gr.cell_start.p, gr.rec.p,
                                     nullptr, H, H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out, p2_out, wk,
-                                    p2_out ? NN_TIGHT : 0, nullptr, cbox, tie_list, tie_cnt, tie_clear);
+                                    p2_out ? NN_TIGHT : 0, nullptr, cbox, tie_list, tie_cnt, tie_clear, coarse);
                 c->nn_parity ^= 1;
                 HIPCHK(hipGetLastError());
                 return SICP_OK;
@@ -1047,7 +1068,7 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
             Timed t(c, SICP_K_KNN1);
             launch_grid_nn(c->stream, qsoa, qsoa + qpad, qsoa + 2 * qpad, Q, prev_p2, gr.g, gr.cell_start.p, gr.rec.p, H,
                            H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out, idx_out, p2_out,
-                           c->count_work ? c->match_work.p : nullptr, Q >= c->nn16_min_q, boxes ? gr.cell_box.p : nullptr);
+                           c->count_work ? c->match_work.p : nullptr, four, boxes ? gr.cell_box.p : nullptr, coarse);
         }
         HIPCHK(hipGetLastError());
         return SICP_OK;
@@ -1305,20 +1326,16 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_KNN_GROUP")) c->knn_group = std::atoi(e);
     if (const char *e = std::getenv("SICP_NN16_MIN_Q")) c->nn16_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_NN16")) c->nn16_filter = !std::strcmp(e, "exact") ? 0 : !std::strcmp(e, "far") ? 1 : 2;
-    if (const char *e = std::getenv("SICP_BOXES")) { c->use_boxes = std::atoi(e) != 0; c->boxes_always = std::atoi(e) >= 2; c->box_eager = std::atoi(e) == 3; }
-    if (const char *e = std::getenv("SICP_BOX_MIN_Q")) c->box_min_q = std::atol(e);
+    if (const char *e = std::getenv("SICP_BOXES")) { c->use_boxes = std::atoi(e) != 0; c->boxes_always = std::atoi(e) >= 2; }
     if (const char *e = std::getenv("SICP_UPLOAD_STAGED")) c->upload_staged = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_GRID_POINTWISE")) c->grid_pointwise = std::atoi(e) != 0;
-    if (const char *e = std::getenv("SICP_SUB_TARGET")) { const double t = std::atof(e); if (t >= 0.25 && t <= 1024) c->sub_target = t; }
     if (const char *e = std::getenv("SICP_NN16F_MIN_Q")) c->nn16f_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_FAR_MOVE")) { const double t = std::atof(e); if (t >= 0) c->far_move = t; }
-    if (const char *e = std::getenv("SICP_COARSE_ITERS")) c->coarse_iters = std::atoi(e);
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
     if (const char *e = std::getenv("SICP_LM")) c->lm_one_launch = std::strcmp(e, "launches") != 0;
     if (const char *e = std::getenv("SICP_HSEL_WINDOW")) c->hsel_window = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_TEST_BARRIER_FAULT")) c->test_barrier_fault = std::atoi(e);
     if (const char *e = std::getenv("SICP_NN_GROUP")) { const int v = std::atoi(e); if (v == 8 || v == 16) c->nn_group = v; }
-    if (const char *e = std::getenv("SICP_MATCH_EPILOGUE")) c->match_epilogue = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_XCHG_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) c->xchg_timeout_s = v; }
     if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
     if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : 0;
@@ -1379,7 +1396,7 @@ int upload_begin(sicp_ctx *c, int slot, int64_t n, int64_t index_base)
     HIPCHK(hipSetDevice(c->device));
     Cloud &cl = c->cloud[slot];
     cl.n = n; cl.npad = round_up(n, TILE_PTS); cl.idx_base = index_base;
-    cl.grid.valid = false; cl.sub_grid.valid = false;
+    cl.grid.valid = false; cl.sub_grid.valid = false; cl.coarse_grid.valid = false;
     cl.pl_n = 0;                                       // a new cloud has no planarity column until one is set
     CHK(cl.xyz.reserve((size_t)3 * cl.npad));
     return SICP_OK;
@@ -1497,7 +1514,7 @@ SICP_EXPORT int sicp_cloud_transform(sicp_ctx *c, int slot, const double H[16])
     Cloud &cl = c->cloud[slot];
     launch_transform(c->stream, cl.x(), cl.y(), cl.z(), cl.n, X);
     HIPCHK(hipGetLastError());
-    cl.grid.valid = false; cl.sub_grid.valid = false;
+    cl.grid.valid = false; cl.sub_grid.valid = false; cl.coarse_grid.valid = false;
     return cloud_stats(c, slot);                          // new bounding box / largest norm (also the synchronisation point)
 }
 
@@ -1913,7 +1930,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 // their place in the full arrays)
                 long lo = 0, cnt = Q;
                 if (qshard) cnt = query_slice(c, Q, &lo);
-                c->last_match_kernel = cnt >= c->nn16_min_q ? 5 : 2;
+                c->last_match_kernel = (cnt >= c->nn16_min_q && (!cl.grid.nonuniform || cnt >= c->nn16f_min_q)) ? 5 : 2;
                 const bool ordered = c->order_min_q > 0 && cnt >= c->order_min_q;
                 if (ordered) CHK(query_order_build(c, lo, cnt, cl.grid.g.h));
                 // A search without a useful bound (the run's first iterations: no previous match, or one made under an estimate
@@ -1929,10 +1946,13 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 // table's limit leaves 25 points per cell, 8 lanes need twice the steps: 2.07 -> 2.53 ms per step) nor below ~200 k
                 // queries (too few waves to fill the machine)
                 const bool eight = c->nn_group ? c->nn_group == 8 : (cnt >= 196608 && !cl.grid.cap_limited && cl.grid.avg_per_cell <= 20.0);
-                const bool many_q = cnt >= c->nn16_min_q;
+                GridLevel coarse_lv; const GridLevel *coarse_grid = nullptr;
+                CHK(grid_coarse_level(c, SICP_MOV, &coarse_lv, &coarse_grid));
+                // (a nonuniform cloud: one wave per query -- 64 rows per batch, the coarse grid for wide passes -- until the filtered search takes over)
+                const bool many_q = cnt >= c->nn16_min_q && (!cl.grid.nonuniform || cnt >= c->nn16f_min_q);
                 // far searches (a run's first iterations) trim their rows by the tight boxes of the cells; large query sets are
                 // searched through the float32 filter (sicp_gridf.hip) when float32 can hold the cloud
-                const bool boxes = c->use_boxes && Q >= c->box_min_q && cnt > 0;
+                const bool boxes = c->use_boxes && cnt > 0;
                 bool filt = many_q && c->nn16_filter != 0 && cnt > 0 && cnt >= c->nn16f_min_q;
                 if (filt || boxes) CHK(grid_companions(c, cl, cl.grid, cl.n, filt, boxes));
                 if (filt && coarse) CHK(grid_companions(c, cl, cl.sub_grid, cl.sub_n, true, false));
@@ -1978,14 +1998,14 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                     launch_grid_nn16f(c->stream, lanes, true, c->icp_dev.p, c->q_slot.p, c->p_slot.p, cnt, cl.grid.g, cl.grid.c0,
                                       cl.grid.eps_p, cl.grid.cell_start.p, cl.grid.recf.p, cl.grid.rec.p, ordered, nullptr, nullptr,
                                       cl.rmax, inf, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo, c->m_p2.p + 3 * lo, wk,
-                                      (coarse ? NN_TIGHT : 0) | (c->box_eager ? NN_EAGER_BOX : 0), all_far ? nullptr : c->nn_state.p, tie_list, tie_cnt);
+                                      (coarse ? NN_TIGHT : 0), all_far ? nullptr : c->nn_state.p, tie_list, tie_cnt);
                     // ties within the filter's margin (and queries float32 cannot place): the exact kernel, from the by-query
                     // arrays (the previous match bounds them; in a cold iteration nothing does: they search outwards)
                     // (the filtered kernels left every such query's approximate winner -- or "none" -- in the by-query match array)
                     launch_grid_nn_redo(c->stream, c->q.p + lo, c->q.p + c->qpad + lo, c->q.p + 2 * c->qpad + lo, cnt,
                                         c->m_p2.p + 3 * lo, cl.grid.g, cl.grid.cell_start.p, cl.grid.rec.p,
                                         c->icp_dev.p, nullptr, nullptr, cl.rmax, inf, cl.idx_base, c->m_d2.p + lo, c->m_idx.p + lo,
-                                        c->m_p2.p + 3 * lo, wk, NN_TIGHT | (c->box_eager ? NN_EAGER_BOX : 0), nullptr, cbox, tie_list, tie_cnt, tie_clear);
+                                        c->m_p2.p + 3 * lo, wk, NN_TIGHT, nullptr, cbox, tie_list, tie_cnt, tie_clear, coarse_grid);
                     c->nn_parity ^= 1;
                 } else {
                 Timed t(c, SICP_K_KNN1);
@@ -1998,7 +2018,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 // distance and the planarity verdict too (what k_postmatch would re-read 72 bytes per correspondence for)
                 // (only in the one-wave-per-query flavour: with four queries per wave at the register limit the epilogue's late
                 // loads cost the search more than k_postmatch's launch -- match 693 -> 758 us at 1 M queries, measured)
-                post_done = !c->collective() && c->match_epilogue && !many_q;
+                post_done = !c->collective() && !many_q;
                 // behind a cloud-shard exchange the winning lanes leave the exchange's packed record instead (no k_pack_best launch)
                 // (query shards: the slim record, the matched index alone -- no k_pack_idx launch)
                 const bool pack = c->collective() && !qshard, pack_idx = c->collective() && qshard;
@@ -2012,8 +2032,8 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                                            coarse ? c->bound_p2.p + 3 * lo : (prev ? prev + 3 * lo : nullptr), cl.grid.g,
                                            cl.grid.cell_start.p, cl.grid.rec.p, c->icp_dev.p, cl.rmax, cl.idx_base, c->m_d2.p + lo,
                                            c->m_idx.p + lo, c->m_p2.p + 3 * lo, c->count_work ? c->match_work.p : nullptr,
-                                           ordered ? c->q_order.p : nullptr, many_q, (coarse ? NN_TIGHT : 0) | (c->box_eager ? NN_EAGER_BOX : 0),
-                                           (post_done || pack || pack_idx) ? &pm : nullptr, eight, cbox);
+                                           ordered ? c->q_order.p : nullptr, many_q, (coarse ? NN_TIGHT : 0),
+                                           (post_done || pack || pack_idx) ? &pm : nullptr, eight, cbox, coarse_grid);
                 }
             } else if (qshard) {
                 return fail(SICP_ERR_INVALID, "query shards need the grid search (SICP_KNN1 forces another kernel)");

@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     PostMatch post /* chained match of an ICP iteration: the winning lane also leaves the point-to-plane distance and the
                       planarity verdict (corrpts.py:139-163,195-211) -- it holds the matched point, the query and H already */,
     const unsigned long long *__restrict__ cell_box /* nullable: the cells' tight boxes (sicp_grid_dev.h) -- far searches trim their rows */,
+    GridGeom G2, const uint32_t *__restrict__ cell_start2 /* nullable: no coarse grid */, const double4 *__restrict__ rec2,
     const uint32_t *__restrict__ redo_list /* nullable: ONLY the queries listed here (what the filtered many-queries kernel left) */,
     const unsigned *__restrict__ redo_count /* entries of redo_list */,
     unsigned *__restrict__ redo_clear /* nullable: the counter the NEXT search's kernels add to -- cleared here (nobody touches it
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
 {
     const int lane = threadIdx.x & 63;
     const int tight = flags & NN_TIGHT;
-    const bool approx = (flags & NN_APPROX) != 0, eager = (flags & NN_EAGER_BOX) != 0;
+    const bool approx = (flags & NN_APPROX) != 0;
   auto one = [&](const long q) {
     const double ax = qx[q], ay = qy[q], az = qz[q];      // (issued before the loop state is waited for)
     double px0 = 0, py0 = 0, pz0 = 0;
@@ -356,17 +357,25 @@ __global__ __launch_bounds__(256) void k_grid_nn(
     unsigned long long n_cand = 0, n_rows = 0;
     bool last = false;
     for (int pass = 0; pass < 4096; ++pass) {                 // (ends by itself: the radius doubles until it hits, then one more pass)
+        // A cloud whose density varies by orders of magnitude is binned for its dense core (cells of centimetres) -- and a query whose
+        // answer lies metres away would walk ten thousand rows of that grid.  Such clouds carry a second, COARSE grid over the same
+        // points (cells 8 x as wide): a pass whose ball spans more than a few fine cells runs on it.  Both grids hold every point, so
+        // which one a pass reads changes what it costs, never what it finds.  (One query per wave: the choice is wave-uniform.)
+        const bool cp = cell_start2 != nullptr && r > 4.0 * G.h;
+        const GridGeom &Gp = cp ? G2 : G;
+        const uint32_t *__restrict__ csp = cp ? cell_start2 : cell_start;
+        const double4 *__restrict__ rcp = cp ? rec2 : rec;
         int lo[3], hi[3];
         const double c3[3] = {cxq, cyq, czq};
         bool all = true;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double fl = floor((c3[a] - r - G.mn[a]) * G.inv_h - 1e-6);
-            const double fh = floor((c3[a] + r - G.mn[a]) * G.inv_h + 1e-6);
-            lo[a] = fl < 0.0 ? 0 : (fl > (double)(G.dim[a] - 1) ? G.dim[a] - 1 : (int)fl);
-            hi[a] = fh < 0.0 ? 0 : (fh > (double)(G.dim[a] - 1) ? G.dim[a] - 1 : (int)fh);
+            const double fl = floor((c3[a] - r - Gp.mn[a]) * Gp.inv_h - 1e-6);
+            const double fh = floor((c3[a] + r - Gp.mn[a]) * Gp.inv_h + 1e-6);
+            lo[a] = fl < 0.0 ? 0 : (fl > (double)(Gp.dim[a] - 1) ? Gp.dim[a] - 1 : (int)fl);
+            hi[a] = fh < 0.0 ? 0 : (fh > (double)(Gp.dim[a] - 1) ? Gp.dim[a] - 1 : (int)fh);
             // whole axis covered <=> the ball reaches past both faces of the box
-            all = all && (fl <= 0.0) && (fh >= (double)(G.dim[a] - 1));
+            all = all && (fl <= 0.0) && (fh >= (double)(Gp.dim[a] - 1));
         }
         best = __builtin_inf(); bidx = 0xffffffffu;
         const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     ok[u] = o + (uint32_t)lane < rlv[u];
-                    P[u] = rec[ok[u] ? rbv[u] + o + (uint32_t)lane : 0u];
+                    P[u] = rcp[ok[u] ? rbv[u] + o + (uint32_t)lane : 0u];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(256) void k_grid_nn(
         // The ball, not its bounding cube: a row (cy, cz) is needed only if its (y, z) rectangle comes within r of the query,
         // and then only the cells within sqrt(r^2 - lb^2) of it along x.  (`all`: the cube covers the whole grid and the pass
         // ends the search whatever it finds -- then every row is taken in full.)
-        const double r2 = r * r, etol = 1e-6 * G.h;
+        const double r2 = r * r, etol = 1e-6 * Gp.h;
         double cull2 = __builtin_inf();                           // rows farther than this cannot hold the answer (set by hits)
         const float inv_ny = 1.0f / (float)ny;
         const bool few_rows = nrows < (1L << 22);
@@ -409,30 +418,30 @@ __global__ __launch_bounds__(256) void k_grid_nn(
             int oy, oz;
             row_split(rr, ny, inv_ny, few_rows, oy, oz);
             cy = lo[1] + oy; cz = lo[2] + oz;
-            row = ((long)cz * G.dim[1] + cy) * G.dim[0];
+            row = ((long)cz * Gp.dim[1] + cy) * Gp.dim[0];
             xl = lo[0]; xh = hi[0];
             lb2 = 0.0;
             if (!all) {
-                const double yl = G.mn[1] + (double)cy * G.h, zl = G.mn[2] + (double)cz * G.h;
-                const double dy = fmax(fmax(yl - etol - cyq, cyq - (yl + G.h + etol)), 0.0);
-                const double dz = fmax(fmax(zl - etol - czq, czq - (zl + G.h + etol)), 0.0);
+                const double yl = Gp.mn[1] + (double)cy * Gp.h, zl = Gp.mn[2] + (double)cz * Gp.h;
+                const double dy = fmax(fmax(yl - etol - cyq, cyq - (yl + Gp.h + etol)), 0.0);
+                const double dz = fmax(fmax(zl - etol - czq, czq - (zl + Gp.h + etol)), 0.0);
                 lb2 = fma(dy, dy, dz * dz);
                 const double rem = fmin(r2, cull2) - lb2;
                 if (rem >= 0.0) {
                     // half-width along x, rounded up (float sqrt + margin; the cell tolerance covers the rest)
                     const double hw = (rem < 1e-30 ? 1e-15 : (double)(sqrtf((float)rem) * 1.000001f)) + etol;
-                    const double fl = floor((cxq - hw - G.mn[0]) * G.inv_h - 1e-6);
-                    const double fh = floor((cxq + hw - G.mn[0]) * G.inv_h + 1e-6);
-                    const int tl = fl < 0.0 ? 0 : (fl > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fl);
-                    const int th = fh < 0.0 ? 0 : (fh > (double)(G.dim[0] - 1) ? G.dim[0] - 1 : (int)fh);
+                    const double fl = floor((cxq - hw - Gp.mn[0]) * Gp.inv_h - 1e-6);
+                    const double fh = floor((cxq + hw - Gp.mn[0]) * Gp.inv_h + 1e-6);
+                    const int tl = fl < 0.0 ? 0 : (fl > (double)(Gp.dim[0] - 1) ? Gp.dim[0] - 1 : (int)fl);
+                    const int th = fh < 0.0 ? 0 : (fh > (double)(Gp.dim[0] - 1) ? Gp.dim[0] - 1 : (int)fh);
                     xl = tl > xl ? tl : xl; xh = th < xh ? th : xh;
                 } else {
                     xh = xl - 1;                                  // outside the ball
                 }
             }
             if (xh >= xl && lb2 <= cull2) {
-                b = cell_start[row + xl];
-                len = cell_start[row + xh + 1] - b;
+                b = csp[row + xl];
+                len = csp[row + xh + 1] - b;
             }
         };
         for (long rb = 0; rb < nrows; rb += 64) {
@@ -441,10 +450,8 @@ __global__ __launch_bounds__(256) void k_grid_nn(
             long row = 0; int cy = 0, cz = 0, xl = 0, xh = -1;
             if (rb + lane < nrows) {
                 row_range(rb + lane, b, len, lb2, row, cy, cz, xl, xh);
-                // (a later batch of a far search: an earlier batch's hit already bounds the answer; eager: the pass's radius does --
-                // a point beyond it neither ends the search nor is the answer of a pass that ends it by other means)
-                if (cell_box && len > 0 && (cull2 < __builtin_inf() || (eager && !all)))
-                    box_trim_row(cell_box, G, row, cy, cz, xl, xh, cxq, cyq, czq, fmin(r2, cull2), etol, b, len);
+                // (a later batch of a far search: an earlier batch's hit already bounds the answer)
+                if (cell_box && !cp && len > 0 && cull2 < __builtin_inf()) box_trim_row(cell_box, Gp, row, cy, cz, xl, xh, cxq, cyq, czq, cull2, etol, b, len);
             }
             unsigned long long todo = __ballot(len > 0);          // rows of this batch that hold points
             if (work && len > 0) n_rows += 1;                     // (per-lane tallies, summed once at the end)
@@ -471,9 +478,9 @@ __global__ __launch_bounds__(256) void k_grid_nn(
                     if (c2 < cull2) {
                         cull2 = c2;
                         // the rows still to do: their cells within the HIT's ball, trimmed by the cells' tight boxes
-                        if (cell_box && ((todo >> lane) & 1ull)) {
+                        if (cell_box && !cp && ((todo >> lane) & 1ull)) {
                             row_range(rb + lane, b, len, lb2, row, cy, cz, xl, xh);
-                            if (len > 0) box_trim_row(cell_box, G, row, cy, cz, xl, xh, cxq, cyq, czq, cull2, etol, b, len);
+                            if (len > 0) box_trim_row(cell_box, Gp, row, cy, cz, xl, xh, cxq, cyq, czq, cull2, etol, b, len);
                         }
                     }
                     todo &= __ballot(len > 0 && lb2 <= cull2);
@@ -2138,7 +2145,7 @@ hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const 
                                        double *out3, void *state, unsigned long long *bar_total, double *partial, double *host_out,
                                        double seq, const IcpDev *st, unsigned absent, bool use_prior)
 {
-    static const long cap = [] { const char *e = std::getenv("SICP_HS_GRID"); const long v = e ? std::atol(e) : 0; return v > 0 && v <= 256 ? v : 256L; }();
+    const long cap = 256;
     // every block must be resident at once (grid barrier): never more blocks than the device can hold (a partitioned device has
     // far fewer CUs than 256)
     const int hsu = Q >= 900000 ? 16 : (Q >= 450000 ? 8 : 4);
@@ -2221,10 +2228,13 @@ void launch_scatter(hipStream_t s, const double *x, const double *y, const doubl
 void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                     const GridGeom &G, const uint32_t *cell_start, const void *rec, const Xf *H, const Xf *Hinv, double rmax,
                     double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
-                    bool four_per_wave, const unsigned long long *cell_box)
+                    bool four_per_wave, const unsigned long long *cell_box, const GridLevel *coarse)
 {
     const dim3 grid(cdiv(Q, 4)), block(256);
     Xf id = {};
+    const GridGeom G2 = coarse ? coarse->g : G;
+    const uint32_t *cs2 = coarse ? coarse->cell_start : nullptr;
+    const double4 *rec2 = coarse ? (const double4 *)coarse->rec : nullptr;
     const uint32_t *no_list = nullptr;
     unsigned *no_count = nullptr;
     if (four_per_wave) {
@@ -2237,10 +2247,10 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
     }
     if (H)
         hipLaunchKernelGGL((k_grid_nn<true, false>), grid, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, *H,
-                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{}, cell_box, no_list, no_count, no_count);
+                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{}, cell_box, G2, cs2, rec2, no_list, no_count, no_count);
     else
         hipLaunchKernelGGL((k_grid_nn<false, false>), grid, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, id,
-                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{}, cell_box, no_list, no_count, no_count);
+                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{}, cell_box, G2, cs2, rec2, no_list, no_count, no_count);
 }
 
 // the match of a chained iteration: transform taken from the loop state on the device
@@ -2248,9 +2258,12 @@ void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, c
                             const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
                             int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
                             const uint32_t *order, bool four_per_wave, int flags, const PostMatch *post, bool eight_per_wave,
-                            const unsigned long long *cell_box)
+                            const unsigned long long *cell_box, const GridLevel *coarse)
 {
     Xf id = {};
+    const GridGeom G2 = coarse ? coarse->g : G;
+    const uint32_t *cs2 = coarse ? coarse->cell_start : nullptr;
+    const double4 *rec2 = coarse ? (const double4 *)coarse->rec : nullptr;
     PostMatch pm = {};
     if (post) pm = *post;
     if (four_per_wave) {
@@ -2268,7 +2281,7 @@ void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, c
     unsigned g = cdiv(Q, 4);
     if (order) g = (g + 7u) & ~7u;
     hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, flags, pm,
-                       cell_box, (const uint32_t *)nullptr, (const unsigned *)nullptr, (unsigned *)nullptr);
+                       cell_box, G2, cs2, rec2, (const uint32_t *)nullptr, (const unsigned *)nullptr, (unsigned *)nullptr);
 }
 
 // The exact one-wave-per-query search over a LIST of queries: what the filtered many-queries kernel (sicp_gridf.hip) would not
@@ -2278,20 +2291,23 @@ void launch_grid_nn_redo(hipStream_t s, const double *qx, const double *qy, cons
                          const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, const Xf *H, const Xf *Hinv,
                          double rmax, double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out,
                          unsigned long long *work, int flags, const PostMatch *post, const unsigned long long *cell_box,
-                         const uint32_t *redo_list, const unsigned *redo_count, unsigned *redo_clear)
+                         const uint32_t *redo_list, const unsigned *redo_count, unsigned *redo_clear, const GridLevel *coarse)
 {
     Xf id = {};
+    const GridGeom G2 = coarse ? coarse->g : G;
+    const uint32_t *cs2 = coarse ? coarse->cell_start : nullptr;
+    const double4 *rec2 = coarse ? (const double4 *)coarse->rec : nullptr;
     PostMatch pm = {};
     if (post) pm = *post;
     long want = Q / 256;                                   // ~1.5 % of the queries at one per wave before the waves loop
     const unsigned g = (unsigned)(want < 8 ? 8 : (want > 1024 ? 1024 : want));
     const uint32_t *no_order = nullptr;
     if (st)
-        hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, redo_list, redo_count, redo_clear);
+        hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, G2, cs2, rec2, redo_list, redo_count, redo_clear);
     else if (H)
-        hipLaunchKernelGGL((k_grid_nn<true, false>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, *H, *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, redo_list, redo_count, redo_clear);
+        hipLaunchKernelGGL((k_grid_nn<true, false>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, *H, *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, G2, cs2, rec2, redo_list, redo_count, redo_clear);
     else
-        hipLaunchKernelGGL((k_grid_nn<false, false>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, redo_list, redo_count, redo_clear);
+        hipLaunchKernelGGL((k_grid_nn<false, false>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, G2, cs2, rec2, redo_list, redo_count, redo_clear);
 }
 
 void launch_stride_sample(hipStream_t s, const double *x, const double *y, const double *z, long n, long stride, long m, long mpad,

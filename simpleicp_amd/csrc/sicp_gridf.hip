@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
     }
     bool done = !active || defer, last = false;
     if (approx) defer = false;                // (a search for a bound answers nobody: such a query simply gets no bound)
-    const bool done_by_search = !defer;       // (false: left to the exact kernel before any search)
+    bool unplaced = defer;                    // left to the exact kernel WITHOUT an approximate winner: it gets no bound
     bool far_defer = false;
     unsigned n_cand = 0, n_rows = 0;
     for (int pass = 0; pass < 4096 && __any(!done); ++pass) {
@@ -307,6 +307,9 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
             }
         };
         bool far_query = false;                  // (FAR = false) this query needs the other flavour
+        // a ball of thousands of rows (a query far from everything, on a grid binned for a dense core): the exact kernel's business --
+        // a wave per query takes 64 rows per batch, and such clouds give it a coarse grid for exactly these passes
+        const bool huge = FAR && !done && !approx && nrows > 2048;
         if constexpr (!FAR) {
             uint32_t b = 0, len = 0;
             far_query = !done && nrows > (long)GS;
@@ -333,13 +336,14 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
             // TWO rows per lane and batch: their offsets are in flight together -- a wide ball's cost is the number of dependent
             // batches (offsets, then records, per batch), not its candidates (measured: 10 batches of 8 rows made the cold search of
             // 1 M queries 1.7 ms where its candidates account for 1.2)
-            for (long rb = 0; __any(rb < nrows); rb += 2 * GS) {
+            const long nrows_s = huge ? 0 : nrows;            // (its lanes simply have no rows: the wave's other groups go on)
+            for (long rb = 0; __any(rb < nrows_s); rb += 2 * GS) {
                 uint32_t b[2] = {0u, 0u}, len[2] = {0u, 0u};
                 double lb2[2] = {__builtin_inf(), __builtin_inf()};
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const long rr = rb + (long)u * GS + gl;
-                    if (rr < nrows) row_range(rr, b[u], len[u], lb2[u]);
+                    if (rr < nrows_s) row_range(rr, b[u], len[u], lb2[u]);
                 }
                 // bit j of the group's mask: row of lane j % GS, slot j / GS
                 unsigned todo = ((unsigned)(__ballot(len[0] > 0) >> gbase) & GMASK) | (((unsigned)(__ballot(len[1] > 0) >> gbase) & GMASK) << GS);
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
 #pragma unroll
                             for (int u = 0; u < 2; ++u) {
                                 const long rr = rb + (long)u * GS + gl;
-                                if (((todo >> (gl + u * GS)) & 1u) && rr < nrows) row_range(rr, b[u], len[u], lb2[u]);
+                                if (((todo >> (gl + u * GS)) & 1u) && rr < nrows_s) row_range(rr, b[u], len[u], lb2[u]);
                             }
                         }
                     }
@@ -422,6 +426,7 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
         const unsigned eq = (unsigned)(__ballot(found && v1 == gmin) >> gbase) & GMASK;         // (a lane that holds the smallest value)
         const uint32_t wpos = (uint32_t)__shfl((int)bpos, gbase + (eq ? __ffs((int)eq) - 1 : 0));
         if (far_query) { far_defer = true; done = true; }
+        if (huge) { defer = true; unplaced = true; done = true; }
         if (!done) {
             // exact contract distance of the winner (every lane of the group computes it: one address, one request)
             double best = __builtin_inf();
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
     // (a query left to another kernel keeps its old bound in pslot: a cloud point still, so still a bound)
     if (!FAR && state && active && gl == 0) state[slot] = far_defer ? (uint8_t)1 : (uint8_t)0;
     // (a query float32 cannot place goes to the exact kernel with no bound at all: x = inf says so)
-    if (defer && !done_by_search && gl == 1 && p2_out) p2_out[3 * (long)q] = __builtin_inf();
+    if (defer && unplaced && gl == 1 && p2_out) p2_out[3 * (long)q] = __builtin_inf();
     {
         // the exact kernel's list: one addition per WAVE (data with coincident points defers every query: a million additions to
         // one word would cost milliseconds)

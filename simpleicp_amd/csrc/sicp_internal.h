@@ -117,23 +117,24 @@ void launch_scatter(hipStream_t s, const double *x, const double *y, const doubl
                     uint32_t *cursor, void *rec);
 // rec: the cloud in cell order as packed 32-byte records (x, y, z, original row as int64 bits)
 // cell_box (nullable): the cells' tight boxes (sicp_grid_dev.h): far searches trim their rows by them
+// a second, coarse grid over the SAME points (clouds whose density varies by orders of magnitude): wide passes of the exact search run on it
+struct GridLevel { GridGeom g; const uint32_t *cell_start; const void *rec; };
 constexpr int NN_TIGHT = 1;      // prev_p2 is a bound to search in one go (the nearest point of a subsample), not an old match
 constexpr int NN_APPROX = 2;     // the first hit is good enough: the caller wants a cloud point NEAR the query (a bound), not the nearest
-constexpr int NN_EAGER_BOX = 4;  // trim every non-empty row by its cells' tight boxes at the PASS's radius, not only behind a first hit
 void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                     const GridGeom &G, const uint32_t *cell_start, const void *rec, const Xf *H, const Xf *Hinv, double rmax,
                     double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
-                    bool four_per_wave, const unsigned long long *cell_box = nullptr);
+                    bool four_per_wave, const unsigned long long *cell_box = nullptr, const GridLevel *coarse = nullptr);
 void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                             const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, double rmax,
                             int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out, unsigned long long *work,
                             const uint32_t *order, bool four_per_wave, int flags = 0, const PostMatch *post = nullptr,
-                            bool eight_per_wave = false, const unsigned long long *cell_box = nullptr);
+                            bool eight_per_wave = false, const unsigned long long *cell_box = nullptr, const GridLevel *coarse = nullptr);
 void launch_grid_nn_redo(hipStream_t s, const double *qx, const double *qy, const double *qz, long Q, const double *prev_p2,
                          const GridGeom &G, const uint32_t *cell_start, const void *rec, const IcpDev *st, const Xf *H, const Xf *Hinv,
                          double rmax, double max_d2, int64_t idx_base, double *d2_out, int64_t *idx_out, double *p2_out,
                          unsigned long long *work, int flags, const PostMatch *post, const unsigned long long *cell_box,
-                         const uint32_t *redo_list, const unsigned *redo_count, unsigned *redo_clear);
+                         const uint32_t *redo_list, const unsigned *redo_count, unsigned *redo_clear, const GridLevel *coarse = nullptr);
 // sicp_gridf.hip: the grid's lazily built companions and the filtered many-queries search
 void launch_recf(hipStream_t s, const void *rec, long n, const double c0[3], void *recf);
 void launch_cell_boxes(hipStream_t s, const uint32_t *cell_start, const void *rec, long ncells, const GridGeom &G, unsigned long long *cell_box);

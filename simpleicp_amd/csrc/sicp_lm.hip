@@ -506,7 +506,7 @@ __global__ __launch_bounds__(LB) void k_lm_all(
 int lm_eval_grid(long Q)
 {
     // (one block per CU: same-address ticket atomics serialise at ~20 ns apiece across the 8 XCDs)
-    static const long cap = [] { const char *e = std::getenv("SICP_LM_GRID"); const long v = e ? std::atol(e) : 0; return v > 0 && v <= NE_MAX_GRID ? v : 256L; }();
+    const long cap = 256;
     long g = ((Q + LB - 1) / LB + LCH - 1) / LCH;     // one round of LCH chunks per block, up to the cap
     if (g < 1) g = 1;
     if (g > cap) g = cap;
