@@ -4,9 +4,9 @@ profiles/latest_pmc.json (per-kernel HBM bytes per launch, read by bench.py).
 
     python scripts/summarize_profile.py r3            # prof_r3 (default line) + every prof_r3_q<Q> (large-Q legs) + prof_r3_C<config>
 
-HBM bytes per launch = FETCH_SIZE * cal + WRITE_SIZE  (both counters are in KiB).  On gfx950 FETCH_SIZE under-reports wide
-coalesced reads by 2x (MI355X_MICROARCH.md, HBM section); `cal` is measured in the same run on k_aos_to_soa, whose read volume
-is known (24 B per point).  Kernels of a large-Q leg are keyed "<kernel>@Q<Q>".  The file is stamped with the hash of the kernel
+HBM bytes per launch = FETCH_SIZE * factor + WRITE_SIZE  (both counters are in KiB).  On gfx950 FETCH_SIZE counts 64 bytes per
+128-byte line requested: wide coalesced reads are under-reported by 2x (MI355X_MICROARCH.md, HBM section; `cal` is measured in the
+same run on k_aos_to_soa, whose read volume is known: 24 B per point), the grid searches' row gathers by 1.64x (fetch_factor below).  Kernels of a large-Q leg are keyed "<kernel>@Q<Q>".  The file is stamped with the hash of the kernel
 sources it was measured on (bench.csrc_hash): bench.py withholds `traffic` when the tree has moved on."""
 import collections
 import csv
@@ -91,7 +91,17 @@ def one(src, suffix):
     cal = 2.0
     if "k_aos_to_soa" in per and per["k_aos_to_soa"].get("FETCH_SIZE"):
         cal = n_pts * 24.0 / per["k_aos_to_soa"]["FETCH_SIZE"]
-    return {k: d.get("FETCH_SIZE", 0.0) * cal + d.get("WRITE_SIZE", 0.0) for k, d in per.items()}, cal
+    return {k: d.get("FETCH_SIZE", 0.0) * fetch_factor(k, cal) + d.get("WRITE_SIZE", 0.0) for k, d in per.items()}, cal
+
+
+# What FETCH_SIZE counts on gfx950, calibrated with scripts/ubench/gather_calib.hip (profiles/r5/README.md section 4): 64 bytes per
+# 128-byte LINE requested.  Streaming kernels request whole lines (x2, measured per run on k_aos_to_soa); the grid searches read rows of
+# 8-24 records at random positions -- 2.75 lines but 4.5 64-byte sectors per 256-byte run: x1.64; isolated gathers would be x1.
+GRID_SEARCHES = ("grid_nn", "grid_knn", "knn_sweep")
+
+
+def fetch_factor(kernel, cal):
+    return 1.64 if any(g in kernel for g in GRID_SEARCHES) else cal
 
 
 out = {}
@@ -111,8 +121,9 @@ for src in [base] + sorted(ROOT.glob(f"gpurun_out/prof_{tag}_q*")) + sorted(ROOT
     h = src / "csrc_hash.txt"
     if h.exists():
         hashes.add(h.read_text().strip())
-out["_note"] = ("HBM bytes per launch = FETCH_SIZE*cal + WRITE_SIZE (KiB counters; cal from k_aos_to_soa of the same run, "
-                f"gfx950 under-reports wide reads 2x); {'; '.join(notes)}; '<kernel>@Q<n>' = the leg with n correspondences")
+out["_note"] = ("HBM bytes per launch = FETCH_SIZE*factor + WRITE_SIZE (KiB counters; factor = cal from k_aos_to_soa of the same run for "
+                "streaming kernels -- gfx950 tallies a 128-byte line at 64 bytes --, 1.64 for the grid searches' row gathers: "
+                f"profiles/r5/README.md section 4); {'; '.join(notes)}; '<kernel>@Q<n>' = the leg with n correspondences")
 out["_csrc_hash"] = hashes.pop() if len(hashes) == 1 else None
 (ROOT / "profiles" / "latest_pmc.json").write_text(json.dumps(out, indent=1) + "\n")
 (dst / "hbm_bytes_per_launch.json").write_text(json.dumps(out, indent=1) + "\n")

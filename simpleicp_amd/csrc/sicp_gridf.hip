@@ -94,8 +94,9 @@ void launch_cell_boxes(hipStream_t s, const uint32_t *cell_start, const void *re
 // ---- the filter's margin ------------------------------------------------------------------------------------------------------------
 // v = float32 value of a candidate p for a query whose pulled-back image is q':  v = fl32(dx^2 + dy^2 + dz^2), dx = fl32(pf.x - qf.x),
 // pf = fl32(p - c0), qf = fl32(q' - c0).  Against the contract distance d2 = |fl(H p) - q|^2 of the same candidate:
-//   * per coordinate |dx - (p.x - q'.x)| <= e_c := eps_p + eps_q + 2^-24 |dx|, eps_p = 2^-24 max |p - c0| (the cloud's half extent),
-//     eps_q = 2^-24 |q' - c0| (both with the float64 subtraction's rounding thrown in: 6.0e-8 instead of 5.96e-8);
+//   * per coordinate |dx - (p.x - q'.x)| <= e_c := eps_p + eps_q + 2^-24 |dx|, eps_q = 2^-24 |q' - c0|, eps_p = 2^-24 |p - c0| <= 2^-24
+//     min(the cloud's half extent, |q' - c0| + A) for a candidate no farther than A from the query (both with the float64
+//     subtraction's rounding thrown in: 6.0e-8 instead of 5.96e-8);
 //   * |sum dx^2 - |p - q'|^2| <= e_c (2 sqrt(3) d + 3 e_c)  (Cauchy-Schwarz on sum |dx|), the three float32 roundings of the sum add
 //     at most 2^-22 d^2;
 //   * |p - q'| and the contract distance agree to `slack` (1e-12 x scale; sicp_grid.hip, the same slack the exact kernels use for the
@@ -205,15 +206,14 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
     if (r > r_lim || (tight && r_lim < __builtin_inf())) r = r_lim;
     // the query in the filter's frame; eps: what float32 loses on a coordinate of the cloud and on one of the query
     float fqx, fqy, fqz;
-    double eps;
+    double qinf;                              // largest |coordinate| of the query in the filter's frame
     bool defer;
     {
         const double rqx = cxq - F.c0[0], rqy = cyq - F.c0[1], rqz = czq - F.c0[2];
         fqx = (float)rqx; fqy = (float)rqy; fqz = (float)rqz;
-        const double qnorm1 = fabs(rqx) + fabs(rqy) + fabs(rqz);
-        eps = F.eps_p + 6.0e-8 * qnorm1;
+        qinf = fmax(fabs(rqx), fmax(fabs(rqy), fabs(rqz)));
         // a query float32 cannot place (1e15 and beyond: squares would overflow) is left to the exact kernel at once
-        defer = active && !(qnorm1 < 1.0e15);
+        defer = active && !(qinf < 1.0e15);
     }
     bool done = !active || defer, last = false;
     if (approx) defer = false;                // (a search for a bound answers nobody: such a query simply gets no bound)
@@ -237,7 +237,11 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
         // The winner only ends the search when it lies inside the pass's ball, i.e. no farther than r: the margin for radius r
         // decides whether it is alone.  (`all`: the pass is final whatever it finds -- the farthest point of the cloud is then the
         // bound: |q'| + rmax.)
-        const float T = filter_margin(all ? (fabs(cxq) + fabs(cyq) + fabs(czq)) + rmax : r, eps, slack);
+        // eps: what float32 loses on a coordinate of the query (6e-8 qinf) and on one of a candidate no farther than A from it
+        // (6e-8 (qinf + A): such a candidate's coordinates are within A of the query's) -- never more than the cloud-wide figure
+        const double A = all ? (fabs(cxq) + fabs(cyq) + fabs(czq)) + rmax : r;
+        const double eps = 6.0e-8 * qinf + fmin(F.eps_p, 6.0e-8 * (qinf + A));
+        const float T = filter_margin(A, eps, slack);
         float v1 = __builtin_inff(), v2 = __builtin_inff();     // smallest and second-smallest value this lane met in this pass
         uint32_t bpos = 0;                                       // where the smallest is (position in cell order)
         const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
