@@ -178,6 +178,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_HSEL_WINDOW")) c->hsel_window = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_TEST_BARRIER_FAULT")) c->test_barrier_fault = std::atoi(e);
     if (const char *e = std::getenv("SICP_NN_GROUP")) { const int v = std::atoi(e); if (v == 8 || v == 16) c->nn_group = v; }
+    if (const char *e = std::getenv("SICP_XCHG_KEYS_MIN_Q")) c->xkeys_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_XCHG_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) c->xchg_timeout_s = v; }
     if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
     if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : 0;

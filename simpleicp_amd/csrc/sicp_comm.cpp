@@ -163,6 +163,36 @@ int exchange_best_chained(sicp_ctx *c, const TailArgs &A, long Q, bool packed_by
     return SICP_OK;
 }
 
+// ... and for MANY queries (xkeys_min_q on, the library's own communicator): three all-reduces on 8-byte keys instead of the
+// all-gather of 40 bytes per query and rank (sicp_kernels.hip); then k_postmatch on the job-wide winners
+bool exchange_by_keys(const sicp_ctx *c, long Q)
+{
+    return c->comm && c->comm_active && c->partition == SICP_PART_CLOUD && c->xkeys_min_q > 0 && Q >= c->xkeys_min_q;
+}
+int exchange_best_keys_chained(sicp_ctx *c, const TailArgs &A, long Q)
+{
+    Timed t(c, SICP_K_XCHG);
+    CHK(c->x_send.reserve((size_t)5 * Q));
+    unsigned long long *gmin = (unsigned long long *)c->x_send.p, *gidx = gmin + Q, *xyz = gidx + Q;
+    auto reduce = [&](unsigned long long *buf, long count, ncclRedOp_t op) -> int {
+        const ncclResult_t r = rccl()->AllReduce(buf, buf, (size_t)count, ncclUint64, op, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(SICP_ERR_EXCHANGE, "ncclAllReduce (keys) failed: %s", rccl()->GetErrorString(r));
+        return SICP_OK;
+    };
+    launch_xkey_d2(c->stream, c->m_d2.p, c->m_idx.p, Q, gmin);
+    CHK(reduce(gmin, Q, ncclMin));
+    launch_xkey_idx(c->stream, c->m_d2.p, c->m_idx.p, gmin, Q, gidx);
+    CHK(reduce(gidx, Q, ncclMin));
+    launch_xkey_xyz(c->stream, c->m_idx.p, c->m_p2.p, gidx, Q, xyz);
+    CHK(reduce(xyz, 3 * Q, ncclMax));
+    launch_xkey_unpack(c->stream, gmin, gidx, xyz, Q, c->m_d2.p, c->m_idx.p, c->m_p2.p);
+    Xf unused = {};
+    launch_postmatch(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q,
+                     unused, A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
+    HIPCHK(hipGetLastError());
+    return SICP_OK;
+}
+
 // query shards (cloud replicated): rank r matched queries [r * per, (r + 1) * per); the slices are gathered in rank
 // order, which IS query order, so every rank ends up with all Q results
 long query_slice(const sicp_ctx *c, long Q, long *lo)

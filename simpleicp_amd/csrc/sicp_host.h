@@ -246,6 +246,8 @@ struct sicp_ctx {
     ncclComm_t comm = nullptr;
     bool comm_active = false;      // a communicator stays with the ctx between runs (sicp_comm_activate): building one costs ~0.1-1 s
     int comm_rank = 0, comm_world = 1;
+    long xkeys_min_q = 32768;      // SICP_XCHG_KEYS_MIN_Q: cloud shards from this many queries on exchange their winners by three all-reduces on
+                                   // 8-byte keys instead of an all-gather of 40-byte records (0: never; the library's own communicator only)
     double xchg_timeout_s = 120.0; // a record that does not arrive within this while collectives are in flight = SICP_ERR_EXCHANGE, not a hang
     DevBuf<double> lm_gsum;        // sharded 6x6 reduction on the device solver: this rank's 8x8 Gram block, summed over ranks in place
     bool resid_sharded = false;    // ... after which only this rank's slice of the residuals is current (recomputed on demand)
@@ -299,6 +301,8 @@ int all_gather_f64(sicp_ctx *c, double *send, double *recv, long count);
 int all_reduce_sum_f64(sicp_ctx *c, double *buf, long count);
 int exchange_best(sicp_ctx *c, double *d2, int64_t *idx, double *p2, long Q);
 int exchange_best_chained(sicp_ctx *c, const TailArgs &A, long Q, bool packed_by_match);
+bool exchange_by_keys(const sicp_ctx *c, long Q);
+int exchange_best_keys_chained(sicp_ctx *c, const TailArgs &A, long Q);
 long query_slice(const sicp_ctx *c, long Q, long *lo);
 int exchange_query_slices_idx(sicp_ctx *c, const TailArgs &A, long Q, bool packed_by_match);
 void plan_chunks(const sicp_ctx *c, long npad, long qblocks, size_t bytes_per_chunk_row, int *chunk_pts, int *nchunks);

@@ -385,7 +385,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 post_done = !c->collective() && !many_q;
                 // behind a cloud-shard exchange the winning lanes leave the exchange's packed record instead (no k_pack_best launch)
                 // (query shards: the slim record, the matched index alone -- no k_pack_idx launch)
-                const bool pack = c->collective() && !qshard, pack_idx = c->collective() && qshard;
+                const bool pack = c->collective() && !qshard && !exchange_by_keys(c, Q), pack_idx = c->collective() && qshard;
                 if (pack) CHK(c->x_send.reserve((size_t)5 * Q));
                 if (pack_idx) CHK(c->x_send.reserve((size_t)((Q + c->world - 1) / c->world)));
                 PostMatch pm = {c->normals.p, c->planarity.p, A.pl2, A.pl2_n, A.min_planarity, post_done ? c->dist.p : nullptr,
@@ -413,7 +413,9 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
             if (qshard) { CHK(exchange_query_slices_idx(c, A, Q, packed)); post_done = true; }      // (distances + verdicts formed by the unpack)
             else if (c->collective() && c->partition == SICP_PART_CLOUD) {
                 CHK(c->x_send.reserve((size_t)5 * Q));
-                CHK(exchange_best_chained(c, A, Q, packed)); post_done = true;                 // (... by the lexicographic minimum's kernel)
+                if (exchange_by_keys(c, Q)) CHK(exchange_best_keys_chained(c, A, Q));           // (many queries: all-reduces on 8-byte keys)
+                else CHK(exchange_best_chained(c, A, Q, packed));                              // (... by the lexicographic minimum's kernel)
+                post_done = true;
             }
             A.seq = (double)(++c->solve_seq);
             seqs[launched % REC_RING] = A.seq;

@@ -161,6 +161,12 @@ void launch_grid_knn_sweep(hipStream_t s, const double *qx, const double *qy, co
                            uint32_t *redo = nullptr /* Q + 1 words: enables the four-queries-per-wave kernel */, int group = 0 /* 0 auto, 1, 4 */);
 
 void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec);
+// the job-wide winner by all-reduces on 8-byte keys (sicp_kernels.hip, "the same winner by three all-reduces")
+void launch_xkey_d2(hipStream_t s, const double *d2, const int64_t *idx, long Q, unsigned long long *key);
+void launch_xkey_idx(hipStream_t s, const double *d2, const int64_t *idx, const unsigned long long *gmin, long Q, unsigned long long *key);
+void launch_xkey_xyz(hipStream_t s, const int64_t *idx, const double *p2, const unsigned long long *gidx, long Q, unsigned long long *xyz);
+void launch_xkey_unpack(hipStream_t s, const unsigned long long *gmin, const unsigned long long *gidx, const unsigned long long *xyz,
+                        long Q, double *d2, int64_t *idx, double *p2);
 void launch_pack_idx(hipStream_t s, const int64_t *idx, long cnt, long per, double *out);
 void launch_unpack_idx_postmatch(hipStream_t s, const double *gathered, long Q, const double *cx, const double *cy, const double *cz,
                                  int64_t idx_base, long n, const double *qx, const double *qy, const double *qz, const float *normals,

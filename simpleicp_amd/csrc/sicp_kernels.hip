@@ -1237,6 +1237,68 @@ __global__ void k_unpack_idx_postmatch(const double *__restrict__ gathered, long
 // ------------------------------------------------------------------------------------
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 
+// ---- the same winner by three all-reduces on 8-byte keys (cloud shards, many queries) ------------------------------
+// An all-gather hands every rank 40 bytes per query and RANK; a ring all-reduce moves ~2 x the vector whatever the rank count:
+//   1. min over the ranks of the squared distance's bit pattern (non-negative doubles order like their bits; ~0 = no match here);
+//   2. min over the ranks of the matched index, offered only by the ranks whose distance IS that minimum (~0 otherwise): together the
+//      lexicographic (d2, index) minimum -- indices are global and the shards disjoint, so exactly one rank owns the winner;
+//   3. max over the ranks of the winner's coordinates as BIT PATTERNS, the owner's against zeros: bit-exact (a sum would turn -0.0
+//      into +0.0).
+// 8 + 8 + 24 bytes per query, three collectives; below ~32 768 queries the single all-gather's latency wins.
+__global__ void k_xkey_d2(const double *__restrict__ d2, const int64_t *__restrict__ idx, long Q, unsigned long long *__restrict__ key)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    key[q] = idx[q] >= 0 ? (unsigned long long)__double_as_longlong(d2[q]) : ~0ull;
+}
+__global__ void k_xkey_idx(const double *__restrict__ d2, const int64_t *__restrict__ idx, const unsigned long long *__restrict__ gmin,
+                           long Q, unsigned long long *__restrict__ key)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const bool mine = idx[q] >= 0 && (unsigned long long)__double_as_longlong(d2[q]) == gmin[q];
+    key[q] = mine ? (unsigned long long)idx[q] : ~0ull;
+}
+__global__ void k_xkey_xyz(const int64_t *__restrict__ idx, const double *__restrict__ p2, const unsigned long long *__restrict__ gidx,
+                           long Q, unsigned long long *__restrict__ xyz)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    // (the index alone names the owner: a rank whose local winner has the winning index holds the winning point)
+    const bool own = idx[q] >= 0 && (unsigned long long)idx[q] == gidx[q];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) xyz[3 * q + a] = own ? (unsigned long long)__double_as_longlong(p2[3 * q + a]) : 0ull;
+}
+__global__ void k_xkey_unpack(const unsigned long long *__restrict__ gmin, const unsigned long long *__restrict__ gidx,
+                              const unsigned long long *__restrict__ xyz, long Q, double *__restrict__ d2, int64_t *__restrict__ idx,
+                              double *__restrict__ p2)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const bool any = gidx[q] != ~0ull;
+    d2[q] = any ? __longlong_as_double((long long)gmin[q]) : __builtin_inf();
+    idx[q] = any ? (int64_t)gidx[q] : (int64_t)-1;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) p2[3 * q + a] = any ? __longlong_as_double((long long)xyz[3 * q + a]) : 0.0;
+}
+void launch_xkey_d2(hipStream_t s, const double *d2, const int64_t *idx, long Q, unsigned long long *key)
+{
+    hipLaunchKernelGGL(k_xkey_d2, dim3(cdiv(Q, 256)), dim3(256), 0, s, d2, idx, Q, key);
+}
+void launch_xkey_idx(hipStream_t s, const double *d2, const int64_t *idx, const unsigned long long *gmin, long Q, unsigned long long *key)
+{
+    hipLaunchKernelGGL(k_xkey_idx, dim3(cdiv(Q, 256)), dim3(256), 0, s, d2, idx, gmin, Q, key);
+}
+void launch_xkey_xyz(hipStream_t s, const int64_t *idx, const double *p2, const unsigned long long *gidx, long Q, unsigned long long *xyz)
+{
+    hipLaunchKernelGGL(k_xkey_xyz, dim3(cdiv(Q, 256)), dim3(256), 0, s, idx, p2, gidx, Q, xyz);
+}
+void launch_xkey_unpack(hipStream_t s, const unsigned long long *gmin, const unsigned long long *gidx, const unsigned long long *xyz,
+                        long Q, double *d2, int64_t *idx, double *p2)
+{
+    hipLaunchKernelGGL(k_xkey_unpack, dim3(cdiv(Q, 256)), dim3(256), 0, s, gmin, gidx, xyz, Q, d2, idx, p2);
+}
+
 void launch_pack_best(hipStream_t s, const double *d2, const int64_t *idx, const double *p2, long Q, double *rec)
 {
     hipLaunchKernelGGL(k_pack_best, dim3(cdiv(Q, 256)), dim3(256), 0, s, d2, idx, p2, Q, rec);

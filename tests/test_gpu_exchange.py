@@ -62,6 +62,12 @@ assert ith == it0 and np.abs(Hh - H0).max() < 1e-9     # device LM vs host LM: s
 from simpleicp_amd import backend as _b
 info = _b.get_context().comm_info()
 assert info["communicator"] and info["backend"] == "none", info      # parked between runs, kept for the next one
+os.environ["SICP_XCHG_KEYS_MIN_Q"] = "1"; backend.reset_context()
+H8, X8, r8, it8 = run()                                # cloud shards' winners by three all-reduces on 8-byte keys (min d2, min index, max of the
+B8 = run("dragon_q5000")                               # owner's coordinate bits) instead of the all-gather of 40-byte records: same bits
+assert it8 == it0 and np.array_equal(H8, H0) and np.array_equal(X8, X0) and np.array_equal(r8, r0), (H8 - H0)
+assert B8[3] == B0[3] and np.array_equal(B8[0], B0[0]) and np.array_equal(B8[2], B0[2]), (B8[0] - B0[0])
+del os.environ["SICP_XCHG_KEYS_MIN_Q"]; backend.reset_context()
 os.environ["SICP_GN_SHARD"] = "1"
 H2, X2, r2, it2 = run()                                # sharded 6x6 reduction requested: the single-workgroup tail (Q <= 2048) ignores it
 assert it2 == it0 and np.array_equal(H2, H0) and np.array_equal(r2, r0), (H2 - H0)
