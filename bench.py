@@ -642,7 +642,7 @@ def compact_line(out):
     if "cpu_reference" in line:
         line["cpu_reference"]["sample"] = out["cpu_reference"]["sample"][:100]
     line["config"]["workload"] = out["config"]["workload"]
-    line["detail"] = "unabridged record: --out FILE (committed examples: profiles/r4/bench_*.json)"
+    line["detail"] = "unabridged record: --out FILE (committed examples: profiles/r5/bench_*.json)"
     return line
 
 
