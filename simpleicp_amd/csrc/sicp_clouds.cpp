@@ -132,6 +132,9 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
     CHK(c->g_ids.reserve(n));
     GridGeom G;
     long ncells = 1;
+    double pw_before = 0.0, h_before = 0.0;             // point-weighted occupancy and cell size before the last shrink
+    int shrinks = 0;
+    bool pw_settled = false;
     for (int attempt = 0;; ++attempt) {
         bool capped = false;
         for (;;) {
@@ -169,12 +172,18 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
         if (!probed && gr.avg_per_cell > 3 * target && attempt < 4 && ncells < cap / 2) { h *= std::sqrt(target / gr.avg_per_cell); continue; }
         // the points' own view: shrink until an average point shares its cell with a few times the target (occupancy ~ h^2 on a surface);
         // not below the table's limit (a binning that was capped stands), at most six rounds
-        if (c->grid_pointwise && pw > 4.0 * target && !capped && attempt < 6) {
-            const double f = std::sqrt(2.0 * target / pw);
-            h *= f < 0.3 ? 0.3 : (f > 0.8 ? 0.8 : f);
-            probed = false;                              // (the window's evidence is overruled: measure the plain occupancy too from here on)
-            gr.nonuniform = true;
-            continue;
+        if (c->grid_pointwise && !pw_settled) {
+            // (the last shrink bought next to nothing: what shares cells is COINCIDENT points, not density -- no cell size separates
+            // those, and smaller cells only make every ball span more rows: back to the size before, and that stands)
+            if (pw_before > 0.0 && pw > 0.7 * pw_before) { h = h_before; pw_settled = true; gr.nonuniform = shrinks > 1; probed = false; continue; }
+            if (pw > 4.0 * target && !capped && attempt < 6) {
+                const double f = std::sqrt(2.0 * target / pw);
+                pw_before = pw; h_before = h; ++shrinks;
+                h *= f < 0.3 ? 0.3 : (f > 0.8 ? 0.8 : f);
+                probed = false;                          // (the window's evidence is overruled: measure the plain occupancy too from here on)
+                gr.nonuniform = true;
+                continue;
+            }
         }
         gr.pointwise_occupancy = pw;
         break;

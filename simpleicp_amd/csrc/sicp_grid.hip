@@ -292,7 +292,9 @@ __global__ __launch_bounds__(256) void k_scatter_order(const uint32_t *__restric
 // contiguous in the cell order); the non-empty rows are then visited FOUR AT A TIME -- their ranges are broadcast
 // with v_readlane (uniform row index: no LDS crossbar), lane l takes point l of each row, and the four 32-byte
 // record loads are in flight together.  A pass costs two dependent memory round trips (offsets, records).
-template <bool XFORM, bool CHAINED>
+template <bool XFORM, bool CHAINED, bool EXT /* the options below the line are live: tight boxes, a coarse twin grid, a list of queries.
+    A latency-bound kernel pays for every scalar register it spills: the plain instantiation (EXT = false) compiles them all away --
+    with them in, the steady match of the headline workload took 8.3 us instead of 6.5 (172 spilled scalar registers against 38) */>
 // (parameter order: the eight pointers the first instructions need come first -- preloaded into SGPRs at wave start,
 // -amdgpu-kernarg-preload-count=16, instead of a kernarg load every dependent load would queue behind)
 __global__ __launch_bounds__(256) void k_grid_nn(
@@ -309,13 +311,16 @@ __global__ __launch_bounds__(256) void k_grid_nn(
                  NN_APPROX: the first hit is good enough (the caller wants A cloud point near the query -- a bound --, not the nearest) */,
     PostMatch post /* chained match of an ICP iteration: the winning lane also leaves the point-to-plane distance and the
                       planarity verdict (corrpts.py:139-163,195-211) -- it holds the matched point, the query and H already */,
-    const unsigned long long *__restrict__ cell_box /* nullable: the cells' tight boxes (sicp_grid_dev.h) -- far searches trim their rows */,
-    GridGeom G2, const uint32_t *__restrict__ cell_start2 /* nullable: no coarse grid */, const double4 *__restrict__ rec2,
-    const uint32_t *__restrict__ redo_list /* nullable: ONLY the queries listed here (what the filtered many-queries kernel left) */,
+    const unsigned long long *__restrict__ cell_box_arg /* nullable: the cells' tight boxes (sicp_grid_dev.h) -- far searches trim their rows */,
+    GridGeom G2, const uint32_t *__restrict__ cell_start2_arg /* nullable: no coarse grid */, const double4 *__restrict__ rec2,
+    const uint32_t *__restrict__ redo_list_arg /* nullable: ONLY the queries listed here (what the filtered many-queries kernel left) */,
     const unsigned *__restrict__ redo_count /* entries of redo_list */,
     unsigned *__restrict__ redo_clear /* nullable: the counter the NEXT search's kernels add to -- cleared here (nobody touches it
                                          before that search is launched: stream order) */)
 {
+    const unsigned long long *const cell_box = EXT ? cell_box_arg : nullptr;
+    const uint32_t *const cell_start2 = EXT ? cell_start2_arg : nullptr;
+    const uint32_t *const redo_list = EXT ? redo_list_arg : nullptr;
     const int lane = threadIdx.x & 63;
     const int tight = flags & NN_TIGHT;
     const bool approx = (flags & NN_APPROX) != 0;
@@ -2235,6 +2240,7 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
     const GridGeom G2 = coarse ? coarse->g : G;
     const uint32_t *cs2 = coarse ? coarse->cell_start : nullptr;
     const double4 *rec2 = coarse ? (const double4 *)coarse->rec : nullptr;
+    const bool ext = cell_box != nullptr || coarse != nullptr;
     const uint32_t *no_list = nullptr;
     unsigned *no_count = nullptr;
     if (four_per_wave) {
@@ -2246,10 +2252,14 @@ void launch_grid_nn(hipStream_t s, const double *qx, const double *qy, const dou
         return;
     }
     if (H)
-        hipLaunchKernelGGL((k_grid_nn<true, false>), grid, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, *H,
+        if (ext) hipLaunchKernelGGL((k_grid_nn<true, false, true>), grid, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, *H,
+                           *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{}, cell_box, G2, cs2, rec2, no_list, no_count, no_count);
+        else hipLaunchKernelGGL((k_grid_nn<true, false, false>), grid, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, *H,
                            *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{}, cell_box, G2, cs2, rec2, no_list, no_count, no_count);
     else
-        hipLaunchKernelGGL((k_grid_nn<false, false>), grid, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, id,
+        if (ext) hipLaunchKernelGGL((k_grid_nn<false, false, true>), grid, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, id,
+                           id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{}, cell_box, G2, cs2, rec2, no_list, no_count, no_count);
+        else hipLaunchKernelGGL((k_grid_nn<false, false, false>), grid, block, 0, s, (const IcpDev *)nullptr, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, (const uint32_t *)nullptr, Q, G, id,
                            id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, 0, PostMatch{}, cell_box, G2, cs2, rec2, no_list, no_count, no_count);
 }
 
@@ -2280,8 +2290,13 @@ void launch_grid_nn_chained(hipStream_t s, const double *qx, const double *qy, c
     }
     unsigned g = cdiv(Q, 4);
     if (order) g = (g + 7u) & ~7u;
-    hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, flags, pm,
-                       cell_box, G2, cs2, rec2, (const uint32_t *)nullptr, (const unsigned *)nullptr, (unsigned *)nullptr);
+    // (the plain instantiation unless an option is live: see the kernel's EXT parameter)
+    if (cell_box != nullptr || coarse != nullptr)
+        hipLaunchKernelGGL((k_grid_nn<true, true, true>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, flags, pm,
+                           cell_box, G2, cs2, rec2, (const uint32_t *)nullptr, (const unsigned *)nullptr, (unsigned *)nullptr);
+    else
+        hipLaunchKernelGGL((k_grid_nn<true, true, false>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, order, Q, G, id, id, rmax, (double)__builtin_inf(), idx_base, d2_out, idx_out, p2_out, work, flags, pm,
+                           cell_box, G2, cs2, rec2, (const uint32_t *)nullptr, (const unsigned *)nullptr, (unsigned *)nullptr);
 }
 
 // The exact one-wave-per-query search over a LIST of queries: what the filtered many-queries kernel (sicp_gridf.hip) would not
@@ -2303,11 +2318,11 @@ void launch_grid_nn_redo(hipStream_t s, const double *qx, const double *qy, cons
     const unsigned g = (unsigned)(want < 8 ? 8 : (want > 1024 ? 1024 : want));
     const uint32_t *no_order = nullptr;
     if (st)
-        hipLaunchKernelGGL((k_grid_nn<true, true>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, G2, cs2, rec2, redo_list, redo_count, redo_clear);
+        hipLaunchKernelGGL((k_grid_nn<true, true, true>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, G2, cs2, rec2, redo_list, redo_count, redo_clear);
     else if (H)
-        hipLaunchKernelGGL((k_grid_nn<true, false>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, *H, *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, G2, cs2, rec2, redo_list, redo_count, redo_clear);
+        hipLaunchKernelGGL((k_grid_nn<true, false, true>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, *H, *Hinv, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, G2, cs2, rec2, redo_list, redo_count, redo_clear);
     else
-        hipLaunchKernelGGL((k_grid_nn<false, false>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, G2, cs2, rec2, redo_list, redo_count, redo_clear);
+        hipLaunchKernelGGL((k_grid_nn<false, false, true>), dim3(g), dim3(256), 0, s, st, qx, qy, qz, prev_p2, cell_start, (const double4 *)rec, no_order, Q, G, id, id, rmax, max_d2, idx_base, d2_out, idx_out, p2_out, work, flags, pm, cell_box, G2, cs2, rec2, redo_list, redo_count, redo_clear);
 }
 
 void launch_stride_sample(hipStream_t s, const double *x, const double *y, const double *z, long n, long stride, long m, long mpad,

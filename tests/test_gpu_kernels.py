@@ -864,7 +864,7 @@ def test_windowed_rejection_equals_the_general_form(Q, kind):
     # the oracle on the host-driven iterations (every one of them a launch that may use the window: the run before left its priors;
     # the chained run carries sin / cos forward on the device, so only the host-driven loop meets the oracle's H bit for bit)
     x = z.copy()
-    for it in range(3):
+    for it in range(3 if Q <= 40_000 else 1):            # (the oracle's brute-force match: 4.5e10 pairs per iteration at 150 000 queries)
         o = orc.icp_iteration(Xm, P[sel], nv, pl, x, x, 1.0, z, z, 0.3)
         assert (a[3][it][1], a[3][it][2], a[3][it][3]) == (o["median"], o["mad"], int(o["keep"].sum()))
         x = np.array(a[3][it][4])
