@@ -69,6 +69,9 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
     // pay 48): six cells per point, at most 2^30 (4 GiB of offsets + as much again of build scratch, on a 288 GB device).
     long cap = 1L << 27;
     if (6 * n > cap) cap = std::min<long>(6 * n, 1L << 30);
+    // (a cloud whose POINTS crowd a few cells -- see the point-weighted occupancy below -- may take a larger table than its size alone
+    // earns: c->grid_cap_nonuniform_log2)
+    long cap_nu = std::max(cap, 1L << c->grid_cap_nonuniform_log2);
     {
         // ... and never more than the device can spare: a cell costs 12 bytes of table + build scratch (+ 8 of tight boxes when a far
         // search asks for them) -- a quarter of what is free, at least 2^22 cells (ranks sharing a device, smaller devices)
@@ -76,6 +79,7 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const long fit = (long)(free_b / 4 / 20);
             cap = std::max<long>(1L << 22, std::min(cap, fit));
+            cap_nu = std::max(cap, std::min(cap_nu, fit));
         }
     }
     double h = deff ? std::pow(vol * target / (double)n, 1.0 / deff) : 1.0;
@@ -175,8 +179,17 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
         if (c->grid_pointwise && !pw_settled) {
             // (the last shrink bought next to nothing: what shares cells is COINCIDENT points, not density -- no cell size separates
             // those, and smaller cells only make every ball span more rows: back to the size before, and that stands)
+            // (the table's limit stopped the shrink while an average point still shares its cell with many: such a cloud gets the larger table)
+            if (capped && cap < cap_nu && pw > 4.0 * target && attempt < 8) {
+                cap = cap_nu;
+                const double f = std::sqrt(2.0 * target / pw);
+                pw_before = pw; h_before = h; ++shrinks;
+                h *= f < 0.3 ? 0.3 : (f > 0.8 ? 0.8 : f);
+                probed = false; gr.nonuniform = true;
+                continue;
+            }
             if (pw_before > 0.0 && pw > 0.7 * pw_before) { h = h_before; pw_settled = true; gr.nonuniform = shrinks > 1; probed = false; continue; }
-            if (pw > 4.0 * target && !capped && attempt < 6) {
+            if (pw > 4.0 * target && !capped && attempt < 8) {
                 const double f = std::sqrt(2.0 * target / pw);
                 pw_before = pw; h_before = h; ++shrinks;
                 h *= f < 0.3 ? 0.3 : (f > 0.8 ? 0.8 : f);
@@ -498,14 +511,15 @@ SICP_EXPORT int sicp_cloud_download_both(sicp_ctx *c, int slot, double *xyz_out,
     if (!c->dl_ev[0]) { HIPCHK(hipEventCreateWithFlags(&c->dl_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->dl_ev[1], hipEventDisableTiming)); }
     const long nchunks = (n + CH - 1) / CH;
     // host threads that fan a chunk out: as many as this process may actually run on (cgroup / affinity limits, not the machine's
-    // core count), at most 8, and none for clouds that are one chunk's worth of microseconds
+    // core count), at most c->dl_threads (8), and none for clouds that are one chunk's worth of microseconds
     unsigned T = 1;
     {
         cpu_set_t set;
         CPU_ZERO(&set);
         if (sched_getaffinity(0, sizeof set, &set) == 0) T = (unsigned)CPU_COUNT(&set);
         else T = std::thread::hardware_concurrency();
-        T = T < 2 ? 1 : (T > 8 ? 8 : T);
+        const unsigned most = (unsigned)c->dl_threads;
+        T = T < 2 ? 1 : (T > most ? most : T);
         if (n < (1L << 16)) T = 1;
     }
     // waiting: a few polite spins, then sleep -- a spinner must not starve the thread it waits for in a one-CPU container
