@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Everything the round's records are made of, in one GPU call:  scripts/final_measure.sh <tag>  -> gpurun_out/final_<tag>/ (+ prof_<tag>*/)
-# Every step under its own timeout; partial results survive a cut-off call.  STEPS selects (default: all).
+# Order: counters first (the bench lines quote them), measurements, the tests last.  Every step under its own timeout; partial results survive a cut-off call.  STEPS selects (default: all).
 set -u
 TAG=${1:-r5}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -11,9 +11,11 @@ cd "$REPO"
 T0=$(date +%s)
 stamp() { echo "[$(( $(date +%s) - T0 )) s] $*" >> "$OUT/steps.log"; }
 has() { case " $STEPS " in *" $1 "*) return 0;; *) return 1;; esac; }
-if has tests; then
-  timeout 1500 python -m pytest tests/ -q -m gpu -p no:cacheprovider > "$OUT/pytest_gpu.txt" 2>&1; stamp "pytest -m gpu rc=$?"
-  tail -3 "$OUT/pytest_gpu.txt" >> "$OUT/steps.log"
+if has profiles; then
+  PASSES="trace fetch write sq1" scripts/gpu_profile.sh $TAG > "$OUT/gpu_profile.log" 2>&1; stamp "profile default"
+  PASSES="trace fetch write sq1" scripts/gpu_profile.sh ${TAG}_q1000000 --correspondences 1000000 >> "$OUT/gpu_profile.log" 2>&1; stamp "profile Q=1M"
+  # the bench lines below carry the counters' traffic only when profiles/latest_pmc.json was made from THIS tree's kernels
+  python scripts/summarize_profile.py $TAG > "$OUT/summarize_profile.txt" 2>&1; stamp "summarize rc=$?"
 fi
 if has bench; then
   timeout 600 python bench.py --out "$OUT/bench_C4.json" > /dev/null 2> "$OUT/bench_C4.err"; stamp "bench C4 rc=$?"
@@ -37,11 +39,11 @@ if has traces; then
   scripts/kernel_timeline.sh c4_$TAG scripts/trace_c4.py > "$OUT/kernel_timeline_c4.txt" 2>&1
   python scripts/iter_timeline.py gpurun_out/kt_c4_$TAG > "$OUT/iter_timeline.txt" 2>&1; stamp "iter timeline"
 fi
-if has profiles; then
-  PASSES="trace fetch write sq1" scripts/gpu_profile.sh $TAG > "$OUT/gpu_profile.log" 2>&1; stamp "profile default"
-  PASSES="trace fetch write sq1" scripts/gpu_profile.sh ${TAG}_q1000000 --correspondences 1000000 >> "$OUT/gpu_profile.log" 2>&1; stamp "profile Q=1M"
-fi
 if has c5; then
   timeout 1200 python bench.py --config C5size --repeats 5 --no-cpu-baseline --no-end-to-end --no-bruteforce-leg --throughput-q 0 --out "$OUT/bench_C5size.json" > /dev/null 2> "$OUT/bench_C5size.err"; stamp "C5size rc=$?"
+fi
+if has tests; then
+  timeout ${TESTS_TIMEOUT:-1500} python -m pytest ${TESTS_ARGS:-tests/} -q -m gpu -p no:cacheprovider --durations=25 > "$OUT/pytest_gpu.txt" 2>&1; stamp "pytest -m gpu rc=$?"
+  tail -3 "$OUT/pytest_gpu.txt" >> "$OUT/steps.log"
 fi
 cat "$OUT/steps.log"; ls "$OUT"

@@ -511,7 +511,7 @@ SICP_EXPORT int sicp_cloud_download_both(sicp_ctx *c, int slot, double *xyz_out,
     if (!c->dl_ev[0]) { HIPCHK(hipEventCreateWithFlags(&c->dl_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->dl_ev[1], hipEventDisableTiming)); }
     const long nchunks = (n + CH - 1) / CH;
     // host threads that fan a chunk out: as many as this process may actually run on (cgroup / affinity limits, not the machine's
-    // core count), at most c->dl_threads (8), and none for clouds that are one chunk's worth of microseconds
+    // core count), at most c->dl_threads (16), and none for clouds that are one chunk's worth of microseconds
     unsigned T = 1;
     {
         cpu_set_t set;

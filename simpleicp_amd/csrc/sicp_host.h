@@ -178,7 +178,7 @@ struct sicp_ctx {
                                    // being latency-bound at ~4 000 queries; its fused distance epilogue is worth a launch, ~4 us)
     int nn16_filter = 2;           // SICP_NN16 = exact (0: k_grid_nn16) | far (1: the filtered search, one flavour) | near (2, default: the lean
                                    // flavour first, the full one for what it leaves)
-    int dl_threads = 8;                   // SICP_DL_THREADS=1..64: host threads that fan a downloaded chunk out into the caller's arrays
+    int dl_threads = 16;                  // SICP_DL_THREADS=1..64: host threads that fan a downloaded chunk out into the caller's arrays (run() at C4: 32 / 25 / 25 ms with 8 / 16 / 32)
     int grid_cap_nonuniform_log2 = 27;    // SICP_GRID_CAP_NONUNIFORM=22..30: log2 of the cell table's limit for clouds whose points crowd a few cells
     bool grid_pointwise = true;    // SICP_GRID_POINTWISE=0: the cell size follows the average over occupied cells only (A/B)
     long nn16f_min_q = 196608;     // SICP_NN16F_MIN_Q: from this many queries per launch on the many-queries search goes through the float32 filter

@@ -353,7 +353,9 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                     // query: the full flavour takes all slots.  Later the lean flavour goes first and marks what it cannot do.
                     // (the estimate still moves by a cell or so per iteration: most searches are wide -- the lean flavour would only find
                     // that out and hand them on; judged from the last iterations the host has seen: the chain runs ahead of it)
-                    const bool all_far = coarse || c->nn16_filter == 1 || !(last_move <= c->far_move * cl.grid.g.h);
+                    // (a nonuniform cloud -- cells of hundreds of points next to empty ones -- hands most of its queries on as well: measured on the
+                    // terrestrial stand-in at 1 M queries, 3.00 ms with the lean flavour first, 2.54 ms without)
+                    const bool all_far = coarse || c->nn16_filter == 1 || cl.grid.nonuniform || !(last_move <= c->far_move * cl.grid.g.h);
                     if (!all_far)
                         launch_grid_nn16f(c->stream, lanes, false, c->icp_dev.p, c->q_slot.p, c->p_slot.p, cnt, cl.grid.g, cl.grid.c0,
                                           cl.grid.eps_p, cl.grid.cell_start.p, cl.grid.recf.p, cl.grid.rec.p, ordered, nullptr, nullptr,

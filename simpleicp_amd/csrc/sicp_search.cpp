@@ -111,7 +111,7 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
                 unsigned long long *wk = c->count_work ? c->match_work.p : nullptr;
                 c->last_match_kernel = 6;
                 Timed t(c, SICP_K_KNN1);
-                const bool all_far = c->nn16_filter == 1;
+                const bool all_far = c->nn16_filter == 1 || gr.nonuniform;
                 if (!all_far)
                     launch_grid_nn16f(c->stream, 16, false, nullptr, c->kq_slot.p, c->kp_slot.p, Q, gr.g, gr.c0, gr.eps_p, gr.cell_start.p,
                                       gr.recf.p, gr.rec.p, false, H, H ? &Hinv : nullptr, cl.rmax, max_d2, cl.idx_base, d2_out,
