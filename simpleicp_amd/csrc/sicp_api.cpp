@@ -173,7 +173,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_GRID_POINTWISE")) c->grid_pointwise = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_DL_THREADS")) { const int d = std::atoi(e); if (d >= 1 && d <= 64) c->dl_threads = d; }
     if (const char *e = std::getenv("SICP_GRID_CAP_NONUNIFORM")) { const int d = std::atoi(e); if (d >= 22 && d <= 30) c->grid_cap_nonuniform_log2 = d; }
-    if (const char *e = std::getenv("SICP_NN16F_MIN_Q")) c->nn16f_min_q = std::atol(e);
+    if (const char *e = std::getenv("SICP_NN16F_MIN_Q")) { c->nn16f_min_q = std::atol(e); c->nn16f_min_q_forced = true; }
     if (const char *e = std::getenv("SICP_FAR_MOVE")) { const double t = std::atof(e); if (t >= 0) c->far_move = t; }
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
     if (const char *e = std::getenv("SICP_LM")) c->lm_one_launch = std::strcmp(e, "launches") != 0;

@@ -294,7 +294,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 // their place in the full arrays)
                 long lo = 0, cnt = Q;
                 if (qshard) cnt = query_slice(c, Q, &lo);
-                c->last_match_kernel = (cnt >= c->nn16_min_q && (!cl.grid.nonuniform || cnt >= c->nn16f_min_q)) ? 5 : 2;
+                c->last_match_kernel = (cnt >= c->nn16_min_q && (!cl.grid.nonuniform || cnt >= filter_min_q(c, true))) ? 5 : 2;
                 const bool ordered = c->order_min_q > 0 && cnt >= c->order_min_q;
                 if (ordered) CHK(query_order_build(c, lo, cnt, cl.grid.g.h));
                 // A search without a useful bound (the run's first iterations: no previous match, or one made under an estimate
@@ -313,11 +313,11 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 GridLevel coarse_lv; const GridLevel *coarse_grid = nullptr;
                 CHK(grid_coarse_level(c, SICP_MOV, &coarse_lv, &coarse_grid));
                 // (a nonuniform cloud: one wave per query -- 64 rows per batch, the coarse grid for wide passes -- until the filtered search takes over)
-                const bool many_q = cnt >= c->nn16_min_q && (!cl.grid.nonuniform || cnt >= c->nn16f_min_q);
+                const bool many_q = cnt >= c->nn16_min_q && (!cl.grid.nonuniform || cnt >= filter_min_q(c, true));
                 // far searches (a run's first iterations) trim their rows by the tight boxes of the cells; large query sets are
                 // searched through the float32 filter (sicp_gridf.hip) when float32 can hold the cloud
                 const bool boxes = c->use_boxes && cnt > 0;
-                bool filt = many_q && c->nn16_filter != 0 && cnt > 0 && cnt >= c->nn16f_min_q;
+                bool filt = many_q && c->nn16_filter != 0 && cnt > 0 && cnt >= filter_min_q(c, cl.grid.nonuniform);
                 if (filt || boxes) CHK(grid_companions(c, cl, cl.grid, cl.n, filt, boxes));
                 if (filt && coarse) CHK(grid_companions(c, cl, cl.sub_grid, cl.sub_n, true, false));
                 if (filt && (!cl.grid.filter_ok || (coarse && !cl.sub_grid.filter_ok))) filt = false;

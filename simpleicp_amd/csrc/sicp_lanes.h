@@ -102,7 +102,7 @@ struct GridBar {
     Line top;                      // groups that are complete, 0 between barriers
     unsigned long long gen;        // number of the last barrier every block reached
     unsigned long long pad1[15];
-    unsigned error;                // a wait timed out (sticky)
+    unsigned error;                // a wait timed out: stays set for the rest of the buffer's life; the host reports it and starts over from a zeroed buffer (reset_barrier_state)
     unsigned pad2[31];
 };
 // all threads call it; every cross-block datum published before must have been written with agent-scope atomics

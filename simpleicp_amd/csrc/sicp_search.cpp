@@ -95,7 +95,7 @@ int knn1_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, co
         c->last_match_kernel = four ? 5 : 2;
         // large query sets: through the float32 filter (sicp_gridf.hip), what it leaves (ties within its margin) through the exact
         // kernel -- the same answers
-        if (Q >= c->nn16_min_q && Q >= c->nn16f_min_q && c->nn16_filter != 0 && Q < (1L << 31)) {
+        if (Q >= c->nn16_min_q && Q >= filter_min_q(c, gr.nonuniform) && c->nn16_filter != 0 && Q < (1L << 31)) {
             CHK(grid_companions(c, cl, gr, cl.n, true, c->use_boxes));
             if (gr.filter_ok) {
                 CHK(c->kq_slot.reserve((size_t)4 * Q)); CHK(c->kp_slot.reserve((size_t)4 * Q));
