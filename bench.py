@@ -459,6 +459,11 @@ def run(args):
     pmc, pmc_src = load_pmc()
 
     def roof(kernel, ms, bytes_alg, note, extra=None):
+        if bytes_alg is None:                    # nothing to price this launch on in this run (no tallies, no counters): say so
+            d = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                 "traffic_source": None, "kernel": kernel, "avg_ms": ms, "bytes_alg_per_launch": None, "note": note}
+            d.update(extra or {})
+            return d
         ach = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # counters are keyed by kernel for the default line and "<kernel>@<config>" for the other configurations' own passes
         traffic = pmc.get(f"{kernel}@{args.config}") if args.config != "C4" else pmc.get(kernel)
@@ -480,9 +485,12 @@ def run(args):
             bytes_match = match_bytes(match_kernel, per, nq)
             extra = {"candidates_per_query": per["candidates"] / nq, "grid_rows_per_query": per["rows"] / nq}
         else:
-            bytes_match = pmc.get(match_kernel) or bytes_bruteforce
-            extra = {"bytes_alg_source": "PMC traffic (no in-kernel work counters in this build)"}
-        extra["pruning_ratio"] = bytes_bruteforce / max(1.0, bytes_match)
+            # --no-work-pass (the kernel-trace run of scripts/gpu_profile.sh): the counters' bytes if this tree has them -- never the
+            # brute-force figure, which a pruned search does not read (it would price the launch above the HBM peak)
+            bytes_match = pmc.get(match_kernel)
+            extra = {"bytes_alg_source": "PMC traffic (no in-kernel tallies in this run)" if bytes_match else
+                     "none: no in-kernel tallies in this run (--no-work-pass) and no counter summary of this tree"}
+        extra["pruning_ratio"] = bytes_bruteforce / max(1.0, bytes_match) if bytes_match else None
         extra["bytes_bruteforce_per_launch"] = int(bytes_bruteforce)
         r_match = roof(match_kernel, match_ms, bytes_match,
                        ("exact 1-NN on a static uniform grid, one wave per query: reads only the cells the bound ball touches "
@@ -745,6 +753,11 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
         pmc_src = "no counter pass for this leg on these clouds"
 
     def roof(kernel, ms, bytes_alg, note, extra=None):
+        if bytes_alg is None:                    # nothing to price this launch on in this run (no tallies, no counters): say so
+            d = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                 "traffic_source": None, "kernel": kernel, "avg_ms": ms, "bytes_alg_per_launch": None, "note": note}
+            d.update(extra or {})
+            return d
         ach = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
              "traffic": pmc.get(kernel + tag), "traffic_source": pmc_src if (pmc.get(kernel + tag) is not None or not pmc) else None,
@@ -763,10 +776,13 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
                             "timed_region": "K steps from the cold state (icp_setup just called), min_change=0, events off"},
            "parallelism": f"query shards x{world}, movable cloud replicated" if exchange else "1 GPU",
            "roofline": roof(kern, avg["match"], bytes_match,
-                            "exact 1-NN on the static grid, four or eight cell-ordered queries per wave, candidates through a float32 filter in the "
-                            "cloud's frame (16-B records), the winner re-evaluated exactly, ties left to the exact kernel; bytes = the candidates and "
-                            "grid rows the search itself TALLIED + 168 B per query (they include what neighbouring queries share in L2: "
-                            "`frac_on_pmc_traffic` prices the same time on the HBM counters' bytes); issue- and latency-bound", {"candidates_per_query": per["candidates"] / max(1, nq_local),
+                            ("exact 1-NN on the static grid, four or eight cell-ordered queries per wave, candidates through a float32 filter in the "
+                             "cloud's frame (16-B records), the winner re-evaluated exactly, ties left to the exact kernel; bytes = the candidates and "
+                             "grid rows the search itself TALLIED + 168 B per query" if kern == "k_grid_nn16f" else
+                             "exact 1-NN on the static grid, one (k_grid_nn) or four (k_grid_nn16) cell-ordered queries per wave, exact arithmetic on "
+                             "every candidate (32-B records); bytes = the candidates and grid rows the search itself TALLIED + 96 B per query") +
+                            " (they include what neighbouring queries share in L2: `frac_on_pmc_traffic` prices the same time on the HBM "
+                            "counters' bytes); issue- and latency-bound", {"candidates_per_query": per["candidates"] / max(1, nq_local),
                                            "grid_rows_per_query": per["rows"] / max(1, nq_local),
                                            "left_to_exact_kernel_per_launch": per.get("deferred"),
                                            "pruning_ratio": (Nm * 24 + nq_local * 40) / max(1.0, bytes_match)}),

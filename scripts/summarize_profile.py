@@ -59,7 +59,20 @@ def one(src, suffix):
     if stats:
         shutil.copy(stats[0], dst / f"kernel_stats{sfx}.csv")
     if (src / "bench_trace.json").exists():
-        shutil.copy(src / "bench_trace.json", dst / f"bench_under_rocprof{sfx}.json")
+        # the line bench.py printed under the kernel trace (its timings are the trace's, slower than the bench's own).  Lines written
+        # before bench.py stopped doing so priced an untallied pruned search on the brute-force bytes (frac > 1): that field is voided
+        text = (src / "bench_trace.json").read_text()
+        try:
+            rec = json.loads(text.strip().splitlines()[-1])
+            for key in ("roofline", "roofline_match"):
+                r = rec.get(key) or {}
+                if r.get("kernel", "").startswith("k_grid_nn") and r.get("bytes_alg_per_launch") == r.get("bytes_bruteforce_per_launch"):
+                    r.update(achieved=None, frac=None, bytes_alg_per_launch=None, pruning_ratio=None,
+                             bytes_alg_source="none: no in-kernel tallies in the traced run (--no-work-pass) and no counter summary then")
+            text = json.dumps(rec) + "\n"
+        except Exception:  # noqa: BLE001
+            pass
+        (dst / f"bench_under_rocprof{sfx}.json").write_text(text)
     per = collections.defaultdict(dict)
     for tagc, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         agg = {k: v for (k, c), v in counters(src, tagc).items() if c == counter}
