@@ -339,7 +339,9 @@ int cloud_stats(sicp_ctx *c, int slot)
     }
     cl.rmax = std::sqrt(nn) * (1.0 + 1e-12);
     for (int a = 0; a < 3; ++a) { cl.bb_lo[a] = key_to_double(hk[a]); cl.bb_hi[a] = key_to_double(hk[3 + a]); }
-    if (slot == SICP_MOV) c->have_prev_match = false;
+    // (a new movable cloud: earlier matches are not its points -- neither the by-query ones nor those the filtered search keeps by slot,
+    // which an operator-route match in between would not rebuild)
+    if (slot == SICP_MOV) { c->have_prev_match = false; c->slot_cnt = -1; }
     return SICP_OK;
 }
 int upload_end(sicp_ctx *c, int slot) { return cloud_stats(c, slot); }

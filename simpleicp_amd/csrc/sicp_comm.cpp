@@ -59,6 +59,7 @@ void abandon_exchange(sicp_ctx *c)
         c->pending.clear();                                   // their events sit on the abandoned stream
     }
     c->have_iter = false; c->have_corr = false; c->have_prev_match = false;
+    c->slot_cnt = -1;
     c->hsel_dirty = true;                                     // whatever the interrupted launches left in the selection state
 }
 

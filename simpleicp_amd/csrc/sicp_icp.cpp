@@ -188,6 +188,7 @@ SICP_EXPORT int sicp_icp_setup(sicp_ctx *c, const int64_t *sel_idx, int64_t Q, c
     c->have_iter = false;
     c->have_corr = false;
     c->have_prev_match = false;
+    c->slot_cnt = -1;                  // (the filtered search's slot-ordered copies of the queries: other queries now)
     c->q_order_lo = -1; c->q_order_cnt = 0;
     c->hsel_run_launches = 0;
     return sync(c);
@@ -895,6 +896,7 @@ SICP_EXPORT int sicp_estimate_parameters(sicp_ctx *c, const sicp_iter_params *P,
     if (pc2_xyz) {
         HIPCHK(hipMemcpyAsync(c->m_p2.p, pc2_xyz, (size_t)3 * Q * sizeof(double), hipMemcpyDefault, c->stream));
         c->have_prev_match = false;                           // no longer points of the searched cloud: not a search bound
+        c->slot_cnt = -1;                                     // (... nor are the bounds kept by slot: the operator route may set have_prev_match again)
     }
     double *h_st;
     CHK(corr_alive_stats(c, nullptr, &h_st));

@@ -670,6 +670,50 @@ def test_many_queries_search_flavours_agree(quantised):
         assert np.array_equal(idx, nn[:, 0])
 
 
+def test_filter_slots_follow_the_setup_through_the_operator_route():
+    """The filtered search keeps the queries (and each one's last match) in slot order between iterations.  A NEW setup with as many
+    queries, then a match through the operator route (sicp_corr_match marks "there is an earlier match"), then a fused iteration: the slots
+    must be the new setup's, not the earlier one's; likewise a new movable cloud between two iterations."""
+    import os
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(7)
+    n, Q = 60_000, 9_000
+    P = _surface(n, 3)
+    Xm = orc.transform(np.linalg.inv(orc.params_to_H(np.array([0.002, -0.001, 0.003, 0.05, -0.03, 0.02]))), P + rng.normal(0, 0.01, P.shape))
+    sel_a = np.sort(rng.choice(n, Q, replace=False))
+    sel_b = np.sort(rng.choice(n, Q, replace=False))
+    z = np.zeros(6)
+    env = {"SICP_NN16F_MIN_Q": "1", "SICP_NN16_MIN_Q": "1"}
+    os.environ.update(env)
+    try:
+        c = _lib.Context(0)
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    with c:
+        c.upload(_lib.FIX, P); c.upload(_lib.MOV, Xm)
+        nva, pla = c.estimate_normals(_lib.FIX, sel_a, 10)
+        nvb, plb = c.estimate_normals(_lib.FIX, sel_b, 10)
+        c.icp_setup(sel_a, nva, pla)
+        c.icp_iterate(z, z, z, 0.3, 1.0)
+        assert c.last_match_kernel() == "k_grid_nn16f"
+        c.icp_setup(sel_b, nvb, plb)                      # same count, other queries
+        idx_op, _ = c.corr_match()
+        c.icp_iterate(z, z, z, 0.3, 1.0)
+        assert c.last_match_kernel() == "k_grid_nn16f"
+        idx, dist, keep, _ = c.icp_state(residual=False)
+        nn, _ = orc.knn(Xm, P[sel_b], k=1)
+        assert np.array_equal(idx_op, nn[:, 0]) and np.array_equal(idx, nn[:, 0])
+        # a new movable cloud: the bounds kept by slot were points of the old one
+        Xm2 = Xm[::-1].copy() + np.array([0.3, -0.2, 0.1])
+        c.upload(_lib.MOV, Xm2)
+        idx_op, _ = c.corr_match()
+        c.icp_iterate(z, z, z, 0.3, 1.0)
+        idx, _, _, _ = c.icp_state(residual=False)
+        nn2, _ = orc.knn(Xm2, P[sel_b], k=1)
+        assert np.array_equal(idx_op, nn2[:, 0]) and np.array_equal(idx, nn2[:, 0])
+
+
 # ---- the one-sweep k-NN + covariance kernel (k_grid_knn_sweep) == k extraction rounds + k_normals == oracle ----
 def _knn_cases():
     rng = np.random.default_rng(2024)
