@@ -72,3 +72,27 @@ def test_float32_value_is_within_the_margin_of_the_contract_distance(name):
     w = worst_ratio(P, Qp, H)
     assert w <= 1.0, (name, w)
     assert w > 0.01, (name, w)           # (a margin a hundred times too wide would send every query to the exact kernel)
+
+
+def test_margin_holds_on_a_seeded_sweep_of_scales_offsets_and_transforms():
+    """... and on 150 random configurations spanning twelve decades of scale, offsets up to 1e4 x the extent, flat and cubic boxes,
+    quantised coordinates, small and arbitrary rotations, query distances from 1e-9 to 10 x the scale (the worst ratio seen over 400 such
+    configurations was 0.50: the margin has a factor of two in hand, as its derivation's constants suggest)."""
+    rng = np.random.default_rng(2025)
+    worst = 0.0
+    for _ in range(150):
+        s = 10.0 ** rng.uniform(-6, 6)
+        ext = s * 10.0 ** rng.uniform(-3, 0, 3)
+        off = rng.uniform(-1, 1, 3) * s * 10.0 ** rng.uniform(0, 4) if rng.random() < 0.6 else np.zeros(3)
+        P = rng.uniform(-1, 1, (1500, 3)) * ext + off
+        if rng.random() < 0.3:
+            P = np.round(P / (s * 1e-3)) * (s * 1e-3)
+        ang = rng.uniform(-np.pi, np.pi, 3) * (1.0 if rng.random() < 0.5 else 1e-3)
+        t = rng.uniform(-1, 1, 3) * s * 10.0 ** rng.uniform(-3, 1)
+        H = orc.params_to_H(np.concatenate((ang, t)))
+        base = P[rng.choice(len(P), 24)] @ H[:3, :3].T + H[:3, 3]
+        disp = rng.normal(0, 1, (24, 3))
+        disp /= np.linalg.norm(disp, axis=1)[:, None]
+        Qp = base + disp * (s * 10.0 ** rng.uniform(-9, 1, (24, 1)))
+        worst = max(worst, worst_ratio(P, Qp, H))
+    assert worst <= 1.0, worst
