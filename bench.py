@@ -660,8 +660,10 @@ def comm_record(ctx, exchange, transport, qshard, world, shard_rows, nq, timing,
     if not exchange:
         return None
     info = ctx.comm_info()
+    xi = ctx.exchange_info()
     x = timing.get("exchange", {"ms": 0.0, "launches": 0})
     return {"backend": info["backend"], "nranks": info["nranks"], "rank": info["rank"], "partition": info["partition"],
+            "winner_exchange": xi["form"], "key_exchange_from_queries": xi["keys_min_q"],
             "gn_shard": info["gn_shard"], "transport_chosen_by_attach": transport,
             "shard_rows_this_rank": int(shard_rows), "queries_this_rank": int((nq + world - 1) // world if qshard else nq),
             "exchange_us_per_iteration": x["ms"] * 1e3 / max(1, x["launches"]), "exchanges_timed": x["launches"],
@@ -678,11 +680,21 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
     sel = np.unique(np.round(np.linspace(0, Nf - 1, Qt)).astype(np.int64))
     nq = len(sel)
     transport = None
+    # N > 1: query shards (every rank the whole movable cloud, its slice of the queries) unless the caller pinned cloud shards
+    # (--partition cloud: index shards of the movable cloud, the winners merged per iteration -- from 32 768 queries by three
+    # reductions on 8-byte keys, the 6x6 reduction sharded from 262 144)
+    tp_qshard = args.partition != "cloud"
+    shard_rows = Nm
     if exchange:
-        # query shards: every rank the whole movable cloud
         dist.detach(ctx)
-        ctx.upload(_lib.MOV, Xm)
-        transport = dist.attach(ctx, gn_shard=False, partition=_lib.PART_QUERIES)
+        if tp_qshard:
+            ctx.upload(_lib.MOV, Xm)
+            transport = dist.attach(ctx, gn_shard=False, partition=_lib.PART_QUERIES)
+        else:
+            lo, hi = dist.shard_bounds(Nm, rank, world)
+            shard_rows = hi - lo
+            ctx.upload(_lib.MOV, Xm[lo:hi], index_base=lo)
+            transport = dist.attach(ctx, gn_shard=nq >= 262144, partition=_lib.PART_CLOUD)
     ctx.timing_enable(False)
     t0 = time.perf_counter()
     normals, planarity = ctx.estimate_normals(_lib.FIX, sel, k)
@@ -726,7 +738,7 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
     work = ctx.match_work()
     ctx.timing_enable(False)
     rec = None if args.no_parity else parity_device(ctx, sel, normals, planarity, obs, ow, iterations=1)
-    comm = comm_record(ctx, exchange, transport, True, world, Nm, nq, timing, args.steps)
+    comm = comm_record(ctx, exchange, transport, tp_qshard, world, shard_rows, nq, timing, args.steps)
     # the one-off before the loop at this Q: estimate_normals again (grid resident), its kernels under HIP events, then once more
     # with the sweep tallying its candidates
     ctx.timing_enable(True)
@@ -743,7 +755,7 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
     if rank != 0:
         return None
     avg = {name: v["ms"] / max(1, v["launches"]) for name, v in timing.items()}
-    nq_local = (nq + world - 1) // world if exchange else nq
+    nq_local = (nq + world - 1) // world if (exchange and tp_qshard) else nq
     per = {kk: v / max(1, work["launches"]) for kk, v in work.items() if kk != "launches"}
     bytes_match = match_bytes(kern, per, nq_local)
     pmc, pmc_src = load_pmc()
@@ -774,7 +786,8 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
            "repeat_stats": {"repeats": len(times), "ms_per_step_p10": float(np.percentile(times, 10)) / args.steps * 1e3,
                             "ms_per_step_p90": float(np.percentile(times, 90)) / args.steps * 1e3,
                             "timed_region": "K steps from the cold state (icp_setup just called), min_change=0, events off"},
-           "parallelism": f"query shards x{world}, movable cloud replicated" if exchange else "1 GPU",
+           "parallelism": (f"query shards x{world}, movable cloud replicated" if tp_qshard else
+                           f"cloud shards x{world}, queries replicated") if exchange else "1 GPU",
            "roofline": roof(kern, avg["match"], bytes_match,
                             ("exact 1-NN on the static grid, four or eight cell-ordered queries per wave, candidates through a float32 filter in the "
                              "cloud's frame (16-B records), the winner re-evaluated exactly, ties left to the exact kernel; bytes = the candidates and "
@@ -785,8 +798,8 @@ def throughput_point(args, ctx, Xf, Xm, Qt, k, rank, world, exchange, share_gpu)
                             "counters' bytes); issue- and latency-bound", {"candidates_per_query": per["candidates"] / max(1, nq_local),
                                            "grid_rows_per_query": per["rows"] / max(1, nq_local),
                                            "left_to_exact_kernel_per_launch": per.get("deferred"),
-                                           "pruning_ratio": (Nm * 24 + nq_local * 40) / max(1.0, bytes_match)}),
-           "roofline_solver": roof("k_lm_eval" if exchange else "k_lm_all", avg["solve"], int(last.n_kept) * 72 * evals,
+                                           "pruning_ratio": (shard_rows * 24 + nq_local * 40) / max(1.0, bytes_match)}),
+           "roofline_solver": roof("k_lm_eval" if (comm and comm["gn_shard"]) else "k_lm_all", avg["solve"], int(last.n_kept) * 72 * evals,
                                    "the iteration's whole minimisation (one launch: evaluations as phases between grid barriers, then the "
                                    "finish): 72 B per kept correspondence and evaluation, 8x8 Gram on the FP64 matrix pipe",
                                    {"evaluations_per_iteration": evals}),

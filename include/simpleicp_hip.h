@@ -38,8 +38,10 @@ extern "C" {
 
 /* 1: round 1.  2: + sicp_corr_*, sicp_estimate_parameters, sicp_comm_*, sicp_set_partition, sicp_cloud_set_planarity,
  * sicp_cloud_download_columns, sicp_match_work; sicp_timing_enable(ctx, 2); every upload resets the slot's planarity
- * column.  3: + sicp_comm_activate, sicp_comm_info, sicp_device_memory; SICP_K_XCHG; sicp_comm_init bounded + handshake.  4: + sicp_knn_work, sicp_cloud_download_both; sicp_estimate_normals runs the one-sweep k-NN + covariance kernel.  5: + sicp_match_deferred, sicp_tail_cycles; kind 6 of sicp_last_match_kernel.  A binding checks sicp_abi_version() against the header it was written for. */
-#define SICP_ABI_VERSION 5
+ * column.  3: + sicp_comm_activate, sicp_comm_info, sicp_device_memory; SICP_K_XCHG; sicp_comm_init bounded + handshake.  4: + sicp_knn_work, sicp_cloud_download_both; sicp_estimate_normals runs the one-sweep k-NN + covariance kernel.  5: + sicp_match_deferred, sicp_tail_cycles; kind 6 of sicp_last_match_kernel.
+ * 6: + SICP_XCHG_MIN_U64 / SICP_XCHG_MAX_U64 (asked of a registered callback with count = 0 first: a callback written for ABI 5 answers
+ * non-zero and keeps the all-gather exchange), sicp_tail_selection, sicp_exchange_info.  A binding checks sicp_abi_version() against the header it was written for. */
+#define SICP_ABI_VERSION 6
 
 #define SICP_OK               0
 #define SICP_ERR_INVALID     -1   /* bad argument / wrong call order                         */
@@ -238,9 +240,18 @@ int sicp_params_to_H(const double x[6], double H_out[16]);
  *                             rank's `a` in rank order (the library packs per-query
  *                             (d2, idx, x, y, z) records into `a` and afterwards reduces `b` to
  *                             the job-wide lexicographic (d2, idx) minimum with its own kernel).
- *   SICP_XCHG_SUM_F64       : a = f64[count]; replace in place by the sum over ranks.          */
+ *   SICP_XCHG_SUM_F64       : a = f64[count]; replace in place by the sum over ranks.
+ *   SICP_XCHG_MIN_U64, SICP_XCHG_MAX_U64 (ABI 6; optional) : a = uint64[count]; replace in place by the element-wise minimum /
+ *                             maximum over ranks, the words compared as UNSIGNED integers.  With them cloud shards of many queries
+ *                             (SICP_XCHG_KEYS_MIN_Q, default 32 768) find the job-wide winner by three reductions on 8-byte keys
+ *                             -- min of the squared distance's bits, min of the index among the holders of that minimum, max of
+ *                             the owner's coordinate bits against zeros -- instead of gathering 40 bytes per query AND RANK.
+ *                             sicp_set_exchange asks once with count = 0 and a = NULL (no data, no collective: just return 0 if
+ *                             the operation is served, non-zero if not); a callback that declines keeps the all-gather road. */
 #define SICP_XCHG_ALLGATHER_F64 1
 #define SICP_XCHG_SUM_F64       2
+#define SICP_XCHG_MIN_U64       3
+#define SICP_XCHG_MAX_U64       4
 typedef int (*sicp_exchange_fn)(void *user, int what, void *a, void *b, void *c, int64_t count);
 /* With an exchange registered, sicp_knn(k == 1) and the iteration's match return JOB-WIDE winners.
  * gn_shard: 0 = every rank reduces all correspondences (no collective in the solver),
@@ -270,6 +281,11 @@ int sicp_comm_destroy(sicp_ctx *ctx);
  *                        ncclCommUserRank); out[3] partition; out[4] gn_shard; out[5] a communicator exists (active or parked). */
 int sicp_comm_activate(sicp_ctx *ctx, int on, int gn_shard);
 int sicp_comm_info(sicp_ctx *ctx, int out[6]);
+/* What the chained iterations' exchanges did since sicp_icp_setup (ABI 6): out4[0] form of the LAST one -- 0 none yet, 1 all-gather of
+ * 40-byte (d2, index, xyz) records + lexicographic minimum (cloud shards), 2 three all-reduces on 8-byte keys (cloud shards from
+ * SICP_XCHG_KEYS_MIN_Q queries), 3 all-gather of the query slices' matched indices (query shards); out4[1] how many exchanges ran;
+ * out4[2] the key exchange's threshold in queries (0 = never); out4[3] 1 if a registered callback serves SICP_XCHG_MIN_U64 / MAX_U64. */
+int sicp_exchange_info(sicp_ctx *ctx, int64_t out4[4]);
 /* free / total bytes of the ctx's device (hipMemGetInfo): what a host consults before it replicates a cloud on every rank */
 int sicp_device_memory(sicp_ctx *ctx, int64_t *free_out, int64_t *total_out);
 /* What the ranks shard:
@@ -329,6 +345,11 @@ int sicp_match_deferred(sicp_ctx *ctx, uint64_t *out);
  * Jacobian evaluations, 6x6 solves), [4] statistics of the residuals, convergence test, the record.  What the bench's latency model
  * (kernel boundaries + dependent memory round trips + these on-chip phases) is built from.  Zeros before the first such iteration. */
 int sicp_tail_cycles(sicp_ctx *ctx, double out5[5]);
+/* How the single-workgroup tail (Q <= 2048) found median and MAD (corrpts.py:165-188) in the LAST iteration it ran: out3[0] / out3[1]
+ * range-histogram rounds spent on the median / the MAD -- 0 = read off a window around the previous iteration's value (the settled
+ * iterations of a chained run; same keys, same order statistic, same bits) --, out3[2] iterations since sicp_icp_setup in which
+ * both came from their windows. */
+int sicp_tail_selection(sicp_ctx *ctx, int64_t out3[3]);
 /* Work the one-sweep k-NN (sicp_estimate_normals, sicp_knn with k > 1 on a binned cloud) did since sicp_timing_reset, under
  * sicp_timing_enable(ctx, 2): out4[0] candidates read (one 32-byte record each), out4[1] sweeps (a query needs one when its first
  * ball holds k points), out4[2] queries that took the k-round extraction instead, out4[3] candidates inside their query's ball. */

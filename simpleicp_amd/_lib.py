@@ -18,10 +18,10 @@ LIB_PATH = Path(os.environ["SICP_LIBRARY"]) if os.environ.get("SICP_LIBRARY") el
 
 FIX, MOV = 0, 1
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_TOO_FEW, ERR_NUMERIC, ERR_EXCHANGE = 0, -1, -2, -3, -4, -5, -6
-XCHG_ALLGATHER_F64, XCHG_SUM_F64 = 1, 2
+XCHG_ALLGATHER_F64, XCHG_SUM_F64, XCHG_MIN_U64, XCHG_MAX_U64 = 1, 2, 3, 4
 PART_CLOUD, PART_QUERIES = 0, 1
 K_KNN1, K_KNNK, K_NORMALEQ, K_SELECT, K_XCHG = 0, 1, 2, 3, 4
-ABI_VERSION = 5          # include/simpleicp_hip.h SICP_ABI_VERSION this binding was written for
+ABI_VERSION = 6          # include/simpleicp_hip.h SICP_ABI_VERSION this binding was written for
 KERNEL_NAMES = {K_KNN1: "match", K_KNNK: "knnk_scan", K_NORMALEQ: "solve", K_SELECT: "reject_select", K_XCHG: "exchange"}
 MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1_frec", 5: "k_grid_nn16", 6: "k_grid_nn16f"}
 
@@ -31,7 +31,7 @@ EXPORTS = [
     "sicp_cloud_download", "sicp_cloud_download_columns", "sicp_cloud_download_both", "sicp_cloud_set_planarity", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
     "sicp_corr_match", "sicp_corr_reject_planarity", "sicp_corr_reject_distances", "sicp_estimate_parameters",
-    "sicp_set_exchange", "sicp_comm_unique_id", "sicp_comm_init", "sicp_comm_destroy", "sicp_comm_activate", "sicp_comm_info", "sicp_device_memory", "sicp_set_partition", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_match_deferred", "sicp_tail_cycles", "sicp_knn_work", "sicp_last_match_kernel",
+    "sicp_set_exchange", "sicp_comm_unique_id", "sicp_comm_init", "sicp_comm_destroy", "sicp_comm_activate", "sicp_comm_info", "sicp_device_memory", "sicp_set_partition", "sicp_ctx_stream", "sicp_lexmin_gathered", "sicp_timing_enable", "sicp_timing_reset", "sicp_timing_get", "sicp_match_work", "sicp_match_deferred", "sicp_tail_cycles", "sicp_tail_selection", "sicp_exchange_info", "sicp_knn_work", "sicp_last_match_kernel",
     "sicp_xyz_count", "sicp_xyz_read", "sicp_xyz_write",
 ]
 
@@ -126,6 +126,8 @@ def load():
     L.sicp_match_work.argtypes = [vp, vp]
     L.sicp_match_deferred.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.sicp_tail_cycles.argtypes = [vp, vp]
+    L.sicp_tail_selection.argtypes = [vp, vp]
+    L.sicp_exchange_info.argtypes = [vp, vp]
     L.sicp_knn_work.argtypes = [vp, vp]
     L.sicp_last_match_kernel.argtypes = [vp, C.POINTER(cint)]
     L.sicp_xyz_count.argtypes = [C.c_char_p, C.POINTER(i64)]
@@ -509,6 +511,20 @@ class Context:
         out = np.zeros(5)
         self._chk(self._L.sicp_tail_cycles(self._h, _ptr(out)))
         return dict(zip(("load", "select", "keep", "lm", "final"), (float(v) for v in out)))
+
+    def tail_selection(self):
+        """How the single-workgroup tail found median / MAD in its last iteration (histogram rounds; 0 = from the window around the
+        previous iteration's value) and in how many iterations since icp_setup both came from their windows."""
+        out = np.zeros(3, np.int64)
+        self._chk(self._L.sicp_tail_selection(self._h, _ptr(out)))
+        return {"median_rounds": int(out[0]), "mad_rounds": int(out[1]), "window_iterations": int(out[2])}
+
+    def exchange_info(self):
+        """What the chained iterations' exchanges did since icp_setup: form of the last one, how many ran."""
+        out = np.zeros(4, np.int64)
+        self._chk(self._L.sicp_exchange_info(self._h, _ptr(out)))
+        return {"form": ("none", "records_allgather", "key_allreduces", "query_slices")[int(out[0])], "count": int(out[1]),
+                "keys_min_q": int(out[2]), "callback_serves_u64": bool(out[3])}
 
     def knn_work(self):
         """Work counters of the one-sweep k-NN (normals) since timing_reset (kept while timing_enable(2) is in force)."""

@@ -178,6 +178,7 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
     if (const char *e = std::getenv("SICP_LM")) c->lm_one_launch = std::strcmp(e, "launches") != 0;
     if (const char *e = std::getenv("SICP_HSEL_WINDOW")) c->hsel_window = std::atoi(e) != 0;
+    if (const char *e = std::getenv("SICP_TAIL_WINDOW")) c->tail_window = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_TEST_BARRIER_FAULT")) c->test_barrier_fault = std::atoi(e);
     if (const char *e = std::getenv("SICP_NN_GROUP")) { const int v = std::atoi(e); if (v == 8 || v == 16) c->nn_group = v; }
     if (const char *e = std::getenv("SICP_XCHG_KEYS_MIN_Q")) c->xkeys_min_q = std::atol(e);
@@ -279,6 +280,12 @@ SICP_EXPORT int sicp_tail_cycles(sicp_ctx *c, double out5[5])
 {
     if (!c || !out5) return fail(SICP_ERR_INVALID, "null argument");
     std::memcpy(out5, c->last_tail_cycles, sizeof c->last_tail_cycles);
+    return SICP_OK;
+}
+SICP_EXPORT int sicp_tail_selection(sicp_ctx *c, int64_t out3[3])
+{
+    if (!c || !out3) return fail(SICP_ERR_INVALID, "null argument");
+    out3[0] = c->last_sel_rounds[0]; out3[1] = c->last_sel_rounds[1]; out3[2] = c->sel_window_hits;
     return SICP_OK;
 }
 SICP_EXPORT int sicp_knn_work(sicp_ctx *c, uint64_t out4[4])

@@ -44,7 +44,7 @@ void abandon_exchange(sicp_ctx *c)
 {
     if (c->comm) { (void)rccl()->CommAbort(c->comm); c->comm = nullptr; }
     c->comm_active = false;
-    c->xfn = nullptr; c->xuser = nullptr;
+    c->xfn = nullptr; c->xuser = nullptr; c->xfn_u64 = false;
     c->rank = 0; c->world = 1; c->gn_shard = 0;
     const auto t0 = std::chrono::steady_clock::now();
     bool drained = false;
@@ -164,28 +164,37 @@ int exchange_best_chained(sicp_ctx *c, const TailArgs &A, long Q, bool packed_by
     return SICP_OK;
 }
 
-// ... and for MANY queries (xkeys_min_q on, the library's own communicator): three all-reduces on 8-byte keys instead of the
-// all-gather of 40 bytes per query and rank (sicp_kernels.hip); then k_postmatch on the job-wide winners
+// ... and for MANY queries (xkeys_min_q on; the library's own communicator, or a callback that serves SICP_XCHG_MIN_U64 / MAX_U64):
+// three all-reduces on 8-byte keys instead of the all-gather of 40 bytes per query and rank (sicp_kernels.hip); then k_postmatch on
+// the job-wide winners
 bool exchange_by_keys(const sicp_ctx *c, long Q)
 {
-    return c->comm && c->comm_active && c->partition == SICP_PART_CLOUD && c->xkeys_min_q > 0 && Q >= c->xkeys_min_q;
+    const bool served = (c->comm && c->comm_active) || (c->xfn && c->xfn_u64);      // the library's communicator, or a callback that said it can
+    return served && c->partition == SICP_PART_CLOUD && c->xkeys_min_q > 0 && Q >= c->xkeys_min_q;
+}
+// element-wise unsigned minimum / maximum over the ranks, in place, enqueued in order on the library's stream
+int all_reduce_u64(sicp_ctx *c, unsigned long long *buf, long count, bool take_max)
+{
+    if (c->comm && c->comm_active) {
+        const ncclResult_t r = rccl()->AllReduce(buf, buf, (size_t)count, ncclUint64, take_max ? ncclMax : ncclMin, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(SICP_ERR_EXCHANGE, "ncclAllReduce (keys) failed: %s", rccl()->GetErrorString(r));
+        return SICP_OK;
+    }
+    if (c->xfn(c->xuser, take_max ? SICP_XCHG_MAX_U64 : SICP_XCHG_MIN_U64, buf, nullptr, nullptr, count) != 0)
+        return fail(SICP_ERR_EXCHANGE, "exchange callback (%s) failed", take_max ? "MAX_U64" : "MIN_U64");
+    return SICP_OK;
 }
 int exchange_best_keys_chained(sicp_ctx *c, const TailArgs &A, long Q)
 {
     Timed t(c, SICP_K_XCHG);
     CHK(c->x_send.reserve((size_t)5 * Q));
     unsigned long long *gmin = (unsigned long long *)c->x_send.p, *gidx = gmin + Q, *xyz = gidx + Q;
-    auto reduce = [&](unsigned long long *buf, long count, ncclRedOp_t op) -> int {
-        const ncclResult_t r = rccl()->AllReduce(buf, buf, (size_t)count, ncclUint64, op, c->comm, c->stream);
-        if (r != ncclSuccess) return fail(SICP_ERR_EXCHANGE, "ncclAllReduce (keys) failed: %s", rccl()->GetErrorString(r));
-        return SICP_OK;
-    };
     launch_xkey_d2(c->stream, c->m_d2.p, c->m_idx.p, Q, gmin);
-    CHK(reduce(gmin, Q, ncclMin));
+    CHK(all_reduce_u64(c, gmin, Q, false));
     launch_xkey_idx(c->stream, c->m_d2.p, c->m_idx.p, gmin, Q, gidx);
-    CHK(reduce(gidx, Q, ncclMin));
+    CHK(all_reduce_u64(c, gidx, Q, false));
     launch_xkey_xyz(c->stream, c->m_idx.p, c->m_p2.p, gidx, Q, xyz);
-    CHK(reduce(xyz, 3 * Q, ncclMax));
+    CHK(all_reduce_u64(c, xyz, 3 * Q, true));
     launch_xkey_unpack(c->stream, gmin, gidx, xyz, Q, c->m_d2.p, c->m_idx.p, c->m_p2.p);
     Xf unused = {};
     launch_postmatch(c->stream, c->q.p, c->q.p + c->qpad, c->q.p + 2 * c->qpad, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q,
@@ -237,6 +246,10 @@ SICP_EXPORT int sicp_set_exchange(sicp_ctx *c, sicp_exchange_fn fn, void *user, 
     if (world > 1 && !fn) return fail(SICP_ERR_INVALID, "world > 1 needs an exchange callback");
     c->comm_active = false;                                // a callback replaces the library's own communicator (which stays parked)
     c->xfn = fn; c->xuser = user; c->rank = rank; c->world = world; c->gn_shard = gn_shard ? 1 : 0;
+    // ABI 6: does the callback reduce 8-byte keys?  Asked with no data (count = 0, a = NULL): nothing is exchanged, every rank's
+    // callback answers for itself -- the same code on every rank, hence the same answer
+    c->xfn_u64 = fn != nullptr && fn(user, SICP_XCHG_MIN_U64, nullptr, nullptr, nullptr, 0) == 0 &&
+                 fn(user, SICP_XCHG_MAX_U64, nullptr, nullptr, nullptr, 0) == 0;
     return SICP_OK;
 }
 
@@ -353,7 +366,7 @@ SICP_EXPORT int sicp_comm_init(sicp_ctx *c, const void *id128, int rank, int wor
         (void)R->CommAbort(c->comm); c->comm = nullptr; c->comm_active = false;
         return rc;
     }
-    c->xfn = nullptr; c->xuser = nullptr;
+    c->xfn = nullptr; c->xuser = nullptr; c->xfn_u64 = false;
     c->rank = rank; c->world = world; c->gn_shard = gn_shard ? 1 : 0;
     return SICP_OK;
 }
@@ -365,7 +378,7 @@ SICP_EXPORT int sicp_comm_activate(sicp_ctx *c, int on, int gn_shard)
     if (!c) return fail(SICP_ERR_INVALID, "null ctx");
     if (on && !c->comm) return fail(SICP_ERR_INVALID, "no communicator: call sicp_comm_init first");
     if (on) {
-        c->xfn = nullptr; c->xuser = nullptr;
+        c->xfn = nullptr; c->xuser = nullptr; c->xfn_u64 = false;
         c->comm_active = true; c->rank = c->comm_rank; c->world = c->comm_world; c->gn_shard = gn_shard ? 1 : 0;
     } else {
         c->comm_active = false;
@@ -387,6 +400,13 @@ SICP_EXPORT int sicp_comm_info(sicp_ctx *c, int out[6])
             return fail(SICP_ERR_EXCHANGE, "ncclCommCount / ncclCommUserRank failed");
         out[1] = n; out[2] = r;
     }
+    return SICP_OK;
+}
+
+SICP_EXPORT int sicp_exchange_info(sicp_ctx *c, int64_t out4[4])
+{
+    if (!c || !out4) return fail(SICP_ERR_INVALID, "null argument");
+    out4[0] = c->last_xchg_form; out4[1] = c->xchg_count; out4[2] = c->xkeys_min_q; out4[3] = (c->xfn && c->xfn_u64) ? 1 : 0;
     return SICP_OK;
 }
 

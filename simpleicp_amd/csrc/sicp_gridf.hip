@@ -149,6 +149,23 @@ void launch_slot_queries(hipStream_t s, const double *qx, const double *qy, cons
     hipLaunchKernelGGL(k_slot_queries, dim3(cdivf(Q, 256)), dim3(256), 0, s, qx, qy, qz, order, prev_p2, Q, (double4 *)qrec, (double4 *)pslot);
 }
 
+// Behind a cloud-shard exchange: the slot's bound becomes the JOB-WIDE winner (the exchange left it in the by-query arrays).  The search
+// itself wrote this rank's own winner there -- on a rank whose shard lies elsewhere that is a far-away point, and every later search
+// of the slot would start from its radius (lean pass, full pass, the exact kernel: ADVICE r5); any cloud point is a valid bound, the
+// nearest one anybody holds is the useful one.
+__global__ __launch_bounds__(256) void k_slot_bounds(const double4 *__restrict__ qrec, const int64_t *__restrict__ idx,
+                                                     const double *__restrict__ p2, long Q, double4 *__restrict__ pslot)
+{
+    const long slot = (long)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= Q) return;
+    const long q = (long)__double_as_longlong(qrec[slot].w);
+    pslot[slot] = idx[q] >= 0 ? make_double4(p2[3 * q], p2[3 * q + 1], p2[3 * q + 2], 0.0) : make_double4(__builtin_inf(), 0.0, 0.0, 0.0);
+}
+void launch_slot_bounds(hipStream_t s, const void *qrec, const int64_t *idx, const double *p2, long Q, void *pslot)
+{
+    hipLaunchKernelGGL(k_slot_bounds, dim3(cdivf(Q, 256)), dim3(256), 0, s, (const double4 *)qrec, idx, p2, Q, (double4 *)pslot);
+}
+
 // FAR = false: the flavour of a run's steady state -- a ball of a few rows, one batch of them, no hit-driven culling, no boxes; a
 //   query that turns out to need more (more rows than the group has lanes, more than four of them non-empty) is left to the exact
 //   kernel like a tie.  That is what the registers of five waves per SIMD pay for.

@@ -217,6 +217,7 @@ struct sicp_ctx {
     double last_x[6] = {0}, last_w = 1.0, last_obs[6] = {0}, last_ow[6] = {0};
     double last_ne[30] = {0};      // normal equations at last_x (fused path caches them)
     double last_tail_cycles[5] = {0};   // k_icp_tail's own clock over its phases, last iteration (sicp_tail_cycles)
+    long last_sel_rounds[2] = {0, 0}, sel_window_hits = 0;   // ... how it found median / MAD (sicp_tail_selection)
     bool have_last_ne = false;
     int solve_mode = 0;            // SICP_SOLVE = fused | host (A/B + tests); 0 = auto
     bool grid_target_forced = false;   // SICP_GRID_TARGET given: every grid uses it
@@ -238,6 +239,8 @@ struct sicp_ctx {
     bool lm_one_launch = true;         // SICP_LM=launches: one launch per evaluation + finish (A/B; always with a sharded reduction)
     unsigned long long hsel_bar = 0;   // what the one-launch rejection's launches have added to its barrier counter so far
     int test_barrier_fault = 0;    // SICP_TEST_BARRIER_FAULT = 1 / 2 (tests only): the rejection's / the solver's grid barrier expects a block that never comes
+    bool tail_window = true;       // SICP_TAIL_WINDOW=0: the single-workgroup tail never looks for median / MAD in a window around the last iteration's (A/B, tests)
+    bool reject_prior = false;     // c->small[0..3] holds the last chained k_reject launch's statistics for the current setup
     bool hsel_window = true;       // SICP_HSEL_WINDOW=0: never the windowed (three-barrier) form of the large-Q rejection
     long hsel_run_launches = 0;    // chained rejection launches since the last setup (the window needs two of them behind it)
     bool hsel_dirty = false;
@@ -246,6 +249,8 @@ struct sicp_ctx {
     // exchange: an RCCL communicator of the library's own (sicp_comm_init) or a host callback (sicp_set_exchange)
     sicp_exchange_fn xfn = nullptr;
     void *xuser = nullptr;
+    int last_xchg_form = 0; long xchg_count = 0;   // sicp_exchange_info: 1 records all-gather, 2 key all-reduces, 3 query slices
+    bool xfn_u64 = false;          // the callback serves SICP_XCHG_MIN_U64 / MAX_U64 (asked once, at registration)
     ncclComm_t comm = nullptr;
     bool comm_active = false;      // a communicator stays with the ctx between runs (sicp_comm_activate): building one costs ~0.1-1 s
     int comm_rank = 0, comm_world = 1;
@@ -312,6 +317,7 @@ int exchange_best(sicp_ctx *c, double *d2, int64_t *idx, double *p2, long Q);
 int exchange_best_chained(sicp_ctx *c, const TailArgs &A, long Q, bool packed_by_match);
 bool exchange_by_keys(const sicp_ctx *c, long Q);
 int exchange_best_keys_chained(sicp_ctx *c, const TailArgs &A, long Q);
+int all_reduce_u64(sicp_ctx *c, unsigned long long *buf, long count, bool take_max);
 long query_slice(const sicp_ctx *c, long Q, long *lo);
 int exchange_query_slices_idx(sicp_ctx *c, const TailArgs &A, long Q, bool packed_by_match);
 void plan_chunks(const sicp_ctx *c, long npad, long qblocks, size_t bytes_per_chunk_row, int *chunk_pts, int *nchunks);

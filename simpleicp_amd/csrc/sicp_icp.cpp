@@ -191,6 +191,9 @@ SICP_EXPORT int sicp_icp_setup(sicp_ctx *c, const int64_t *sel_idx, int64_t Q, c
     c->slot_cnt = -1;                  // (the filtered search's slot-ordered copies of the queries: other queries now)
     c->q_order_lo = -1; c->q_order_cnt = 0;
     c->hsel_run_launches = 0;
+    c->sel_window_hits = 0; c->last_sel_rounds[0] = c->last_sel_rounds[1] = 0;
+    c->last_xchg_form = 0; c->xchg_count = 0;
+    c->reject_prior = false;
     return sync(c);
 }
 
@@ -270,6 +273,7 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
     A.min_planarity = (float)P0->min_planarity;
     A.max_steps = P0->max_lm_steps > 0 ? (int)P0->max_lm_steps : 100;
     A.Q = (int)Q;
+    A.window = c->tail_window ? 1 : 0;
     A.pl2 = cl.pl_n > 0 ? cl.pl.p : nullptr;
     A.pl2_n = cl.pl_n;
 
@@ -413,12 +417,17 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
             }
             HIPCHK(hipGetLastError());
             c->have_prev_match = true;          // (after an exchange: the job-wide winner's coordinates -- still a valid bound)
-            if (qshard) { CHK(exchange_query_slices_idx(c, A, Q, packed)); post_done = true; }      // (distances + verdicts formed by the unpack)
+            if (qshard) { CHK(exchange_query_slices_idx(c, A, Q, packed)); post_done = true; c->last_xchg_form = 3; ++c->xchg_count; }      // (distances + verdicts formed by the unpack)
             else if (c->collective() && c->partition == SICP_PART_CLOUD) {
                 CHK(c->x_send.reserve((size_t)5 * Q));
-                if (exchange_by_keys(c, Q)) CHK(exchange_best_keys_chained(c, A, Q));           // (many queries: all-reduces on 8-byte keys)
+                const bool by_keys = exchange_by_keys(c, Q);
+                if (by_keys) CHK(exchange_best_keys_chained(c, A, Q));                          // (many queries: all-reduces on 8-byte keys)
                 else CHK(exchange_best_chained(c, A, Q, packed));                              // (... by the lexicographic minimum's kernel)
+                // the filtered search keeps its bounds by slot and wrote THIS rank's winner there: make it the job-wide one
+                if (c->last_match_kernel == 6 && c->slot_cnt == Q)
+                    launch_slot_bounds(c->stream, c->q_slot.p, c->m_idx.p, c->m_p2.p, Q, c->p_slot.p);
                 post_done = true;
+                c->last_xchg_form = by_keys ? 2 : 1; ++c->xchg_count;
             }
             A.seq = (double)(++c->solve_seq);
             seqs[launched % REC_RING] = A.seq;
@@ -441,7 +450,9 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                     if (!post_done)
                         launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
                                          A.min_planarity, A.pl2, A.pl2_n, c->dist.p, c->flag.p, c->icp_dev.p);
-                    launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->icp_dev.p, c->small.p + 4);
+                    launch_reject(c->stream, c->dist.p, c->flag.p, Q, c->keep.p, c->small.p, c->icp_dev.p, c->small.p + 4,
+                                  c->tail_window && c->reject_prior);
+                    c->reject_prior = true;               // (c->small[0..3] now holds this iteration's statistics: the next launch's window)
                 } else {
                     if (!post_done)
                         launch_postmatch(c->stream, qx, qy, qz, c->normals.p, c->planarity.p, c->m_p2.p, c->m_idx.p, Q, unused,
@@ -537,7 +548,11 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
         std::memcpy(c->last_ne, o + 20, sizeof c->last_ne);
         c->have_last_ne = true;
         c->resid_slot = small_q ? 0 : (int)o[REC_RESID_SLOT];
-        if (small_q) std::memcpy(c->last_tail_cycles, o + 50, 5 * sizeof(double));
+        if (small_q) {
+            std::memcpy(c->last_tail_cycles, o + 50, 5 * sizeof(double));
+            c->last_sel_rounds[0] = (long)o[56]; c->last_sel_rounds[1] = (long)o[58];
+            if (o[56] == 0.0 && o[58] == 0.0) ++c->sel_window_hits;
+        }
         if (c->solve_trace && small_q)
             std::fprintf(stderr, "[tail] cycles: load+dist %.0f select %.0f (median %.0f in %.0f rounds, MAD %.0f in %.0f) keep %.0f lm %.0f "
                                  "(%lld evals %.0f, %lld steps, solves %.0f, accept %.0f) final %.0f\n",

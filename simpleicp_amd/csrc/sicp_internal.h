@@ -37,7 +37,9 @@ struct IcpDev {
     double prev_mean, prev_std;   // residual statistics of the last completed iteration (convergence test)
     int done_iters;               // iterations completed in this run
     int stop;                     // the run is over (converged / failed): later launches of the chain exit at once
-    int pad[2];
+    int sel_m;                    // the single-workgroup tail's last selection: how many distances took part ...
+    int pad;
+    double sel_med, sel_mad;      // ... their median and MAD (sel_mad > 0: the next launch looks for both in a window around these first)
 };
 // what the match kernel of a chained iteration leaves besides the match itself (null dist = nothing): the point-to-plane
 // distance and the planarity verdict per query, i.e. k_postmatch's output
@@ -60,6 +62,7 @@ struct TailArgs {
     float min_planarity;
     int max_steps;
     int Q;
+    int window;                   // k_icp_tail: 1 = try the window around the last launch's median / MAD first (sicp_tail.hip)
     const float *pl2;             // movable cloud's planarity column by GLOBAL index (corrpts.py:158-163), or null
     long pl2_n;
 };
@@ -140,6 +143,7 @@ void launch_recf(hipStream_t s, const void *rec, long n, const double c0[3], voi
 void launch_cell_boxes(hipStream_t s, const uint32_t *cell_start, const void *rec, long ncells, const GridGeom &G, unsigned long long *cell_box);
 void launch_slot_queries(hipStream_t s, const double *qx, const double *qy, const double *qz, const uint32_t *order, const double *prev_p2,
                          long Q, void *qrec, void *pslot);
+void launch_slot_bounds(hipStream_t s, const void *qrec, const int64_t *idx, const double *p2, long Q, void *pslot);
 // far: the flavour with row batches, hit-driven culling and box trimming (a run's first iterations); otherwise the lean flavour,
 // which marks the queries it cannot do in `state` (1) for a launch of the other flavour over the same slots
 void launch_grid_nn16f(hipStream_t s, int lanes_per_query, bool far, const IcpDev *st, const void *qrec, void *pslot, long Q,
@@ -221,8 +225,10 @@ void launch_postmatch(hipStream_t s, const double *qx, const double *qy, const d
                       const float *planarity, const double *p2, const int64_t *idx, long Q, const Xf &H,
                       float min_planarity, const float *pl2, long pl2_n, double *dist, uint8_t *flag, const IcpDev *st = nullptr);
 // st (nullable): loop state of a chained run -- H comes from it (postmatch) and every kernel exits at once when the run is over
+// use_prior: out4 holds the (m, median, mad, kept) an earlier launch left for the SAME correspondences' last iteration -- both
+// statistics are looked for in a window around them first (any values are safe: a window that misses falls back)
 void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4,
-                   const IcpDev *st = nullptr, double *out3 = nullptr);
+                   const IcpDev *st = nullptr, double *out3 = nullptr, bool use_prior = false);
 void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3, const double *also4 = nullptr,
                   double *host_out = nullptr, double seq = 0.0, double *partial = nullptr, unsigned *ticket = nullptr,
                   const IcpDev *st = nullptr);

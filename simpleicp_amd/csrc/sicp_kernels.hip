@@ -719,8 +719,11 @@ __device__ __forceinline__ double ord_val(uint64_t k)
 }
 
 constexpr int RJ_BLOCK = 1024, RJ_WAVES = RJ_BLOCK / 64, RJ_HC = 16, RJ_CAND = 8;
+constexpr int RJ_WCAP = 64, RJ_WSEG = 32;          // keys a selection window may hold in all / per wave (sicp_tail.hip: window_collect)
 struct RejectShared {
     uint64_t key[REJECT_MAX_Q];
+    uint64_t wc[2][RJ_WAVES][RJ_WSEG];             // windowed selection: per-wave candidate keys, one buffer per statistic
+    unsigned wci[2][RJ_WAVES], wbl[2][RJ_WAVES];   // ... how many, and how many member keys lie below the window
     unsigned hc[RJ_HC * 257];
     unsigned tot[256];
     uint64_t cand[RJ_CAND];
@@ -834,36 +837,115 @@ __device__ void lds_range_select(RejectShared &S, int n, long r, bool want2, uin
     __syncthreads();                          // S.cand / S.wmin consumed
 }
 
+
+// ---- order statistics from a window around the last launch's values (the selection of a settled chained run; the idea, the
+// exactness argument and the window's width are sicp_tail.hip's: window_collect / window_pick) -- here over keys that pass through
+// registers on their way into LDS, 16 waves.  A wave lists its member keys inside the window (ballot compaction) and counts those
+// below it; after one barrier every wave ranks the <= 64 listed keys itself.  All lanes of the block call rj_window_add in uniform
+// control flow (`mem` says whether the lane holds a member key).
+// (a step = the up to four keys a lane holds at once; nin / nbel: the wave's running totals, uniform)
+template <int N>
+__device__ __forceinline__ void rj_window_add(RejectShared &S, int buf, const bool (&mem)[N], const uint64_t (&k)[N], uint64_t wlo, uint64_t whi,
+                                              unsigned &nin, unsigned &nbel)
+{
+    const int wid = threadIdx.x >> 6;
+    unsigned cin = 0, cbel = 0;
+    bool inw[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        inw[u] = mem[u] && k[u] >= wlo && k[u] <= whi;
+        cin += inw[u] ? 1u : 0u;
+        cbel += (mem[u] && k[u] < wlo) ? 1u : 0u;
+    }
+    const unsigned incl = wscan_u32(cin | (cbel << 16));          // one wave prefix sum for both counts (<= 64 N each)
+    unsigned slot = nin + (incl & 0xffffu) - cin;
+#pragma unroll
+    for (int u = 0; u < N; ++u)
+        if (inw[u]) { if (slot < (unsigned)RJ_WSEG) S.wc[buf][wid][slot] = k[u]; ++slot; }
+    const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    nin += tot & 0xffffu; nbel += tot >> 16;
+}
+__device__ __forceinline__ void rj_window_close(RejectShared &S, int buf, unsigned nin, unsigned nbel)
+{
+    if ((threadIdx.x & 63) == 0) { S.wci[buf][threadIdx.x >> 6] = nin; S.wbl[buf][threadIdx.x >> 6] = nbel; }
+}
+// after the barrier: false = the wanted rank(s) are not inside the window (or it overflowed)
+__device__ __forceinline__ bool rj_window_pick(const RejectShared &S, int buf, long r, bool want2, uint64_t &ka, uint64_t &kb)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned n = 0, seg_max = 0, my_w = 0, my_base = 0;
+    long below = 0;
+#pragma unroll
+    for (int w = 0; w < RJ_WAVES; ++w) {
+        const unsigned c = S.wci[buf][w];
+        if ((unsigned)lane >= n && (unsigned)lane < n + c) { my_w = (unsigned)w; my_base = n; }
+        n += c; seg_max = c > seg_max ? c : seg_max;
+        below += (long)S.wbl[buf][w];
+    }
+    long t = r - below;
+    if (n > (unsigned)RJ_WCAP || seg_max > (unsigned)RJ_WSEG || t < 0 || t + (want2 ? 1 : 0) >= (long)n) return false;
+    uint64_t mine = ~0ull;
+    if ((unsigned)lane < n) mine = S.wc[buf][my_w][(unsigned)lane - my_base];
+    // quickselect on the total order (key, lane), wave-uniform bookkeeping (sicp_tail.hip: window_pick)
+    unsigned long long active = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+    int pa = 0;
+#pragma unroll 1
+    for (;;) {
+        const int p = __ffsll((long long)active) - 1;
+        const uint64_t pv = rj_readlane_u64(mine, p);
+        const unsigned long long less = __ballot(mine < pv || (mine == pv && lane < p)) & active;
+        const long c = (long)__popcll((long long)less);
+        if (c == t) { ka = pv; pa = p; break; }
+        if (c > t) active = less;
+        else { active &= ~less & ~(1ull << p); t -= c + 1; }
+    }
+    kb = ka;
+    if (want2) {
+        const bool behind = (unsigned)lane < n && (mine > ka || (mine == ka && lane > pa));
+        kb = rj_wmin_u64(behind ? mine : ~0ull);
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(RJ_BLOCK) void k_reject(
     const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q, uint8_t *__restrict__ keep, double *__restrict__ out4,
-    double *__restrict__ out3, const IcpDev *__restrict__ st)
+    double *__restrict__ out3, const IcpDev *__restrict__ st, int use_prior /* out4 still holds the LAST launch's (m, median, mad, kept)
+                                                                              of this run: look for both statistics in a window around them first */)
 {
     __shared__ RejectShared S;
     if (st && st->stop) return;
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const int n = (int)Q;
+    // the last launch's statistics (read before anything here overwrites them)
+    const double pcnt = use_prior ? out4[0] : 0.0, pmed = use_prior ? out4[1] : 0.0, pmad = use_prior ? out4[2] : 0.0;
+    bool win = pmad > 0.0 && pmad < __builtin_inf() && pcnt >= 1.0 && pmed == pmed;
+    const double hw_med = pmad * fmin(0.25, 75.0 / pcnt), hw_mad = pmad * fmin(0.25, 47.0 / pcnt);
+    const uint64_t wlo = ord_key(pmed - hw_med), whi = ord_key(pmed + hw_med);
     for (int i = tid; i < RJ_HC * 257; i += RJ_BLOCK) S.hc[i] = 0u;
     if (tid == 0) S.ncand = 0u;
-    unsigned cnt = 0;
+    unsigned cnt = 0, nin = 0, nbel = 0;
     double dmn = __builtin_inf(), dmx = -__builtin_inf();
     // four rows per lane and step: their loads are issued together (one workgroup has to cover the memory latency itself)
-    for (int base = tid; base < n; base += 4 * RJ_BLOCK) {
+    for (int base0 = 0; base0 < n; base0 += 4 * RJ_BLOCK) {
         double d[4];
         bool f[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = base + u * RJ_BLOCK;
+            const int i = base0 + tid + u * RJ_BLOCK;
             const int ic = i < n ? i : n - 1;
-            d[u] = dist[ic]; f[u] = flag[ic] != 0;
+            d[u] = dist[ic]; f[u] = i < n && flag[ic] != 0;
         }
+        uint64_t k4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = base + u * RJ_BLOCK;
-            if (i >= n) continue;
-            S.key[i] = f[u] ? ord_key(d[u]) : ~0ull;
+            const int i = base0 + tid + u * RJ_BLOCK;
+            k4[u] = f[u] ? ord_key(d[u]) : ~0ull;
+            if (i < n) S.key[i] = k4[u];
             if (f[u]) { cnt += 1; dmn = fmin(dmn, d[u]); dmx = fmax(dmx, d[u]); }
         }
+        if (win) rj_window_add<4>(S, 0, f, k4, wlo, whi, nin, nbel);
     }
+    if (win) rj_window_close(S, 0, nin, nbel);
     cnt = (unsigned)wsum_u64(cnt);
     dmn = rj_wmin_f64(dmn); dmx = rj_wmin_f64(-dmx);
     if (lane == 0) { S.wcnt[wid] = cnt; S.red[0][wid][0] = dmn; S.red[0][wid][1] = dmx; }
@@ -871,9 +953,9 @@ __global__ __launch_bounds__(RJ_BLOCK) void k_reject(
     long m = 0;
 #pragma unroll
     for (int w = 0; w < RJ_WAVES; ++w) { m += S.wcnt[w]; dmn = fmin(dmn, S.red[0][w][0]); dmx = fmin(dmx, S.red[0][w][1]); }
-    __syncthreads();
     if (m == 0) {
         for (int i = tid; i < n; i += RJ_BLOCK) keep[i] = 0;
+        __syncthreads();                                   // (every lane has read the prior before lane 0 overwrites it)
         if (tid == 0) {
             out4[0] = 0; out4[1] = __builtin_nan(""); out4[2] = __builtin_nan(""); out4[3] = 0;
             if (out3) { out3[0] = 0; out3[1] = __builtin_nan(""); out3[2] = __builtin_nan(""); }
@@ -881,14 +963,27 @@ __global__ __launch_bounds__(RJ_BLOCK) void k_reject(
         return;
     }
     uint64_t ka, kb;
-    lds_range_select(S, n, (m - 1) / 2, (m & 1) == 0, ord_key(dmn), ord_key(-dmx), ka, kb);
+    // (one miss ends the attempts of this launch: a median that moved takes the MAD with it)
+    if (win) win = rj_window_pick(S, 0, (m - 1) / 2, (m & 1) == 0, ka, kb);
+    __syncthreads();
+    if (!win) lds_range_select(S, n, (m - 1) / 2, (m & 1) == 0, ord_key(dmn), ord_key(-dmx), ka, kb);
     const double med = (ord_val(ka) + ord_val(kb)) / 2.0;
-    for (int i = tid; i < n; i += RJ_BLOCK) {
-        const uint64_t k = S.key[i];
-        if (k != ~0ull) S.key[i] = ord_key(fabs(ord_val(k) - med));
+    {
+        const uint64_t alo = ord_key(fmax(pmad - hw_mad, 0.0)), ahi = ord_key(pmad + hw_mad);
+        nin = 0; nbel = 0;
+        for (int i0 = 0; i0 < n; i0 += RJ_BLOCK) {
+            const int i = i0 + tid;
+            const uint64_t k = i < n ? S.key[i] : ~0ull;
+            const bool mem[1] = {k != ~0ull};
+            const uint64_t a[1] = {mem[0] ? ord_key(fabs(ord_val(k) - med)) : ~0ull};
+            if (mem[0]) S.key[i] = a[0];
+            if (win) rj_window_add<1>(S, 1, mem, a, alo, ahi, nin, nbel);
+        }
+        if (win) rj_window_close(S, 1, nin, nbel);
     }
     __syncthreads();
-    {   // |d - med| is monotone in d on either side of med: its range follows from the distances' own
+    if (win) win = rj_window_pick(S, 1, (m - 1) / 2, (m & 1) == 0, ka, kb);
+    if (!win) {   // |d - med| is monotone in d on either side of med: its range follows from the distances' own
         const double u = fabs(dmn - med), v = fabs(-dmx - med);
         lds_range_select(S, n, (m - 1) / 2, (m & 1) == 0, ord_key(0.0), ord_key(u > v ? u : v), ka, kb);
     }
@@ -1531,9 +1626,9 @@ void launch_scatter_f32(hipStream_t s, float *dst, const int64_t *rows, const fl
 }
 
 void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, const IcpDev *st,
-                   double *out3)
+                   double *out3, bool use_prior)
 {
-    hipLaunchKernelGGL(k_reject, dim3(1), dim3(RJ_BLOCK), 0, s, dist, flag, Q, keep, out4, out3, st);
+    hipLaunchKernelGGL(k_reject, dim3(1), dim3(RJ_BLOCK), 0, s, dist, flag, Q, keep, out4, out3, st, use_prior ? 1 : 0);
 }
 
 void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3, const double *also4,

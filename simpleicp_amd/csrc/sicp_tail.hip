@@ -52,6 +52,7 @@ constexpr int TB = 256;                    // 4 waves, one per SIMD: each may us
 constexpr int NW = TB / 64;
 constexpr int HC = 16;                     // privatised histogram copies of a selection round
 constexpr int CAND_MAX = 8;                // keys left when a selection stops binning and ranks them directly
+constexpr int WCAP = 64;                   // keys a selection window may hold (one per lane of the wave that ranks them)
 constexpr unsigned long long NOKEY = ~0ull;
 constexpr int ST_DOUBLES = sizeof(IcpDev) / sizeof(double);
 static_assert(sizeof(IcpDev) % sizeof(double) == 0 && ST_DOUBLES <= 64, "the loop state leaves the kernel as one 64-lane store");
@@ -77,6 +78,9 @@ struct TailShared {
     long long evt[8];                      // cycle stamps inside the last evaluation (trace build only)
 #endif
     unsigned tot[256];                     // folded histogram of a selection round
+    unsigned long long wc[2][NW][WCAP];    // windowed selection: per-wave candidate keys (one buffer per statistic: no barrier between
+    alignas(16) unsigned wci[2][NW];       //  the median's readers and the MAD's writers), how many (read as one uint4),
+    alignas(16) unsigned wbl[2][NW];       //  and how many member keys lie below the window
     unsigned long long cand[CAND_MAX];
     unsigned ncand;
     unsigned wcnt[NW];
@@ -227,6 +231,81 @@ __device__ __forceinline__ void block_select(TailShared &S, unsigned *hc, const 
         kb = b;
     }
     SICP_ST(6)
+}
+
+
+// ---- order statistics from a WINDOW (the selection of a settled run) --------------------------------------------------------
+// From a run's fourth or fifth iteration on, median and MAD of the distances are where the last iteration left them, give or take
+// a few per cent of a MAD (profiles/r6/sel_dynamics.txt) -- and the range-histogram selection above spends 4 k cycles per statistic
+// finding that out again.  So the loop state carries both (IcpDev::sel_*), and a launch first looks at a window around each: every
+// wave counts its member keys BELOW the window and lists those INSIDE it (ballot compaction, no atomics), one barrier, then every
+// wave ranks the <= 64 listed keys itself (lane i holds key i and counts the keys that sort before it: register broadcasts, no
+// LDS).  If the wanted rank (ranks) falls inside the list, that IS the exact order statistic -- same keys, same total order as
+// block_select, so the same bits; if not (the estimate still moves, the window overflows) block_select runs as before.
+// window_collect: call before a barrier;  window_pick: after it (false = the window missed).
+template <int EPT>
+__device__ __forceinline__ void window_collect(TailShared &S, int buf, const unsigned long long (&k)[EPT], unsigned long long wlo,
+                                               unsigned long long whi)
+{
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // a lane's own counts first, ONE wave prefix sum for both (inside: low half, below: high half; <= 64 * EPT each), then the
+    // lane writes its keys behind its predecessors' (a ballot + bit count per key put four dependent vector -> scalar -> vector
+    // round trips on a single wave's critical path: 1.2 k cycles against 0.25 k)
+    unsigned cin = 0, cbel = 0;
+    bool inw[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const bool mem = k[e] != NOKEY;
+        inw[e] = mem && k[e] >= wlo && k[e] <= whi;
+        cin += inw[e] ? 1u : 0u;
+        cbel += (mem && k[e] < wlo) ? 1u : 0u;
+    }
+    const unsigned incl = wscan_u32(cin | (cbel << 16));
+    unsigned slot = (incl & 0xffffu) - cin;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        if (inw[e]) { if (slot < (unsigned)WCAP) S.wc[buf][wid][slot] = k[e]; ++slot; }
+    if (lane == 63) { S.wci[buf][wid] = incl & 0xffffu; S.wbl[buf][wid] = incl >> 16; }
+}
+__device__ __forceinline__ bool window_pick(const TailShared &S, int buf, long r, bool want2, unsigned long long &ka, unsigned long long &kb)
+{
+    static_assert(NW == 4, "the four waves' counts are read as one uint4");
+    const int lane = threadIdx.x & 63;
+    const uint4 ci = *reinterpret_cast<const uint4 *>(&S.wci[buf][0]), bl = *reinterpret_cast<const uint4 *>(&S.wbl[buf][0]);
+    const unsigned n0 = ci.x, n1 = ci.y, n2 = ci.z, n3 = ci.w;
+    const unsigned n = (n0 + n1) + (n2 + n3);
+    const long below = (long)((bl.x + bl.y) + (bl.z + bl.w));
+    long t = r - below;                                          // rank inside the window
+    if (n > (unsigned)WCAP || t < 0 || t + (want2 ? 1 : 0) >= (long)n) return false;
+    unsigned long long mine = NOKEY;
+    {
+        const unsigned i = (unsigned)lane;
+        const unsigned w = i < n0 ? 0u : (i < n0 + n1 ? 1u : (i < n0 + n1 + n2 ? 2u : 3u));
+        const unsigned base = w == 0u ? 0u : (w == 1u ? n0 : (w == 2u ? n0 + n1 : n0 + n1 + n2));
+        if (i < n) mine = S.wc[buf][w][i - base];
+    }
+    // the key of rank t among the n listed ones, by QUICKSELECT on the total order (key, lane) with wave-uniform bookkeeping: the
+    // pivot is the first lane still in play (the list is in no particular order), one ballot counts the keys before it -- a
+    // handful of rounds of ~10 instructions where counting every key against every other took n rounds
+    unsigned long long active = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+    int pa = 0;
+#pragma unroll 1
+    for (;;) {
+        const int p = __ffsll((long long)active) - 1;
+        const unsigned long long pv = readlane_u64(mine, p);
+        const unsigned long long less = __ballot(mine < pv || (mine == pv && lane < p)) & active;
+        const long c = (long)__popcll((long long)less);
+        if (c == t) { ka = pv; pa = p; break; }
+        if (c > t) active = less;
+        else { active &= ~less & ~(1ull << p); t -= c + 1; }
+    }
+    kb = ka;
+    if (want2) {
+        // the successor of (ka, pa) in that order: the smallest listed key behind it
+        const bool behind = (unsigned)lane < n && (mine > ka || (mine == ka && lane > pa));
+        kb = wmin_u64(behind ? mine : NOKEY);
+    }
+    return true;
 }
 
 template <int EPT>
@@ -486,6 +565,8 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
     const double w_state = st->w, prev_mean = st->prev_mean, prev_std = st->prev_std;
     const int done_iters = st->done_iters;
     const int stop = st->stop;
+    const double pmed = st->sel_med, pmad = st->sel_mad;               // the last launch's median and MAD (0: none) ...
+    const int pcnt = st->sel_m;                                        // ... of this many distances
     Corr<EPT> C;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -519,6 +600,12 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         if (fl[e]) { key[e] = okey(d[e]); dmn = fmin(dmn, d[e]); dmx = fmax(dmx, d[e]); }
         nflag += (unsigned)__popcll((long long)__ballot(fl[e]));
     }
+    // a settled run: both statistics are looked for in a window around the last launch's first (window_collect).  Half widths in
+    // units of the MAD, sized for ~40 of the `pcnt` keys (a normal density holds 0.27 n keys per MAD at its median, 0.43 n of the
+    // absolute deviations at theirs)
+    bool win = A.window != 0 && pmad > 0.0 && pmad < __builtin_inf() && pcnt > 0;
+    const double hw_med = pmad * fmin(0.25, 75.0 / (double)pcnt), hw_mad = pmad * fmin(0.25, 47.0 / (double)pcnt);
+    if (win) window_collect<EPT>(S, 0, key, okey(pmed - hw_med), okey(pmed + hw_med));
     // survivors of the planarity test and the range of their distances: wave reductions + one barrier
     dmn = wmin_f64(dmn); dmx = wmin_f64(-dmx);
     if ((tid & 63) == 0) { S.wcnt[wid] = nflag; S.dmm[wid][0] = dmn; S.dmm[wid][1] = dmx; }
@@ -555,6 +642,10 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
             const double u = fabs(oval(klo) - med), v = fabs(oval(khi) - med);
             klo = okey(0.0); khi = okey(u > v ? u : v);
             tsel = clock64();
+            if (win) {
+                window_collect<EPT>(S, 1, key, okey(fmax(pmad - hw_mad, 0.0)), okey(pmad + hw_mad));
+                __syncthreads();
+            }
         }
         unsigned long long ka, kb;
         int nr = 0;
@@ -562,7 +653,9 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         if (tid == 0) S.selw = which;
         __syncthreads();
 #endif
-        block_select<EPT>(S, hc, key, (m - 1) / 2, (m & 1) == 0, klo, khi, ka, kb, nr);
+        // (one miss ends the attempts of this launch: a median that moved takes the MAD with it)
+        if (win) win = window_pick(S, which, (m - 1) / 2, (m & 1) == 0, ka, kb);
+        if (!win) block_select<EPT>(S, hc, key, (m - 1) / 2, (m & 1) == 0, klo, khi, ka, kb, nr);
         const double mid = (oval(ka) + oval(kb)) / 2.0;
         if (which == 0) { med = mid; rounds[0] = nr; } else { mad = mid; rounds[1] = nr; }
     }
@@ -771,7 +864,8 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
             n.Hinv.m[4 * i + 3] = -(Hn[i] * Hn[3] + Hn[4 + i] * Hn[7] + Hn[8 + i] * Hn[11]);
         }
         n.w = w; n.prev_mean = rmean; n.prev_std = rstd;
-        n.done_iters = done_iters + 1; n.stop = (conv || !finite) ? 1 : 0; n.pad[0] = 0; n.pad[1] = 0;
+        n.done_iters = done_iters + 1; n.stop = (conv || !finite) ? 1 : 0; n.sel_m = (int)m; n.pad = 0;
+        n.sel_med = med; n.sel_mad = mad;
         const double *src = reinterpret_cast<const double *>(&n);
 #pragma unroll
         for (int j = 0; j < ST_DOUBLES; ++j) S.out[j] = src[j];

@@ -90,6 +90,51 @@ def exchange_best_match(d2, idx, xyz, group=None):
     return d2, idx, xyz
 
 
+_SIGN = -(1 << 63)          # int64 whose bit pattern is 0x8000...: XOR with it maps unsigned order onto signed order
+
+
+def allreduce_u64(bits, take_max, group=None):
+    """In place: element-wise UNSIGNED minimum / maximum over the ranks of 8-byte words held as an int64 tensor (torch has no
+    uint64 reductions): flipping the sign bit maps the unsigned order onto the signed one, the reduction runs on that, the flip is
+    undone.  What SICP_XCHG_MIN_U64 / SICP_XCHG_MAX_U64 ask of a callback (include/simpleicp_hip.h)."""
+    import torch.distributed as td
+    bits ^= _SIGN
+    td.all_reduce(bits, op=td.ReduceOp.MAX if take_max else td.ReduceOp.MIN, group=group)
+    bits ^= _SIGN
+    return bits
+
+
+def exchange_best_keys(d2, idx, xyz, group=None):
+    """The job-wide lexicographic (d2, idx) winner by THREE reductions on 8-byte keys instead of gathering every rank's record --
+    the torch restatement of the library's `exchange_best_keys_chained` (sicp_comm.cpp; kernels k_xkey_* in sicp_kernels.hip),
+    which cloud shards use from SICP_XCHG_KEYS_MIN_Q queries on.  In place on (d2[Q] f64, idx[Q] int64 GLOBAL indices, xyz[Q,3]);
+    idx == -1 / d2 == +inf marks "no candidate here".
+      1. min over ranks of the squared distance's bit pattern (non-negative doubles order like their bits as unsigned integers;
+         all-ones = no candidate);
+      2. min over ranks of the index, offered only by the ranks whose distance IS that minimum (all-ones otherwise): together the
+         lexicographic minimum -- and since indices are global and the shards disjoint, exactly ONE rank owns the winner;
+      3. max over ranks of the winner's coordinates as bit patterns, the owner's against zeros -- bit-exact where a sum would turn
+         -0.0 into +0.0.
+    Equals `exchange_best_match` word for word (tests/test_dist_gloo.py)."""
+    import torch
+    all_ones = -1                                            # int64 view of 0xffff...
+    none = idx < 0
+    key = d2.contiguous().view(torch.int64).clone()
+    key[none] = all_ones
+    gmin = allreduce_u64(key, False, group)
+    mine = (~none) & (d2.contiguous().view(torch.int64) == gmin)
+    ikey = torch.where(mine, idx, torch.full_like(idx, all_ones))
+    gidx = allreduce_u64(ikey.clone(), False, group)
+    own = (~none) & (idx == gidx)
+    xb = torch.where(own.unsqueeze(1), xyz.contiguous().view(torch.int64), torch.zeros_like(xyz, dtype=torch.int64)).contiguous()
+    allreduce_u64(xb.view(-1), True, group)
+    nobody = gmin == all_ones
+    d2.copy_(torch.where(nobody, torch.full_like(d2, float("inf")), gmin.view(torch.float64)))
+    idx.copy_(torch.where(nobody, torch.full_like(idx, -1), gidx))
+    xyz.copy_(torch.where(nobody.unsqueeze(1), torch.zeros_like(xyz), xb.view(torch.float64).view_as(xyz)))
+    return d2, idx, xyz
+
+
 def allreduce_sum(buf, group=None):
     import torch.distributed as td
     td.all_reduce(buf, op=td.ReduceOp.SUM, group=group)
@@ -249,21 +294,25 @@ def make_exchange(ctx, group=None, synchronous=None):
     lib_stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev)
     views = {}
 
-    def view(ptr, count):
-        key = (ptr, count)
+    def view(ptr, count, typestr="<f8"):
+        key = (ptr, count, typestr)
         t = views.get(key)
         if t is None:
             if len(views) > 64:
                 views.clear()
-            t = views[key] = _wrap(ptr, (count,), "<f8", dev)
+            t = views[key] = _wrap(ptr, (count,), typestr, dev)
         return t
+
+    serve_u64 = os.environ.get("SICP_XCHG_U64", "1") != "0"      # =0: answer like a callback written for ABI 5 (tests of the decline)
 
     host_staged = td.get_backend(group) == "gloo"      # a group without GPU collectives: stage through host memory, blocking
 
     def fn_host(what, a, b, c, count):
+        if what in (_lib.XCHG_MIN_U64, _lib.XCHG_MAX_U64) and count == 0:
+            return 0 if serve_u64 else 1                # the library's question at registration: is the operation served?
         with torch.cuda.device(dev):
             lib_stream.synchronize()
-            send = view(a, count).cpu()
+            send = view(a, count).cpu() if what in (_lib.XCHG_ALLGATHER_F64, _lib.XCHG_SUM_F64) else None
             if what == _lib.XCHG_ALLGATHER_F64:
                 recv = torch.empty(count * world, dtype=torch.float64)
                 allgather_into(recv, send, group)
@@ -271,6 +320,10 @@ def make_exchange(ctx, group=None, synchronous=None):
             elif what == _lib.XCHG_SUM_F64:
                 allreduce_sum(send, group)
                 view(a, count).copy_(send)
+            elif what in (_lib.XCHG_MIN_U64, _lib.XCHG_MAX_U64) and serve_u64:
+                bits = view(a, count, "<i8").cpu()
+                allreduce_u64(bits, what == _lib.XCHG_MAX_U64, group)
+                view(a, count, "<i8").copy_(bits)
             else:
                 return 1
             torch.cuda.synchronize(dev)
@@ -279,6 +332,8 @@ def make_exchange(ctx, group=None, synchronous=None):
     def fn(what, a, b, c, count):
         if host_staged:
             return fn_host(what, a, b, c, count)
+        if what in (_lib.XCHG_MIN_U64, _lib.XCHG_MAX_U64) and count == 0:
+            return 0 if serve_u64 else 1
         with torch.cuda.device(dev), torch.cuda.stream(lib_stream):
             if synchronous:
                 lib_stream.synchronize()
@@ -286,6 +341,8 @@ def make_exchange(ctx, group=None, synchronous=None):
                 allgather_into(view(b, count * world), view(a, count), group)
             elif what == _lib.XCHG_SUM_F64:
                 allreduce_sum(view(a, count), group)
+            elif what in (_lib.XCHG_MIN_U64, _lib.XCHG_MAX_U64) and serve_u64:
+                allreduce_u64(view(a, count, "<i8"), what == _lib.XCHG_MAX_U64, group)      # (two in-place XORs around the collective, same stream)
             else:
                 return 1
             if synchronous:

@@ -129,7 +129,8 @@ class SimpleICP:
         upload_movable()
         self._job = {"ranks": world, "partition": None, "exchange": None}
         if sharded:
-            how = dist.attach(ctx, gn_shard=(not qshard) and (correspondences >= 262144 or os.environ.get("SICP_GN_SHARD") == "1"),
+            how = dist.attach(ctx, gn_shard=(not qshard) and os.environ.get("SICP_GN_SHARD", "") != "0"
+                              and (correspondences >= 262144 or os.environ.get("SICP_GN_SHARD") == "1"),
                               partition=_lib.PART_QUERIES if qshard else _lib.PART_CLOUD)
             self._job.update(partition="queries" if qshard else "cloud", exchange=how)
         else:
@@ -267,6 +268,10 @@ class SimpleICP:
             pc2.write_xyz(Path(debug_dirpath).joinpath(f"iteration{it:03d}_postoptim_pcmov.xyz"))
 
         self.last_run_info = {"iterations": it + 1, "stats": stats, "seconds": time.time() - t_start, **getattr(self, "_job", {})}
+        if sharded:
+            # how the shards' winners met: "records_allgather" / "key_allreduces" (cloud shards) / "query_slices", and how often
+            xi = ctx.exchange_info()
+            self.last_run_info.update(winner_exchange=xi["form"], exchanges=xi["count"])
         _log.info(f"Finished in {time.time() - t_start:.3f} seconds!")
         return H, X_new, rbp, residuals
 

@@ -57,6 +57,8 @@ def build_calls():
         "sicp_match_work": lambda: L.sicp_match_work(None, buf),
         "sicp_match_deferred": lambda: L.sicp_match_deferred(None, C.cast(buf, C.POINTER(C.c_uint64))),
         "sicp_tail_cycles": lambda: L.sicp_tail_cycles(None, buf),
+        "sicp_tail_selection": lambda: L.sicp_tail_selection(None, buf),
+        "sicp_exchange_info": lambda: L.sicp_exchange_info(None, buf),
         "sicp_knn_work": lambda: L.sicp_knn_work(None, buf),
         "sicp_last_match_kernel": lambda: L.sicp_last_match_kernel(None, C.byref(ci)),
         "sicp_xyz_count": lambda: L.sicp_xyz_count(None, C.byref(i64)),

@@ -35,6 +35,7 @@ def _worker(rank, world, port, tmp):
         n, q = 30_001, 700
         Xm = np.round(rng.uniform(-5, 5, (n, 3)), 1)         # quantised -> exact ties across shards
         Xm[n // 2:n // 2 + 200] = Xm[:200]                   # duplicates living in different shards
+        Xm[Xm == 0.0] = -0.0                                 # coordinates whose bit pattern a SUM would not carry (the key exchange's max must)
         Qp = np.round(rng.uniform(-5, 5, (q, 3)), 1)
         H = orc.params_to_H(np.array([0.1, -0.2, 0.05, 0.3, 0.1, -0.2]))
         lo, hi = dist.shard_bounds(n, rank, world)
@@ -52,6 +53,19 @@ def _worker(rank, world, port, tmp):
             assert np.array_equal(t_xyz.numpy()[ok], Xm[fidx[ok, 0]]) and np.all(t_xyz.numpy()[~ok] == 0)
             if np.isfinite(max_dist):
                 assert (~ok).any() and ok.any()
+            # the same winner by three reductions on 8-byte keys (cloud shards of many queries; sicp_comm.cpp:
+            # exchange_best_keys_chained): min of the distance's bits, min of the index among the holders of that minimum, max of
+            # the owner's coordinate bits -- equal to the gathered records' lexicographic minimum word for word, signs of zeros included
+            k_d2, k_idx, k_xyz = torch.from_numpy(d2.copy()), torch.from_numpy(idx.copy()), torch.from_numpy(xyz.copy())
+            dist.exchange_best_keys(k_d2, k_idx, k_xyz)
+            assert np.array_equal(k_idx.numpy(), t_idx.numpy()) and np.array_equal(k_d2.numpy(), t_d2.numpy())
+            assert np.array_equal(k_xyz.numpy().view(np.int64), t_xyz.numpy().view(np.int64))
+            assert np.signbit(k_xyz.numpy()[ok]).any() and (k_xyz.numpy()[ok] == 0).any()          # (-0.0 did travel)
+            # exact ties ACROSS shards were among the cases: a winner whose distance another rank holds too
+            gd2 = [torch.empty_like(t_d2) for _ in range(world)]
+            td.all_gather(gd2, torch.from_numpy(d2))
+            holders = sum((g.numpy() == t_d2.numpy()) & np.isfinite(g.numpy()) for g in gd2)
+            assert (holders >= 2).any()
 
         # query shards (SURVEY 8e "alternative"): every rank matches its slice of the queries in the WHOLE cloud;
         # gathering the slices in rank order restores the full result -- no reduction, bit-exact by construction

@@ -212,7 +212,119 @@ def test_bench_two_ranks_self_launched(partition, launcher):
     # the record says what exchange ran, as the library counts it
     assert d["comm"]["backend"] == "callback" and d["comm"]["nranks"] == 2 and d["comm"]["partition"] == partition, d["comm"]
     assert d["comm"]["exchanges_timed"] == 6 and d["comm"]["exchange_us_per_iteration"] > 0
-    # the throughput leg ran under query shards on both ranks and met the oracle
+    # the throughput leg ran under query shards on both ranks (cloud shards when the caller pinned them: then the winners met by the
+    # three reductions on 8-byte keys -- 40 000 queries are above the threshold) and met the oracle
     tp = d["throughput_point"]
-    assert tp["n_gpus"] == 2 and tp["comm"]["partition"] == "queries" and tp["comm"]["queries_this_rank"] == (tp["correspondences"] + 1) // 2
+    assert d["comm"]["winner_exchange"] == ("query_slices" if partition == "queries" else "records_allgather"), d["comm"]
+    if partition == "cloud":
+        assert tp["n_gpus"] == 2 and tp["comm"]["partition"] == "cloud" and tp["comm"]["queries_this_rank"] == tp["correspondences"]
+        assert tp["comm"]["winner_exchange"] == "key_allreduces" and tp["comm"]["shard_rows_this_rank"] == 150_000, tp["comm"]
+    else:
+        assert tp["n_gpus"] == 2 and tp["comm"]["partition"] == "queries" and tp["comm"]["queries_this_rank"] == (tp["correspondences"] + 1) // 2
+        assert tp["comm"]["winner_exchange"] == "query_slices", tp["comm"]
     assert tp["parity"]["ok"] is True and tp["roofline"]["kernel"] in ("k_grid_nn", "k_grid_nn16", "k_grid_nn16f"), tp
+
+
+WORKER_KEYS = r"""
+import os, sys, json, numpy as np
+rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+sys.path.insert(0, "%(root)s"); sys.path.insert(0, "%(root)s/tests")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SIMPLEICP_DEVICE="0", SICP_PARTITION="cloud")
+cases = json.loads(os.environ["SICP_TEST_CASES"])
+import bench
+from simpleicp_amd import PointCloud, SimpleICP, backend
+if world > 1:
+    import torch, torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+res = {}
+for case in cases:
+    for k, v in case.get("env", {}).items():
+        os.environ[k] = v
+    backend.reset_context()
+    Xf, Xm, _ = bench.synthetic_pair(case["n"])
+    if case.get("sorted"):                       # index shards = slabs along x: spatially DISJOINT shards
+        Xm = Xm[np.argsort(Xm[:, 0], kind="stable")]
+    pf = PointCloud(Xf, columns=["x", "y", "z"]); pm = PointCloud(Xm, columns=["x", "y", "z"])
+    icp = SimpleICP(verbose=False); icp.add_point_clouds(pf, pm)
+    ctx = backend.get_context()
+    ctx.timing_enable(True, count_work=True); ctx.timing_reset()
+    H, X, rbp, r = icp.run(correspondences=case["q"], max_iterations=case["its"], min_change=0.0)
+    info = icp.last_run_info
+    work = ctx.match_work(); ctx.timing_enable(False)
+    if world > 1:
+        assert info["ranks"] == world and info["exchange"] == "callback" and info["partition"] == "cloud", info
+        assert info["winner_exchange"] == case["form"] and info["exchanges"] == case["its"], info
+        assert ctx.last_match_kernel() == case["kernel"], ctx.last_match_kernel()
+    name = case["name"]
+    res[name + "_H"] = H; res[name + "_r"] = r; res[name + "_X"] = X[:: max(1, len(X) // 5000)]
+    res[name + "_cand"] = np.array([work["candidates"] / (case["q"] * case["its"])])
+    for k in case.get("env", {}):
+        del os.environ[k]
+if world > 1:
+    td.barrier(); td.destroy_process_group()
+np.savez(out, **res)
+print("RANK_OK", rank)
+"""
+
+
+def _run_key_workers(tmp_path, cases, world):
+    import json
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / f"worker_keys{world}.py"
+    script.write_text(WORKER_KEYS % {"root": str(ROOT)})
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SICP_")}
+    env["SICP_TEST_CASES"] = json.dumps(cases)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(port), str(tmp_path / f"w{world}_rank{r}.npz")], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=1200)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs) and all("RANK_OK" in o for o in outs), "\n".join(o[-3000:] for o in outs)
+    return [np.load(tmp_path / f"w{world}_rank{r}.npz") for r in range(world)]
+
+
+def test_two_ranks_key_exchange_equals_one_rank(tmp_path):
+    """The DEFAULT exchange of cloud shards from 32 768 queries -- three reductions on 8-byte keys (sicp_comm.cpp:
+    exchange_best_keys_chained; min of the distance's bits, min of the index among the holders of that minimum, max of the owner's
+    coordinate bits) -- with TWO real shards on hardware: two processes share cuda:0 over a gloo group whose callback serves
+    SICP_XCHG_MIN_U64 / MAX_U64 (ABI 6).  Q = 40 000 (four queries per wave) and Q = 262 144 (the float32-filtered search, whose
+    slot bounds the exchange refreshes), the solver replicated: H, the residuals and the transformed cloud bit-identical to the
+    one-process run; with the sharded 6x6 reduction (the default from 262 144 correspondences): equal to rounding.  A callback
+    that declines the new operations (an ABI-5 host) keeps the all-gather of records -- same bits."""
+    cases = [
+        dict(name="q40k", n=600_000, q=40_000, its=6, form="key_allreduces", kernel="k_grid_nn16", env={"SICP_GN_SHARD": "0"}),
+        dict(name="q40k_declined", n=600_000, q=40_000, its=6, form="records_allgather", kernel="k_grid_nn16",
+             env={"SICP_GN_SHARD": "0", "SICP_XCHG_U64": "0"}),
+        dict(name="q262k", n=600_000, q=262_144, its=6, form="key_allreduces", kernel="k_grid_nn16f", env={"SICP_GN_SHARD": "0"}),
+        dict(name="q262k_gn", n=600_000, q=262_144, its=6, form="key_allreduces", kernel="k_grid_nn16f", env={}),
+    ]
+    one = _run_key_workers(tmp_path, cases, 1)[0]
+    two = _run_key_workers(tmp_path, cases, 2)
+    for z in two:
+        for c in cases:
+            n = c["name"]
+            if n.endswith("_gn"):
+                assert np.abs(z[n + "_H"] - one[n + "_H"]).max() < 1e-9 and np.abs(z[n + "_r"] - one[n + "_r"]).max() < 1e-9
+            else:
+                assert np.array_equal(z[n + "_H"], one[n + "_H"]) and np.array_equal(z[n + "_r"], one[n + "_r"]) \
+                    and np.array_equal(z[n + "_X"], one[n + "_X"]), (n, np.abs(z[n + "_H"] - one[n + "_H"]).max())
+
+
+def test_spatially_disjoint_shards_search_from_the_job_wide_winner(tmp_path):
+    """under cloud shards the filtered search bounds a slot by what IT left there -- this rank's own winner.
+    With index shards that are slabs of the cloud (a cloud stored in scan order) half of every rank's queries have their answer on the
+    other rank, and without the refresh (k_slot_bounds behind the exchange) each of those searches goes out to its far-away local
+    neighbour in every iteration.  Same bits as one rank either way; the tallied candidates per query and iteration must stay at the
+    one-rank figure's order (each rank reads its half of the cloud's cells: about half the candidates, not hundreds of times more)."""
+    env = {"SICP_GN_SHARD": "0", "SICP_NN16F_MIN_Q": "50000"}
+    cases = [dict(name="slabs1", n=600_000, q=100_000, its=1, form="key_allreduces", kernel="k_grid_nn16f", sorted=True, env=env),
+             dict(name="slabs", n=600_000, q=100_000, its=8, form="key_allreduces", kernel="k_grid_nn16f", sorted=True, env=env)]
+    one = _run_key_workers(tmp_path, cases, 1)[0]
+    two = _run_key_workers(tmp_path, cases, 2)
+    # candidates per query of iterations 1..7 (the cold iteration 0 has no bound on any rank: a rank's far queries walk out to its
+    # own shard once; from then on the exchange's winner bounds them)
+    later = lambda z: (8 * float(z["slabs_cand"][0]) - float(z["slabs1_cand"][0])) / 7
+    for z in two:
+        assert np.array_equal(z["slabs_H"], one["slabs_H"]) and np.array_equal(z["slabs_r"], one["slabs_r"])
+        assert later(z) <= 1.25 * later(one), (later(z), later(one), float(z["slabs1_cand"][0]), float(one["slabs1_cand"][0]))

@@ -1,4 +1,5 @@
 """Parity of the HIP kernels (through the C ABI) against the CPU oracle.  GPU only."""
+import os
 import numpy as np
 import pytest
 
@@ -1003,3 +1004,60 @@ def test_knn_sweep_random_clouds(seed):
     if kind in (0, 4, 5):
         assert ok.all()
         assert np.abs(nv - rnv).max() <= 2e-7 and np.abs(pl - rpl).max() <= 2e-6 * max(1.0, np.abs(rpl).max())
+
+
+@pytest.mark.parametrize("Q", [40, 300, 1000, 1500, 2048, 2049, 6000, 16_384])
+@pytest.mark.parametrize("kind", ["plain", "quantised", "layers"])
+def test_tail_window_selection_equals_the_histogram_selection(Q, kind):
+    """The single-workgroup tail of a chained run looks for median and MAD in a window around the last iteration's values first
+    (sicp_tail.hip: window_collect / window_pick) and falls back to the range-histogram selection when the wanted rank is not inside.
+    Same keys, same order statistic: a run with the windows on must reproduce the run with them off (SICP_TAIL_WINDOW=0) bit for
+    bit -- every iteration's median, MAD, counts, estimate and residual statistics -- and the windows must actually have been used
+    once the estimate has settled.  `layers`: thousands of exactly equal distances (a window full of one key value: more members
+    than it holds -> the fallback, every iteration).  Above 2048 correspondences the one-workgroup rejection (k_reject, keys in LDS)
+    does the same from the statistics its last launch left."""
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(Q)
+    n = 60_000
+    if kind == "layers":
+        P = np.column_stack((rng.uniform(0, 30, n), rng.uniform(0, 30, n), np.zeros(n)))
+        Xm = P + np.array([0.0, 0.0, 0.25]) * rng.integers(0, 3, n)[:, None]
+        Xm[:, :2] += 0.001
+    else:
+        P = _surface(n, 50 + (Q % 5))
+        x_true = np.array([0.004, -0.003, 0.006, 0.08, -0.05, 0.03])
+        Xm = orc.transform(np.linalg.inv(orc.params_to_H(x_true)), P + rng.normal(0, 0.01, P.shape))
+        if kind == "quantised":
+            P, Xm = np.round(P, 2), np.round(Xm, 2)
+    sel = np.sort(rng.choice(n, Q, replace=False))
+    z = np.zeros(6)
+    ow = np.full(6, np.inf) if kind == "layers" else z            # (layers: match + rejection only)
+    runs = {}
+    for window in ("1", "0"):
+        os.environ["SICP_TAIL_WINDOW"] = window
+        try:
+            c = _lib.Context(0)
+        finally:
+            del os.environ["SICP_TAIL_WINDOW"]
+        c.upload(_lib.FIX, P); c.upload(_lib.MOV, Xm)
+        if kind == "layers":
+            nv = np.tile(np.array([0, 0, 1], np.float32), (Q, 1)); pl = np.ones(Q, np.float32)
+        else:
+            nv, pl = c.estimate_normals(_lib.FIX, sel, 10)
+        c.icp_setup(sel, nv, pl)
+        R = c.icp_run(z, z, ow, 0.3, None if kind != "layers" else 1.0, max_iterations=16, min_change=0.0)
+        runs[window] = ([(r.median, r.mad, r.n_planar, r.n_kept, tuple(r.x[:]), r.res_mean, r.res_std, r.dist_mean, r.dist_std, r.lm_steps)
+                         for r in R], c.icp_state(), c.tail_selection())
+        c.close()
+    on, off = runs["1"], runs["0"]
+    assert len(on[0]) == len(off[0]) == 16 and on[0] == off[0]
+    for a, b in zip(on[1], off[1]):
+        assert np.array_equal(a, b)
+    assert off[2]["window_iterations"] == 0
+    if Q > 2048:
+        return                                                      # (k_reject keeps no tally: equality is the test)
+    if kind == "layers":
+        assert on[2]["window_iterations"] == 0                     # a window cannot hold thousands of equal keys: always the fallback
+    else:
+        assert on[2]["window_iterations"] >= 6, on[2]
+        assert on[2]["median_rounds"] == 0 and on[2]["mad_rounds"] == 0
