@@ -15,7 +15,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libsimpleicp_hip.so"
-SOURCES = [CSRC / "sicp_api.cpp", CSRC / "sicp_clouds.cpp", CSRC / "sicp_search.cpp", CSRC / "sicp_icp.cpp", CSRC / "sicp_comm.cpp", CSRC / "sicp_kernels.hip", CSRC / "sicp_grid.hip", CSRC / "sicp_gridf.hip", CSRC / "sicp_tail.hip", CSRC / "sicp_lm.hip", CSRC / "sicp_io.cpp"]
+SOURCES = [CSRC / "sicp_api.cpp", CSRC / "sicp_clouds.cpp", CSRC / "sicp_search.cpp", CSRC / "sicp_icp.cpp", CSRC / "sicp_comm.cpp", CSRC / "sicp_kernels.hip", CSRC / "sicp_grid.hip", CSRC / "sicp_gridf.hip", CSRC / "sicp_tail.hip", CSRC / "sicp_reject.hip", CSRC / "sicp_lm.hip", CSRC / "sicp_io.cpp"]
 HEADERS = [CSRC / "sicp_internal.h", CSRC / "sicp_host.h", CSRC / "sicp_lanes.h", CSRC / "sicp_solver.h", CSRC / "sicp_normals.h", CSRC / "sicp_grid_dev.h", PKG.parent / "include" / "simpleicp_hip.h"]
 # -amdgpu-mfma-vgpr-form: MFMA results land in ordinary VGPRs (gfx950's register file is unified), so the VALU work
 # that consumes them (min trees of the matrix-pipe filter, Gram folds) needs no v_accvgpr_read per register

@@ -692,328 +692,7 @@ __global__ void k_scatter_f32(float *__restrict__ dst, const int64_t *__restrict
     if (i < m) dst[rows[i]] = vals[i];
 }
 
-// ------------------------------------------------------------------------------------
-// K6: median / raw-MAD rejection      corrpts.py:165-188  (np.median: mean of the two
-// middle values for even counts; scipy median_abs_deviation with scale = 1.0)
-//
-// One 1024-lane workgroup, one launch, Q <= REJECT_MAX_Q: the order-preserving uint64 images of the flagged
-// distances are staged in LDS ONCE (128 KB of the CU's 160 KB; unflagged rows hold an all-ones sentinel) and every
-// later pass reads LDS.  Exact order statistics by RANGE-HISTOGRAM SELECTION (the small-Q tail's algorithm,
-// sicp_tail.hip): 256 bins over the current key interval -- counted in 16 privatised copies, because distances share
-// their leading bits and same-address LDS atomics serialise per lane --, the bin that holds the wanted rank becomes
-// the next interval (2-3 rounds on real distances instead of 8 radix passes), the last <= 8 keys are ranked with one
-// ballot.  FUSED (chained runs): the kernel also computes the point-to-plane distances and planarity flags it
-// rejects on (corrpts.py:139-163,195-211; H from the device loop state) and the kept distances' count / mean /
-// std (simpleicp.py:233-234) -- three launches of the multi-kernel tail in one.
-// out4[0]=m (planarity survivors) out4[1]=median out4[2]=mad out4[3]=n_kept;  out3 = n, mean, std of the kept
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t ord_key(double v)
-{
-    const uint64_t b = (uint64_t)__double_as_longlong(v);
-    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double ord_val(uint64_t k)
-{
-    const uint64_t b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)b);
-}
-
-constexpr int RJ_BLOCK = 1024, RJ_WAVES = RJ_BLOCK / 64, RJ_HC = 16, RJ_CAND = 8;
-constexpr int RJ_WCAP = 64, RJ_WSEG = 32;          // keys a selection window may hold in all / per wave (sicp_tail.hip: window_collect)
-struct RejectShared {
-    uint64_t key[REJECT_MAX_Q];
-    uint64_t wc[2][RJ_WAVES][RJ_WSEG];             // windowed selection: per-wave candidate keys, one buffer per statistic
-    unsigned wci[2][RJ_WAVES], wbl[2][RJ_WAVES];   // ... how many, and how many member keys lie below the window
-    unsigned hc[RJ_HC * 257];
-    unsigned tot[256];
-    uint64_t cand[RJ_CAND];
-    unsigned ncand;
-    uint64_t wmin[RJ_WAVES];
-    double red[2][RJ_WAVES][4];
-    unsigned wcnt[RJ_WAVES];
-};
-
-__device__ __forceinline__ uint64_t rj_wmin_u64(uint64_t v)
-{
-    unsigned long long o;
-    o = lane_xor64<32>(v); v = o < v ? o : v;  o = lane_xor64<16>(v); v = o < v ? o : v;
-    o = lane_xor64<8>(v);  v = o < v ? o : v;  o = lane_xor64<4>(v);  v = o < v ? o : v;
-    o = lane_xor64<2>(v);  v = o < v ? o : v;  o = lane_xor64<1>(v);  v = o < v ? o : v;
-    return v;
-}
-__device__ __forceinline__ double rj_wmin_f64(double v)
-{
-    v = fmin(v, lane_xor_f64<32>(v)); v = fmin(v, lane_xor_f64<16>(v)); v = fmin(v, lane_xor_f64<8>(v));
-    v = fmin(v, lane_xor_f64<4>(v));  v = fmin(v, lane_xor_f64<2>(v));  v = fmin(v, lane_xor_f64<1>(v));
-    return v;
-}
-__device__ __forceinline__ uint64_t rj_readlane_u64(uint64_t v, int l)
-{
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// keys of rank r and (want2) r + 1 among the member keys (!= ~0) of S.key[0..n); [lo, hi] contains them all.
-// S.hc and S.ncand are zero on entry and on exit.
-__device__ void lds_range_select(RejectShared &S, int n, long r, bool want2, uint64_t lo, uint64_t hi, uint64_t &ka, uint64_t &kb)
-{
-    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-    const uint64_t NOKEY = ~0ull;
-    uint64_t below = 0;
-    unsigned cs = 0;
-    int sh = 0;
-    unsigned *mycopy = S.hc + (lane & (RJ_HC - 1)) * 257;
-    for (int round = 0; round < 10; ++round) {
-        const uint64_t range = hi - lo;
-        sh = range < 256ull ? 0 : (64 - __clzll((long long)range)) - 8;
-        for (int i = tid; i < n; i += RJ_BLOCK) {
-            const uint64_t k = S.key[i];
-            if (k != NOKEY && k >= lo && k <= hi) atomicAdd(&mycopy[(unsigned)((k - lo) >> sh)], 1u);
-        }
-        __syncthreads();
-        if (tid < 256) {
-            unsigned tot = 0;
-#pragma unroll
-            for (int c = 0; c < RJ_HC; ++c) { tot += S.hc[c * 257 + tid]; S.hc[c * 257 + tid] = 0u; }
-            S.tot[tid] = tot;
-        }
-        __syncthreads();
-        const uint4 h4 = *reinterpret_cast<const uint4 *>(&S.tot[4 * lane]);
-        const unsigned mine = h4.x + h4.y + h4.z + h4.w;
-        const unsigned incl = wscan_u32(mine);
-        const uint64_t t = (uint64_t)r - below;
-        const unsigned long long gt = __ballot((uint64_t)incl > t);
-        const int L = __ffsll((long long)gt) - 1;
-        const unsigned eL = (unsigned)__builtin_amdgcn_readlane((int)(incl - mine), L);
-        const unsigned a0 = (unsigned)__builtin_amdgcn_readlane((int)h4.x, L), a1 = (unsigned)__builtin_amdgcn_readlane((int)h4.y, L);
-        const unsigned a2 = (unsigned)__builtin_amdgcn_readlane((int)h4.z, L), a3 = (unsigned)__builtin_amdgcn_readlane((int)h4.w, L);
-        unsigned acc = eL; int j = 0; cs = a0;
-        if (t >= (uint64_t)acc + a0) { acc += a0; j = 1; cs = a1;
-            if (t >= (uint64_t)acc + a1) { acc += a1; j = 2; cs = a2;
-                if (t >= (uint64_t)acc + a2) { acc += a2; j = 3; cs = a3; } } }
-        below += acc;
-        lo = lo + ((uint64_t)(4u * (unsigned)L + (unsigned)j) << sh);
-        if (sh > 0) { const uint64_t top = lo + ((1ull << sh) - 1ull); hi = top < hi ? top : hi; } else hi = lo;
-        if (cs <= (unsigned)RJ_CAND || sh == 0) break;
-    }
-    const uint64_t t = (uint64_t)r - below;
-    const bool need_above = want2 && t + 1 >= cs;
-    if (sh == 0 || lo == hi) {
-        ka = lo; kb = lo;
-    } else {
-        for (int i = tid; i < n; i += RJ_BLOCK) {
-            const uint64_t k = S.key[i];
-            if (k != NOKEY && k >= lo && k <= hi) { const unsigned slot = atomicAdd(&S.ncand, 1u); if (slot < (unsigned)RJ_CAND) S.cand[slot] = k; }
-        }
-        __syncthreads();
-        if (tid == 0) S.ncand = 0u;
-        const int ci = lane >> 3, cj = lane & 7;
-        const uint64_t vi = S.cand[ci], vj = S.cand[cj];
-        const bool before = ci != cj && (unsigned)ci < cs && (unsigned)cj < cs && (cj < ci ? vj <= vi : vj < vi);
-        const unsigned long long M = __ballot(before);
-        const unsigned rk = (unsigned)__popcll((long long)((M >> (8 * (lane & 7))) & 0xffull));
-        const uint64_t mine = S.cand[lane & 7];
-        const bool valid = lane < 8 && (unsigned)lane < cs;
-        const unsigned long long ha = __ballot(valid && (uint64_t)rk == t);
-        ka = rj_readlane_u64(mine, __ffsll((long long)ha) - 1);
-        kb = ka;
-        if (want2 && !need_above) {
-            const unsigned long long hb = __ballot(valid && (uint64_t)rk == t + 1);
-            kb = rj_readlane_u64(mine, __ffsll((long long)hb) - 1);
-        }
-    }
-    if (need_above) {
-        uint64_t nx = NOKEY;
-        for (int i = tid; i < n; i += RJ_BLOCK) { const uint64_t k = S.key[i]; if (k != NOKEY && k > hi) nx = k < nx ? k : nx; }
-        nx = rj_wmin_u64(nx);
-        if (lane == 0) S.wmin[wid] = nx;
-        __syncthreads();
-        uint64_t bmin = S.wmin[0];
-#pragma unroll
-        for (int w = 1; w < RJ_WAVES; ++w) { const uint64_t a = S.wmin[w]; bmin = a < bmin ? a : bmin; }
-        kb = bmin;
-    }
-    __syncthreads();                          // S.cand / S.wmin consumed
-}
-
-
-// ---- order statistics from a window around the last launch's values (the selection of a settled chained run; the idea, the
-// exactness argument and the window's width are sicp_tail.hip's: window_collect / window_pick) -- here over keys that pass through
-// registers on their way into LDS, 16 waves.  A wave lists its member keys inside the window (ballot compaction) and counts those
-// below it; after one barrier every wave ranks the <= 64 listed keys itself.  All lanes of the block call rj_window_add in uniform
-// control flow (`mem` says whether the lane holds a member key).
-// (a step = the up to four keys a lane holds at once; nin / nbel: the wave's running totals, uniform)
-template <int N>
-__device__ __forceinline__ void rj_window_add(RejectShared &S, int buf, const bool (&mem)[N], const uint64_t (&k)[N], uint64_t wlo, uint64_t whi,
-                                              unsigned &nin, unsigned &nbel)
-{
-    const int wid = threadIdx.x >> 6;
-    unsigned cin = 0, cbel = 0;
-    bool inw[N];
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-        inw[u] = mem[u] && k[u] >= wlo && k[u] <= whi;
-        cin += inw[u] ? 1u : 0u;
-        cbel += (mem[u] && k[u] < wlo) ? 1u : 0u;
-    }
-    const unsigned incl = wscan_u32(cin | (cbel << 16));          // one wave prefix sum for both counts (<= 64 N each)
-    unsigned slot = nin + (incl & 0xffffu) - cin;
-#pragma unroll
-    for (int u = 0; u < N; ++u)
-        if (inw[u]) { if (slot < (unsigned)RJ_WSEG) S.wc[buf][wid][slot] = k[u]; ++slot; }
-    const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-    nin += tot & 0xffffu; nbel += tot >> 16;
-}
-__device__ __forceinline__ void rj_window_close(RejectShared &S, int buf, unsigned nin, unsigned nbel)
-{
-    if ((threadIdx.x & 63) == 0) { S.wci[buf][threadIdx.x >> 6] = nin; S.wbl[buf][threadIdx.x >> 6] = nbel; }
-}
-// after the barrier: false = the wanted rank(s) are not inside the window (or it overflowed)
-__device__ __forceinline__ bool rj_window_pick(const RejectShared &S, int buf, long r, bool want2, uint64_t &ka, uint64_t &kb)
-{
-    const int lane = threadIdx.x & 63;
-    unsigned n = 0, seg_max = 0, my_w = 0, my_base = 0;
-    long below = 0;
-#pragma unroll
-    for (int w = 0; w < RJ_WAVES; ++w) {
-        const unsigned c = S.wci[buf][w];
-        if ((unsigned)lane >= n && (unsigned)lane < n + c) { my_w = (unsigned)w; my_base = n; }
-        n += c; seg_max = c > seg_max ? c : seg_max;
-        below += (long)S.wbl[buf][w];
-    }
-    long t = r - below;
-    if (n > (unsigned)RJ_WCAP || seg_max > (unsigned)RJ_WSEG || t < 0 || t + (want2 ? 1 : 0) >= (long)n) return false;
-    uint64_t mine = ~0ull;
-    if ((unsigned)lane < n) mine = S.wc[buf][my_w][(unsigned)lane - my_base];
-    // quickselect on the total order (key, lane), wave-uniform bookkeeping (sicp_tail.hip: window_pick)
-    unsigned long long active = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
-    int pa = 0;
-#pragma unroll 1
-    for (;;) {
-        const int p = __ffsll((long long)active) - 1;
-        const uint64_t pv = rj_readlane_u64(mine, p);
-        const unsigned long long less = __ballot(mine < pv || (mine == pv && lane < p)) & active;
-        const long c = (long)__popcll((long long)less);
-        if (c == t) { ka = pv; pa = p; break; }
-        if (c > t) active = less;
-        else { active &= ~less & ~(1ull << p); t -= c + 1; }
-    }
-    kb = ka;
-    if (want2) {
-        const bool behind = (unsigned)lane < n && (mine > ka || (mine == ka && lane > pa));
-        kb = rj_wmin_u64(behind ? mine : ~0ull);
-    }
-    return true;
-}
-
-__global__ __launch_bounds__(RJ_BLOCK) void k_reject(
-    const double *__restrict__ dist, const uint8_t *__restrict__ flag, long Q, uint8_t *__restrict__ keep, double *__restrict__ out4,
-    double *__restrict__ out3, const IcpDev *__restrict__ st, int use_prior /* out4 still holds the LAST launch's (m, median, mad, kept)
-                                                                              of this run: look for both statistics in a window around them first */)
-{
-    __shared__ RejectShared S;
-    if (st && st->stop) return;
-    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-    const int n = (int)Q;
-    // the last launch's statistics (read before anything here overwrites them)
-    const double pcnt = use_prior ? out4[0] : 0.0, pmed = use_prior ? out4[1] : 0.0, pmad = use_prior ? out4[2] : 0.0;
-    bool win = pmad > 0.0 && pmad < __builtin_inf() && pcnt >= 1.0 && pmed == pmed;
-    const double hw_med = pmad * fmin(0.25, 75.0 / pcnt), hw_mad = pmad * fmin(0.25, 47.0 / pcnt);
-    const uint64_t wlo = ord_key(pmed - hw_med), whi = ord_key(pmed + hw_med);
-    for (int i = tid; i < RJ_HC * 257; i += RJ_BLOCK) S.hc[i] = 0u;
-    if (tid == 0) S.ncand = 0u;
-    unsigned cnt = 0, nin = 0, nbel = 0;
-    double dmn = __builtin_inf(), dmx = -__builtin_inf();
-    // four rows per lane and step: their loads are issued together (one workgroup has to cover the memory latency itself)
-    for (int base0 = 0; base0 < n; base0 += 4 * RJ_BLOCK) {
-        double d[4];
-        bool f[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = base0 + tid + u * RJ_BLOCK;
-            const int ic = i < n ? i : n - 1;
-            d[u] = dist[ic]; f[u] = i < n && flag[ic] != 0;
-        }
-        uint64_t k4[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = base0 + tid + u * RJ_BLOCK;
-            k4[u] = f[u] ? ord_key(d[u]) : ~0ull;
-            if (i < n) S.key[i] = k4[u];
-            if (f[u]) { cnt += 1; dmn = fmin(dmn, d[u]); dmx = fmax(dmx, d[u]); }
-        }
-        if (win) rj_window_add<4>(S, 0, f, k4, wlo, whi, nin, nbel);
-    }
-    if (win) rj_window_close(S, 0, nin, nbel);
-    cnt = (unsigned)wsum_u64(cnt);
-    dmn = rj_wmin_f64(dmn); dmx = rj_wmin_f64(-dmx);
-    if (lane == 0) { S.wcnt[wid] = cnt; S.red[0][wid][0] = dmn; S.red[0][wid][1] = dmx; }
-    __syncthreads();
-    long m = 0;
-#pragma unroll
-    for (int w = 0; w < RJ_WAVES; ++w) { m += S.wcnt[w]; dmn = fmin(dmn, S.red[0][w][0]); dmx = fmin(dmx, S.red[0][w][1]); }
-    if (m == 0) {
-        for (int i = tid; i < n; i += RJ_BLOCK) keep[i] = 0;
-        __syncthreads();                                   // (every lane has read the prior before lane 0 overwrites it)
-        if (tid == 0) {
-            out4[0] = 0; out4[1] = __builtin_nan(""); out4[2] = __builtin_nan(""); out4[3] = 0;
-            if (out3) { out3[0] = 0; out3[1] = __builtin_nan(""); out3[2] = __builtin_nan(""); }
-        }
-        return;
-    }
-    uint64_t ka, kb;
-    // (one miss ends the attempts of this launch: a median that moved takes the MAD with it)
-    if (win) win = rj_window_pick(S, 0, (m - 1) / 2, (m & 1) == 0, ka, kb);
-    __syncthreads();
-    if (!win) lds_range_select(S, n, (m - 1) / 2, (m & 1) == 0, ord_key(dmn), ord_key(-dmx), ka, kb);
-    const double med = (ord_val(ka) + ord_val(kb)) / 2.0;
-    {
-        const uint64_t alo = ord_key(fmax(pmad - hw_mad, 0.0)), ahi = ord_key(pmad + hw_mad);
-        nin = 0; nbel = 0;
-        for (int i0 = 0; i0 < n; i0 += RJ_BLOCK) {
-            const int i = i0 + tid;
-            const uint64_t k = i < n ? S.key[i] : ~0ull;
-            const bool mem[1] = {k != ~0ull};
-            const uint64_t a[1] = {mem[0] ? ord_key(fabs(ord_val(k) - med)) : ~0ull};
-            if (mem[0]) S.key[i] = a[0];
-            if (win) rj_window_add<1>(S, 1, mem, a, alo, ahi, nin, nbel);
-        }
-        if (win) rj_window_close(S, 1, nin, nbel);
-    }
-    __syncthreads();
-    if (win) win = rj_window_pick(S, 1, (m - 1) / 2, (m & 1) == 0, ka, kb);
-    if (!win) {   // |d - med| is monotone in d on either side of med: its range follows from the distances' own
-        const double u = fabs(dmn - med), v = fabs(-dmx - med);
-        lds_range_select(S, n, (m - 1) / 2, (m & 1) == 0, ord_key(0.0), ord_key(u > v ? u : v), ka, kb);
-    }
-    const double mad = (ord_val(ka) + ord_val(kb)) / 2.0;
-    const double bound = 3 * mad;
-    // keep mask (key = |d - med| of a flagged row) + statistics of the kept distances, one pass over deviations from
-    // the median (a shift within a few MAD of the mean: var = (S2 - S1^2 / n) / n loses nothing to cancellation)
-    double v3[3] = {0.0, 0.0, 0.0};
-    for (int i = tid; i < n; i += RJ_BLOCK) {
-        const uint64_t k = S.key[i];
-        const uint8_t kq = (k != ~0ull && ord_val(k) <= bound) ? 1 : 0;
-        keep[i] = kq;
-        if (kq) {
-            v3[0] += 1.0;
-            if (out3) { const double dev = dist[i] - med; v3[1] += dev; v3[2] = fma(dev, dev, v3[2]); }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { v3[j] = wsum(v3[j]); if (lane == 0) S.red[1][wid][j] = v3[j]; }
-    __syncthreads();
-    if (tid == 0) {
-        double t[3] = {0.0, 0.0, 0.0};
-        for (int w = 0; w < RJ_WAVES; ++w) for (int j = 0; j < 3; ++j) t[j] += S.red[1][w][j];
-        out4[0] = (double)m; out4[1] = med; out4[2] = mad; out4[3] = t[0];
-        if (out3) {
-            const double var = (t[2] - t[1] * t[1] / t[0]) / t[0];
-            out3[0] = t[0]; out3[1] = med + t[1] / t[0]; out3[2] = sqrt(var > 0.0 ? var : 0.0);
-        }
-    }
-}
+// (K6, the median / raw-MAD rejection by one workgroup -- corrpts.py:165-188 --, lives in sicp_reject.hip)
 
 // ------------------------------------------------------------------------------------
 // masked mean / population std (two-pass, np.std ddof=0)     simpleicp.py:233-234,356-379
@@ -1623,12 +1302,6 @@ void launch_fill_f32(hipStream_t s, float *dst, long n, float v)
 void launch_scatter_f32(hipStream_t s, float *dst, const int64_t *rows, const float *vals, long m)
 {
     if (m > 0) hipLaunchKernelGGL(k_scatter_f32, dim3(cdiv(m, 256)), dim3(256), 0, s, dst, rows, vals, m);
-}
-
-void launch_reject(hipStream_t s, const double *dist, const uint8_t *flag, long Q, uint8_t *keep, double *out4, const IcpDev *st,
-                   double *out3, bool use_prior)
-{
-    hipLaunchKernelGGL(k_reject, dim3(1), dim3(RJ_BLOCK), 0, s, dist, flag, Q, keep, out4, out3, st, use_prior ? 1 : 0);
 }
 
 void launch_stats(hipStream_t s, const double *v, const uint8_t *keep, long Q, double *out3, const double *also4,
