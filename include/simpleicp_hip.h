@@ -273,7 +273,7 @@ int sicp_comm_destroy(sicp_ctx *ctx);
  * are both awaited with a deadline (SICP_COMM_TIMEOUT_S, default 60 s) and what RCCL reports (ncclCommCount /
  * ncclCommUserRank) is checked against rank / world; any failure returns SICP_ERR_EXCHANGE and leaves the ctx without a
  * communicator, so the host can send every rank down another road together.  Inside a run a result that does not arrive within
- * SICP_XCHG_TIMEOUT_S (default 120 s) while collectives are in flight is SICP_ERR_EXCHANGE as well, not a hang.
+ * twice that deadline (default 120 s) while collectives are in flight is SICP_ERR_EXCHANGE as well, not a hang.
  *   sicp_comm_activate : the communicator stays with the ctx between runs; on = 1 makes the ctx's searches and iterations
  *                        job-wide again (with this gn_shard), on = 0 parks it (single-GPU behaviour, communicator kept).
  *   sicp_comm_info     : out[0] exchange in force: 0 none, 1 host callback, 2 the library's RCCL communicator;

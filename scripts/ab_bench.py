@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B the bench line under environment switches in ONE GPU call (every variant: `bench.py` without the slow legs, parity leg on).
 
-    python scripts/ab_bench.py [--config C4] [--repeats 20] base: depth8:SICP_CHAIN_DEPTH=8 evals2:SICP_LM_EVALS=2,SICP_LM_GRID=128
+    python scripts/ab_bench.py [--config C4] [--repeats 20] base: launches:SICP_LM=launches nowindow:SICP_TAIL_WINDOW=0
 
 Each argument is NAME:VAR=VALUE[,VAR=VALUE...] (NAME: alone = the defaults).  Prints one row per variant -- iterations/s, ms per
 step, instrumented match / tail / selection times, solver evaluations per iteration, parity verdict -- and writes the JSON lines

@@ -33,8 +33,6 @@ VARIANTS = {
     "sweep_b64": {"SICP_KNN_BATCH": "64"},
     "sweep_unordered": {"SICP_ORDER_MIN_Q": "0"},
     "sweep_unordered_b1": {"SICP_ORDER_MIN_Q": "0", "SICP_KNN_BATCH": "1"},
-    "sweep_target8": {"SICP_GRID_TARGET": "8"},
-    "sweep_target32": {"SICP_GRID_TARGET": "32"},
 }
 names = sys.argv[4:] or ["rounds", "sweep", "sweep_b16", "sweep_unordered"]
 

@@ -19,7 +19,7 @@ stamp "bench rc=$?"
 if [ "${EXTRAS:-0}" = "1" ]; then      # the two small records of profiles/r2 (operator_cost.txt, host_enqueue.txt)
   timeout ${T_OPCOST:-120} python scripts/operator_cost.py > "$OUT/operator_cost.txt" 2>&1
   stamp "operator cost rc=$?"
-  SICP_HOST_TRACE=1 timeout 120 python scripts/trace_c4.py 2>&1 | grep -E "\[host\]|iterations:" | tail -26 > "$OUT/host_enqueue.txt"
+  SICP_SOLVE_TRACE=host timeout 120 python scripts/trace_c4.py 2>&1 | grep -E "\[host\]|iterations:" | tail -26 > "$OUT/host_enqueue.txt"
   stamp "host enqueue trace rc=$?"
 fi
 tail -3 "$OUT/ops.log"; tail -3 "$OUT/suite.log"; cat "$OUT/steps.log"

@@ -161,7 +161,6 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (rc == SICP_OK) std::memset(c->h_rec, 0, (size_t)REC_RING * REC_DOUBLES * sizeof(double));
     if (rc == SICP_OK && hipMemsetAsync(c->ticket.p, 0, 4 * sizeof(unsigned), c->stream) != hipSuccess) rc = SICP_ERR_HIP;
     if (rc != SICP_OK) { sicp_ctx_destroy(c); return rc; }
-    if (const char *e = std::getenv("SICP_LM_EVALS")) { const int d = std::atoi(e); if (d >= 0 && d <= 32) c->lm_evals = d; }
     if (const char *e = std::getenv("SICP_ORDER_MIN_Q")) c->order_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_KNN_SWEEP")) c->knn_sweep = std::atoi(e) != 0;
     if (const char *e = std::getenv("SICP_KNN_BATCH")) c->knn_batch = std::atol(e);
@@ -169,10 +168,6 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_NN16_MIN_Q")) c->nn16_min_q = std::atol(e);
     if (const char *e = std::getenv("SICP_NN16")) c->nn16_filter = !std::strcmp(e, "exact") ? 0 : !std::strcmp(e, "far") ? 1 : 2;
     if (const char *e = std::getenv("SICP_BOXES")) { c->use_boxes = std::atoi(e) != 0; c->boxes_always = std::atoi(e) >= 2; }
-    if (const char *e = std::getenv("SICP_UPLOAD_STAGED")) c->upload_staged = std::atoi(e) != 0;
-    if (const char *e = std::getenv("SICP_GRID_POINTWISE")) c->grid_pointwise = std::atoi(e) != 0;
-    if (const char *e = std::getenv("SICP_DL_THREADS")) { const int d = std::atoi(e); if (d >= 1 && d <= 64) c->dl_threads = d; }
-    if (const char *e = std::getenv("SICP_GRID_CAP_NONUNIFORM")) { const int d = std::atoi(e); if (d >= 22 && d <= 30) c->grid_cap_nonuniform_log2 = d; }
     if (const char *e = std::getenv("SICP_NN16F_MIN_Q")) { c->nn16f_min_q = std::atol(e); c->nn16f_min_q_forced = true; }
     if (const char *e = std::getenv("SICP_FAR_MOVE")) { const double t = std::atof(e); if (t >= 0) c->far_move = t; }
     if (const char *e = std::getenv("SICP_COARSE_MIN_N")) c->coarse_min_n = std::atol(e);
@@ -182,13 +177,16 @@ SICP_EXPORT int sicp_ctx_create(int device, sicp_ctx **ctx_out)
     if (const char *e = std::getenv("SICP_TEST_BARRIER_FAULT")) c->test_barrier_fault = std::atoi(e);
     if (const char *e = std::getenv("SICP_NN_GROUP")) { const int v = std::atoi(e); if (v == 8 || v == 16) c->nn_group = v; }
     if (const char *e = std::getenv("SICP_XCHG_KEYS_MIN_Q")) c->xkeys_min_q = std::atol(e);
-    if (const char *e = std::getenv("SICP_XCHG_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) c->xchg_timeout_s = v; }
-    if (const char *e = std::getenv("SICP_CHAIN_DEPTH")) { const int d = std::atoi(e); if (d >= 1 && d < REC_RING) c->chain_depth = d; }
+    if (const char *e = std::getenv("SICP_COMM_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) c->xchg_timeout_s = 2.0 * v; }    // (a record wait with collectives in flight: twice the rendezvous deadline)
     if (const char *e = std::getenv("SICP_FSCAN")) c->fscan_variant = !std::strcmp(e, "inline") ? 1 : 0;
     if (const char *e = std::getenv("SICP_FSCAN_CAP")) c->fscan_cap = std::atol(e);
-    if (const char *e = std::getenv("SICP_GRID_TARGET")) { const double t = std::atof(e); if (t >= 0.25 && t <= 1024) { c->grid_target = t; c->grid_target_forced = true; } }
-    c->host_trace = std::getenv("SICP_HOST_TRACE") != nullptr;
-    c->solve_trace = std::getenv("SICP_SOLVE_TRACE") != nullptr;
+    // SICP_SOLVE_TRACE: per-iteration traces on stderr -- any value: the tail's cycle counters; "host": the host's enqueue timings too;
+    // "sel" / "eval": the fine splits of a -DSICP_SEL_FINE_TRACE / -DSICP_EVAL_FINE_TRACE build (build.build_variant)
+    if (const char *e = std::getenv("SICP_SOLVE_TRACE")) {
+        c->solve_trace = true;
+        c->host_trace = std::strstr(e, "host") != nullptr;
+        c->trace_sel = std::strstr(e, "sel") != nullptr; c->trace_eval = std::strstr(e, "eval") != nullptr;
+    }
     if (const char *e = std::getenv("SICP_SOLVE")) c->solve_mode = !std::strcmp(e, "fused") ? 1 : !std::strcmp(e, "host") ? 2 : 0;
     if (const char *e = std::getenv("SICP_KNN1"))
         c->knn1_mode = !std::strcmp(e, "exact") ? 1 : !std::strcmp(e, "filter") ? 2 : !std::strcmp(e, "grid") ? 3 : 0;

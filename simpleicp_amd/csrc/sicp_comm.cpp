@@ -84,7 +84,7 @@ int wait_ticket(sicp_ctx *c, const double *flag_word, double seq)
                 const int rank = c->rank, world = c->world;
                 abandon_exchange(c);
                 return fail(SICP_ERR_EXCHANGE, "no result after %.0f s with a multi-GPU exchange in flight (rank %d of %d): a rank left "
-                                               "the job or the ranks' collectives are out of step (SICP_XCHG_TIMEOUT_S); the "
+                                               "the job or the ranks' collectives are out of step (twice SICP_COMM_TIMEOUT_S); the "
                                                "communicator was aborted, the context is single-GPU again",
                             c->xchg_timeout_s, rank, world);
             }

@@ -178,14 +178,14 @@ struct sicp_ctx {
                                    // being latency-bound at ~4 000 queries; its fused distance epilogue is worth a launch, ~4 us)
     int nn16_filter = 2;           // SICP_NN16 = exact (0: k_grid_nn16) | far (1: the filtered search, one flavour) | near (2, default: the lean
                                    // flavour first, the full one for what it leaves)
-    int dl_threads = 16;                  // SICP_DL_THREADS=1..64: host threads that fan a downloaded chunk out into the caller's arrays (run() at C4: 32 / 25 / 25 ms with 8 / 16 / 32)
-    int grid_cap_nonuniform_log2 = 27;    // SICP_GRID_CAP_NONUNIFORM=22..30: log2 of the cell table's limit for clouds whose points crowd a few cells
-    bool grid_pointwise = true;    // SICP_GRID_POINTWISE=0: the cell size follows the average over occupied cells only (A/B)
+    int dl_threads = 16;                  // host threads that fan a downloaded chunk out into the caller's arrays (run() at C4: 32 / 25 / 25 ms with 8 / 16 / 32)
+    int grid_cap_nonuniform_log2 = 27;    // log2 of the cell table's limit for clouds whose points crowd a few cells
+    bool grid_pointwise = true;    // the cell size follows the POINT-weighted occupancy (false: the average over occupied cells only -- round 4's rule)
     long nn16f_min_q = 196608;     // SICP_NN16F_MIN_Q: from this many queries per launch on the many-queries search goes through the float32 filter
     bool nn16f_min_q_forced = false;   // (the environment named it: no per-cloud adjustment)
                                    // (below: its two extra launches cost more than the filter saves on a machine that is not full)
     double far_move = 0.75;        // SICP_FAR_MOVE: the lean flavour goes first once the estimate moves by less than this many cells per iteration
-    bool upload_staged = true;     // SICP_UPLOAD_STAGED=0: every upload is a DMA straight out of the caller's arrays (A/B)
+    bool upload_staged = true;     // small uploads go through the pinned buffer (false: every upload a DMA straight out of the caller's arrays)
     bool use_boxes = false;        // SICP_BOXES=1: far searches trim their rows by the cells' tight boxes.  OFF by default: measured (profiles/r5), the
                                    // boxes cut 14-30 % of the candidates and never a microsecond -- DESIGN.md section 4
     bool boxes_always = false;     // SICP_BOXES=2: ... and stand-alone searches of a handful of queries build them too (tests)
@@ -220,18 +220,19 @@ struct sicp_ctx {
     long last_sel_rounds[2] = {0, 0}, sel_window_hits = 0;   // ... how it found median / MAD (sicp_tail_selection)
     bool have_last_ne = false;
     int solve_mode = 0;            // SICP_SOLVE = fused | host (A/B + tests); 0 = auto
-    bool grid_target_forced = false;   // SICP_GRID_TARGET given: every grid uses it
-    double grid_target = 16.0;     // points per occupied grid cell the cell size aims at (SICP_GRID_TARGET overrides;
+    bool grid_target_forced = false;   // (kept for a caller that pins the target: every grid uses it then)
+    double grid_target = 16.0;     // points per occupied grid cell the cell size aims at (
                                    // measured flat from 12 to 32, 5-20 % slower below 8: fewer, longer rows win)
-    bool host_trace = false;       // SICP_HOST_TRACE: per-iteration host timings on stderr
+    bool host_trace = false;       // SICP_SOLVE_TRACE=host: per-iteration host timings on stderr
     bool solve_trace = false;      // SICP_SOLVE_TRACE: the fused kernel's cycle counters on stderr
+    bool trace_sel = false, trace_eval = false;   // SICP_SOLVE_TRACE=sel / eval: the fine splits of a trace build
     long solve_seq = 0;            // completion tickets of the fused kernel
     DevBuf<IcpDev> icp_dev;        // device-resident loop state of a chained run (sicp_tail.hip)
     DevBuf<LmDev> lm_dev;          // solver state of the multi-workgroup evaluation chain (sicp_lm.hip)
     LmDev *h_lm = nullptr;         // pinned staging of it
     DevBuf<double> resid2;         // second residual buffer of that chain (trial / accepted alternate)
     int resid_slot = 0;            // which buffer holds the last iteration's accepted residuals
-    int lm_evals = 4;              // evaluations enqueued per iteration for Q > SOLVE_MAX_Q (SICP_LM_EVALS; k_lm_finish completes the rest)
+    int lm_evals = 4;              // evaluations enqueued per iteration for Q > SOLVE_MAX_Q (k_lm_finish completes the rest)
     double *h_rec = nullptr;       // pinned ring of per-iteration records the tail kernel streams to the host
     IcpDev *h_state = nullptr;     // pinned staging of the loop state
     DevBuf<unsigned long long> lm_bar_buf;   // grid barrier of the one-launch minimisation (zeroed when allocated)
@@ -245,7 +246,7 @@ struct sicp_ctx {
     long hsel_run_launches = 0;    // chained rejection launches since the last setup (the window needs two of them behind it)
     bool hsel_dirty = false;
     int nn_group = 0;              // SICP_NN_GROUP=8|16: lanes per query of the many-queries search (0: chosen per launch)
-    int chain_depth = 4;           // iterations enqueued ahead of the last record read (SICP_CHAIN_DEPTH)
+    int chain_depth = 4;           // iterations enqueued ahead of the last record read (two are not enough, four are: profiles/r2/ab_chain_depth.txt)
     // exchange: an RCCL communicator of the library's own (sicp_comm_init) or a host callback (sicp_set_exchange)
     sicp_exchange_fn xfn = nullptr;
     void *xuser = nullptr;

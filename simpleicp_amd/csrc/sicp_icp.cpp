@@ -188,7 +188,9 @@ SICP_EXPORT int sicp_icp_setup(sicp_ctx *c, const int64_t *sel_idx, int64_t Q, c
     c->have_iter = false;
     c->have_corr = false;
     c->have_prev_match = false;
+#ifndef SICP_TEST_REVERT_SLOT_FIX         // (tests/test_gpu_fuzz.py builds a variant WITHOUT this line to show that the call-sequence fuzz finds round 5's stale-slot bug)
     c->slot_cnt = -1;                  // (the filtered search's slot-ordered copies of the queries: other queries now)
+#endif
     c->q_order_lo = -1; c->q_order_cnt = 0;
     c->hsel_run_launches = 0;
     c->sel_window_hits = 0; c->last_sel_rounds[0] = c->last_sel_rounds[1] = 0;
@@ -389,7 +391,9 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
                 // distance and the planarity verdict too (what k_postmatch would re-read 72 bytes per correspondence for)
                 // (only in the one-wave-per-query flavour: with four queries per wave at the register limit the epilogue's late
                 // loads cost the search more than k_postmatch's launch -- match 693 -> 758 us at 1 M queries, measured)
-                post_done = !c->collective() && !many_q;
+                // ... except below ~65 536 queries, where the machine is not full: there the epilogue costs the search ~0.07 us per
+                // 1 000 queries and k_postmatch's launch 5 us (profiles/r6: 10 000 correspondences, 63.6 -> 58.9 us per iteration)
+                post_done = !c->collective() && (!many_q || cnt < 65536);
                 // behind a cloud-shard exchange the winning lanes leave the exchange's packed record instead (no k_pack_best launch)
                 // (query shards: the slim record, the matched index alone -- no k_pack_idx launch)
                 const bool pack = c->collective() && !qshard && !exchange_by_keys(c, Q), pack_idx = c->collective() && qshard;
@@ -557,10 +561,10 @@ int run_device_tail(sicp_ctx *c, const sicp_iter_params *P0, int64_t max_it, dou
             std::fprintf(stderr, "[tail] cycles: load+dist %.0f select %.0f (median %.0f in %.0f rounds, MAD %.0f in %.0f) keep %.0f lm %.0f "
                                  "(%lld evals %.0f, %lld steps, solves %.0f, accept %.0f) final %.0f\n",
                          o[50], o[51], o[55], o[56], o[57], o[58], o[52], o[53], (long long)R.ne_evals, o[59], (long long)R.lm_steps, o[60], o[62], o[54]);
-        if (c->solve_trace && small_q && std::getenv("SICP_SEL_TRACE"))      // (a -DSICP_SEL_FINE_TRACE build: build.build_variant)
+        if (c->solve_trace && small_q && c->trace_sel)      // (a -DSICP_SEL_FINE_TRACE build: build.build_variant)
             std::fprintf(stderr, "[sel] median: atomics+barrier %.0f fold+barrier %.0f scan+pick %.0f (more rounds %.0f) gather+barrier %.0f rank %.0f | "
                                  "MAD: %.0f %.0f %.0f (%.0f) %.0f %.0f\n", o[38], o[39], o[40], o[41], o[42], o[43], o[44], o[45], o[46], o[47], o[48], o[49]);
-        if (c->solve_trace && small_q && std::getenv("SICP_EVAL_TRACE"))     // (a -DSICP_EVAL_FINE_TRACE build)
+        if (c->solve_trace && small_q && c->trace_eval)     // (a -DSICP_EVAL_FINE_TRACE build)
             std::fprintf(stderr, "[eval] rows + LDS writes %.0f barrier %.0f MFMA Gram %.0f block write + barrier %.0f fold %.0f\n", o[38], o[39], o[40], o[41], o[42]);
         if (o[REC_CONVERGED] != 0.0) over = true;
     }

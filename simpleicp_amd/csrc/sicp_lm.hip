@@ -373,11 +373,13 @@ __device__ __forceinline__ void lm_finish_body(
             out[REC_RESID_SLOT] = cur;
         }
     }
-    rec[tid] = out[tid];                                   // (tid < 64; the ticket word is overwritten last, below)
+    // (tid < 64; the ticket word is overwritten last, below.  System-scope write-through stores, drained, then the ticket: no fence --
+    // the host reads nothing else, and a system-scope release would write this XCD's L2 back on the iteration's critical path:
+    // sicp_tail.hip, flush_rec)
+    __hip_atomic_store(rec + tid, out[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
-        __threadfence_system();
-        __hip_atomic_store(rec + REC_TICKET, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(rec + REC_TICKET, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // the next iteration's start
         if (too_few || !finite) { st->stop = 1; }
         else {
@@ -491,15 +493,16 @@ __global__ __launch_bounds__(LB) void k_lm_all(
         __syncthreads();
     }
     if (blockIdx.x == 0) {
-        {   // the state the finish (and the next iteration) reads
-            double *dst = reinterpret_cast<double *>(L);
-            const double *src = reinterpret_cast<const double *>(&Ls);
-            for (int i = tid; i < (int)(sizeof(LmDev) / sizeof(double)); i += LB) dst[i] = src[i];
-        }
-        __threadfence();
-        __syncthreads();
+        // the finish works on this block's LDS copy of the solver state (it reads what the loop left and leaves the next iteration's
+        // start there), and only then does the state go to memory -- the next launch reads it, a kernel boundary away.  (Round 5
+        // stored the state first and had all 512 lanes execute __threadfence() so that the finish could read it back: an L2
+        // write-back + invalidate on the iteration's critical path.)
         const bool bad = __hip_atomic_load(&B->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-        lm_finish_body(S, out, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, resid0, resid1, rec, bad);
+        lm_finish_body(S, out, qx, qy, qz, normals, p2, keep, Q, A, st, &Ls, rj4, stats, resid0, resid1, rec, bad);
+        __syncthreads();
+        double *dst = reinterpret_cast<double *>(L);
+        const double *src = reinterpret_cast<const double *>(&Ls);
+        for (int i = tid; i < (int)(sizeof(LmDev) / sizeof(double)); i += LB) dst[i] = src[i];
     }
 }
 

@@ -515,19 +515,26 @@ __device__ __forceinline__ void eval_ne_mfma(TailShared &S, const double (&x)[6]
     SICP_ET(5)
 }
 
-// wave 0: the words parked in S.out leave in ONE store instruction; for the record the completion ticket
-// follows behind a system-scope fence (the host polls that pinned word instead of waiting for the end-of-kernel signal)
+// wave 0: the words parked in S.out leave in ONE store instruction.  The record goes to pinned host memory and the host polls its
+// ticket word instead of waiting for the end-of-kernel signal: record words as system-scope write-through stores, drained
+// (vmcnt(0)), then the ticket as one more such store.  No fence: the host reads nothing else this kernel wrote.  (Round 5 issued
+// __threadfence_system() AND a release store; measured side by side in round 6, profiles/r6: the same 13.0 us per launch -- the
+// kernel's end writes the L2 back anyway -- so the simpler form stays.)
 __device__ __forceinline__ void flush_out(TailShared &S, double *dst, int count)
 {
     const int lane = threadIdx.x;
     if (lane < count) dst[lane] = S.out[lane];
 }
+__device__ __forceinline__ void flush_rec(TailShared &S, double *rec, int count)
+{
+    const int lane = threadIdx.x;
+    if (lane < count) __hip_atomic_store(rec + lane, S.out[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ void publish(double *rec, double seq)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0) {
-        __threadfence_system();
-        __hip_atomic_store(rec + REC_TICKET, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(rec + REC_TICKET, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -582,7 +589,7 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
     if (tid < 64) S.out[tid] = 0.0;
     if (stop) {
         // the run ended in an earlier launch (converged / failed): nothing to do but tell the host
-        if (tid == 0) rec[REC_STATUS] = 3.0;
+        if (tid == 0) __hip_atomic_store(rec + REC_STATUS, 3.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (wid == 0) publish(rec, A.seq);
         return;
     }
@@ -625,7 +632,7 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
             S.out[REC_STATUS] = 1.0;
             st->stop = 1;
         }
-        if (wid == 0) { flush_out(S, rec, REC_TICKET); publish(rec, A.seq); }
+        if (wid == 0) { flush_rec(S, rec, REC_TICKET); publish(rec, A.seq); }
         return;
     }
 
@@ -699,7 +706,7 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
             S.out[REC_STATUS] = 1.0;
             st->stop = 1;
         }
-        if (wid == 0) { flush_out(S, rec, REC_TICKET); publish(rec, A.seq); }
+        if (wid == 0) { flush_rec(S, rec, REC_TICKET); publish(rec, A.seq); }
         return;
     }
     const double w = need_w ? 1.0 / (dstd * dstd) : w_state;          // simpleicp.py:233-234 (frozen afterwards)
@@ -846,7 +853,7 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
 #endif
 
     }
-    flush_out(S, rec, REC_TICKET);
+    flush_rec(S, rec, REC_TICKET);
     publish(rec, A.seq);
     // the next iteration's start: estimate, its sin / cos, H(x) and the rigid inverse [R^T | -R^T t]
     if (tid == 0) {
