@@ -175,6 +175,8 @@ def match_bytes(kernel, per, nq):
     kernel (k_grid_nn16f): a 16-B float record per candidate, the same offsets, per query its 32-B slot record, the 32-B bound it reads
     and the 32-B bound it leaves, the winner's 32-B record and the 40-B result."""
     if kernel == "k_grid_nn16f":
+        # (an approximation from below on data with many ties: the queries the filter leaves to the exact kernel -- `deferred`, 0.1-0.5 % on
+        # the bench clouds, ALL of them on lattice data -- add their 32-byte candidates to the same tallies and are priced at 16 here)
         return per["candidates"] * 16 + per["rows"] * 8 + nq * (32 + 32 + 32 + 32 + 40)
     return per["candidates"] * 32 + per["rows"] * 8 + nq * (24 + 24 + 48)
 

@@ -17,9 +17,18 @@ int grid_build(sicp_ctx *c, int slot, long icp_queries)
     if (!c->grid_target_forced && slot == SICP_MOV && icp_queries >= c->nn16_min_q && c->nn16_min_q > 0) target = 0.5 * target;
     // a grid binned for the other regime (the same clouds first registered with 1000 correspondences, then with a million) is
     // rebuilt -- by the ICP match only: ~1 ms per 10 M points once, against 0.1 ms per iteration of a million queries
-    if (cl.grid.valid && cl.grid.target_used > 0 && cl.grid.target_used != target) cl.grid.valid = false;
+    if (cl.grid.valid && cl.grid.target_used > 0 && cl.grid.target_used != target) {
+        cl.grid.valid = false;
+        // (its coarse twin is 8 x the OLD cell size -- k_grid_nn switches to it at r > 4 h and assumes 8 x the new h -- and may no longer
+        // be wanted at all: rebuilt on demand, released when the new grid is not nonuniform: ADVICE r5)
+        cl.coarse_grid.valid = false;
+    }
     cl.grid.target_used = target;
-    return grid_build_arrays(c, cl, cl.x(), cl.y(), cl.z(), cl.n, cl.grid, target);
+    CHK(grid_build_arrays(c, cl, cl.x(), cl.y(), cl.z(), cl.n, cl.grid, target));
+    if (!cl.grid.nonuniform && !cl.coarse_grid.valid && cl.coarse_grid.rec.p) {      // a second 32-byte-per-point copy nobody reads
+        cl.coarse_grid.rec.release(); cl.coarse_grid.cell_start.release();
+    }
+    return SICP_OK;
 }
 
 // the cloud's subsample (every SUB_STRIDE-th point) and its grid
@@ -173,7 +182,8 @@ int grid_build_arrays(sicp_ctx *c, const Cloud &cl, const double *X, const doubl
         gr.avg_per_cell = probed ? target : (double)n / (double)std::max<unsigned long long>(res2[0], 1);
         // still far too coarse (small clouds are not probed; windows can mislead): shrink and bin again
         if (h_forced > 0.0) { gr.pointwise_occupancy = pw; break; }
-        if (!probed && gr.avg_per_cell > 3 * target && attempt < 4 && ncells < cap / 2) { h *= std::sqrt(target / gr.avg_per_cell); continue; }
+        // (not once the point-weighted rule has settled on a size: shrinking again would undo its take-back -- ADVICE r5)
+        if (!probed && !pw_settled && gr.avg_per_cell > 3 * target && attempt < 4 && ncells < cap / 2) { h *= std::sqrt(target / gr.avg_per_cell); continue; }
         // the points' own view: shrink until an average point shares its cell with a few times the target (occupancy ~ h^2 on a surface);
         // not below the table's limit (a binning that was capped stands), at most six rounds
         if (c->grid_pointwise && !pw_settled) {

@@ -1533,9 +1533,9 @@ __device__ __forceinline__ int h3_region(int b)      // 0..3: a coarse region, -
 // misses on the keys (3: histogram, lists, the meeting before the wipe) + the general form after it (per statistic HS_PASSES digit
 // passes and one collecting sweep) + the keep / statistics sweep.  The host advances the barrier counter by exactly this much per
 // launch (barrier numbers are absolute): a launch that could take one more would leave the next launch's first barrier open.
-constexpr int HS_WINDOW_BARRIERS = 3, HS_STAT_BARRIERS = HS_PASSES + 1, HS_FINAL_BARRIERS = 1;
+constexpr int HS_WINDOW_BARRIERS = 3, HS_STAT_BARRIERS = HS_PASSES + 1, HS_FINAL_BARRIERS = 0;      // (the fold behind the last sweep is a ticket, not a meeting)
 constexpr int HS_MAXB = HS_WINDOW_BARRIERS + 2 * HS_STAT_BARRIERS + HS_FINAL_BARRIERS;
-static_assert(HS_MAXB == 18, "k_hsel_all's worst case: 3 (window tried and missed late) + 2 x (6 passes + 1) + 1");
+static_assert(HS_MAXB == 17, "k_hsel_all's worst case: 3 (window tried and missed late) + 2 x (6 passes + 1)");
 struct HselAll {
     GridBar bar;                   // (sicp_lanes.h) all zero when the buffer is new
     unsigned long long nxt[2];     // per statistic: smallest key above the prefix interval (~0 between launches; see hsel_state_init)
@@ -1545,7 +1545,8 @@ struct HselAll {
     // windowed form
     double prior[2][2];            // (median, MAD) of the last two launches, [1] the latest
     unsigned n_prior;              // how many of them this run has produced (the host restarts the count with every setup)
-    unsigned pad3[3];
+    unsigned ticket;               // blocks that have finished their last sweep (0 between launches): the last one folds the partial sums
+    unsigned pad3[2];
     unsigned whist[H3_NB + 2];     // all zero between launches
     unsigned wcoarse[4];           // zoned flush (large Q): keys below / between / above the three zones; zero between launches
     unsigned wcnt[HS_GRID_MAX][2]; // per block: median-bin keys, shell keys it found (rewritten by every launch that collects)
@@ -2064,15 +2065,23 @@ __global__ __launch_bounds__(256) void k_hsel_all(const double *__restrict__ dis
         __hip_atomic_store(&partial[(long)tid * NE_MAX_GRID + blockIdx.x], (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     SICP_TQ();
-    grid_barrier(&S->bar, bar_base + (unsigned long long)(++nb), absent);
+    // No last meeting: whoever finishes LAST (a ticket, nobody waits) folds the blocks' partial sums -- every other block is then past
+    // its last use of the shared words, which is what the barrier that stood here (~6 us of dependent device-scope round trips at
+    // 256 blocks) was for.
     if (nb > HS_MAXB && tid == 0) __hip_atomic_store(&S->bar.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (budget exceeded: never, by the count above HselAll)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int is_last;
+    if (tid == 0) is_last = __hip_atomic_fetch_add(&S->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g - 1u ? 1 : 0;
+    __syncthreads();
     SICP_TQ();
 #ifdef SICP_HSEL_DEBUG
-    if (blockIdx.x == 0 && tid == 0 && have)
-        printf("[hsel3-t] sweep1+flush %lld | B1 %lld | analysis %lld | sweep2+lists %lld (incl. stamp) | B2 %lld | gather %lld | sorts+premise %lld | sweep3 %lld | B3 %lld\n",
+    if (is_last && tid == 0 && have)
+        printf("[hsel3-t] sweep1+flush %lld | B1 %lld | analysis %lld | sweep2+lists %lld (incl. stamp) | B2 %lld | gather %lld | sorts+premise %lld | sweep3 %lld | ticket %lld\n",
                tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[5] - tq[3], tq[6] - tq[5], tq[7] - tq[6], tq[8] - tq[7], tq[9] - tq[8], tq[10] - tq[9]);
 #endif
-    if (blockIdx.x == 0) {
+    if (is_last) {
+        if (tid == 0) __hip_atomic_store(&S->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
         if (wid < 3) {
             double t = 0;
             for (unsigned blk = lane; blk < g; blk += 64)

@@ -440,7 +440,9 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
           o = __uint_as_float(lane_xor32<2>(__float_as_uint(gmin)));  gmin = o < gmin ? o : gmin;
           o = __uint_as_float(lane_xor32<1>(__float_as_uint(gmin)));  gmin = o < gmin ? o : gmin; }
         const bool found = gmin < __builtin_inff();
-        const float lim = gmin + T;
+        // (rounded UP: the float32 addition may lose up to 6e-8 (gmin + T) -- near the cloud's centre that is a tenth of T -- and a
+        // candidate that is within the margin must count as within it: ADVICE r5)
+        const float lim = (gmin + T) * 1.0000003f;
         const unsigned near1 = (unsigned)(__ballot(found && v1 <= lim) >> gbase) & GMASK;       // lanes whose smallest is within T
         const unsigned near2 = (unsigned)(__ballot(found && v2 <= lim) >> gbase) & GMASK;       // ... whose second-smallest is too
         const bool alone = __popc(near1) == 1 && near2 == 0u;

@@ -48,6 +48,8 @@ __device__ __forceinline__ double oval(unsigned long long k)
 }
 
 constexpr int TB = 256;                    // 4 waves, one per SIMD: each may use the whole 512-entry register file
+                                           // (measured in round 6 with 8 waves: two waves share a SIMD's 512 registers, the LM state spills
+                                           // to scratch and the iteration goes 24.3 -> 28.3 us: profiles/r6/q_sweep_tail_512_lanes.txt)
                                            // (the uniform solver state and up to 8 correspondences per lane live there)
 constexpr int NW = TB / 64;
 constexpr int HC = 16;                     // privatised histogram copies of a selection round
@@ -96,7 +98,11 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double (*buf)[4])
     for (int i = 0; i < NV; ++i) { v[i] = wsum(v[i]); if (lane == 0) buf[wid][i] = v[i]; }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = (buf[0][i] + buf[1][i]) + (buf[2][i] + buf[3][i]);
+    for (int i = 0; i < NV; ++i) {
+        double t = (buf[0][i] + buf[1][i]) + (buf[2][i] + buf[3][i]);
+        if constexpr (NW == 8) t += (buf[4][i] + buf[5][i]) + (buf[6][i] + buf[7][i]);
+        v[i] = t;
+    }
 }
 
 __device__ __forceinline__ unsigned long long wmin_u64(unsigned long long v)
@@ -157,7 +163,7 @@ __device__ __forceinline__ void block_select(TailShared &S, unsigned *hc, const 
             if (k[e] != NOKEY && k[e] >= lo && k[e] <= hi) atomicAdd(&mycopy[(unsigned)((k[e] - lo) >> sh)], 1u);
         __syncthreads();
         if (round == 0) { SICP_ST(1) }
-        {   // lane t folds bin t over the copies and leaves them clean for the next round
+        if (TB == 256 || tid < 256) {   // lane t folds bin t over the copies and leaves them clean for the next round
             unsigned tot = 0;
 #pragma unroll
             for (int c = 0; c < HC; ++c) { tot += hc[c * 257 + tid]; hc[c * 257 + tid] = 0u; }
@@ -269,21 +275,25 @@ __device__ __forceinline__ void window_collect(TailShared &S, int buf, const uns
 }
 __device__ __forceinline__ bool window_pick(const TailShared &S, int buf, long r, bool want2, unsigned long long &ka, unsigned long long &kb)
 {
-    static_assert(NW == 4, "the four waves' counts are read as one uint4");
+    static_assert(NW == 4 || NW == 8, "the waves' counts are read four at a time");
     const int lane = threadIdx.x & 63;
-    const uint4 ci = *reinterpret_cast<const uint4 *>(&S.wci[buf][0]), bl = *reinterpret_cast<const uint4 *>(&S.wbl[buf][0]);
-    const unsigned n0 = ci.x, n1 = ci.y, n2 = ci.z, n3 = ci.w;
-    const unsigned n = (n0 + n1) + (n2 + n3);
-    const long below = (long)((bl.x + bl.y) + (bl.z + bl.w));
+    unsigned n = 0, my_w = 0, my_base = 0;
+    long below = 0;
+#pragma unroll
+    for (int w4 = 0; w4 < NW; w4 += 4) {
+        const uint4 ci = *reinterpret_cast<const uint4 *>(&S.wci[buf][w4]), bl = *reinterpret_cast<const uint4 *>(&S.wbl[buf][w4]);
+        const unsigned cc[4] = {ci.x, ci.y, ci.z, ci.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if ((unsigned)lane >= n && (unsigned)lane < n + cc[j]) { my_w = (unsigned)(w4 + j); my_base = n; }
+            n += cc[j];
+        }
+        below += (long)((bl.x + bl.y) + (bl.z + bl.w));
+    }
     long t = r - below;                                          // rank inside the window
     if (n > (unsigned)WCAP || t < 0 || t + (want2 ? 1 : 0) >= (long)n) return false;
     unsigned long long mine = NOKEY;
-    {
-        const unsigned i = (unsigned)lane;
-        const unsigned w = i < n0 ? 0u : (i < n0 + n1 ? 1u : (i < n0 + n1 + n2 ? 2u : 3u));
-        const unsigned base = w == 0u ? 0u : (w == 1u ? n0 : (w == 2u ? n0 + n1 : n0 + n1 + n2));
-        if (i < n) mine = S.wc[buf][w][i - base];
-    }
+    if ((unsigned)lane < n) mine = S.wc[buf][my_w][(unsigned)lane - my_base];
     // the key of rank t among the n listed ones, by QUICKSELECT on the total order (key, lane) with wave-uniform bookkeeping: the
     // pivot is the first lane still in play (the list is in no particular order), one ballot counts the keys before it -- a
     // handful of rounds of ~10 instructions where counting every key against every other took n rounds
@@ -433,7 +443,10 @@ __device__ __forceinline__ void eval_ne(TailShared &S, const double (&x)[6], con
     // every wave adds the four waves' sums itself (fixed order) and parks the matrix in its own LDS slot
     const int idx = sum_index(lane >> 3, lane & 7);
     double v = 0.0;
-    if (idx >= 0) v = (S.gw[parity][0][idx] + S.gw[parity][1][idx]) + (S.gw[parity][2][idx] + S.gw[parity][3][idx]);
+    if (idx >= 0) {
+        v = (S.gw[parity][0][idx] + S.gw[parity][1][idx]) + (S.gw[parity][2][idx] + S.gw[parity][3][idx]);
+        if constexpr (NW == 8) v += (S.gw[parity][4][idx] + S.gw[parity][5][idx]) + (S.gw[parity][6][idx] + S.gw[parity][7][idx]);
+    }
     S.gf[wid][slot][lane] = v;
     SICP_ET(5)
 }
@@ -695,7 +708,9 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
     } else {
         if ((tid & 63) == 0) S.wcnt[wid] = nkeep;        // (its earlier content was consumed two barriers ago)
         __syncthreads();
-        nk = (double)((S.wcnt[0] + S.wcnt[1]) + (S.wcnt[2] + S.wcnt[3]));
+        unsigned nkw = (S.wcnt[0] + S.wcnt[1]) + (S.wcnt[2] + S.wcnt[3]);
+        if constexpr (NW == 8) nkw += (S.wcnt[4] + S.wcnt[5]) + (S.wcnt[6] + S.wcnt[7]);
+        nk = (double)nkw;
     }
     if (tid == 0) { S.out[0] = (double)m; S.out[1] = med; S.out[2] = mad; S.out[3] = nk; S.out[4] = dmean; S.out[5] = dstd; }
     if (nk < 6.0) {

@@ -20,6 +20,9 @@ GOLDEN_CHAIN = ["dragon_chain", "bunny_chain"]
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: the full-size legs that take 15-60 s each (100 M-point clouds, 10 M x 10 M select_in_range, "
+                                       "1 M-query oracle samples): run with SICP_TEST_SLOW=1 -- scripts/final_measure.sh does, and "
+                                       "commits the log under profiles/ -- so that a plain `-m gpu` stays well inside ten minutes")
 
 
 def has_gpu():
@@ -31,6 +34,11 @@ def has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
+    if os.environ.get("SICP_TEST_SLOW") != "1":
+        skip_slow = pytest.mark.skip(reason="full-size leg: set SICP_TEST_SLOW=1 (scripts/final_measure.sh runs them; log under profiles/)")
+        for item in items:
+            if "slow" in item.keywords:
+                item.add_marker(skip_slow)
     # `-m gpu` on a box without a GPU must fail loudly, not skip silently;
     # plain runs without a GPU skip the gpu-marked tests.
     if has_gpu():

@@ -13,7 +13,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 N, Q, SAMPLE = 100_000_000, 1_000_000, 300

@@ -167,6 +167,7 @@ def test_normals_knn_equals_oracle_at_full_size(data):
     assert np.array_equal(nn40, orc.knn(Xf, Xf[sub], k=40)[0])
 
 
+@pytest.mark.slow
 def test_select_in_range_at_full_size(data):
     """select_in_range with ALL 10 M fixed points as queries against the 10 M movable cloud under a rigid H
     (pointcloud.py:161-167, strict `<`): 2000 sampled verdicts against orc.knn(max_dist), plus a bound chosen ON a
@@ -270,6 +271,7 @@ def check_large_q_iteration(c, Xf, Xm, sel, nv, pl, x, R, n_sample, min_planarit
     return ox
 
 
+@pytest.mark.slow
 def test_large_q_iterations_equal_oracle_at_full_size(data, big_q):
     """10 M clouds, Q = 1 M: three iterations of the many-workgroup path (a6-a10 at C5-class Q)."""
     Xf, Xm, H_true, _ = data
@@ -290,6 +292,7 @@ def test_large_q_iterations_equal_oracle_at_full_size(data, big_q):
     assert whole[-1].n_kept == R.n_kept and abs(whole[-1].median - R.median) < 1e-12 and abs(whole[-1].mad - R.mad) < 1e-12
 
 
+@pytest.mark.slow
 def test_normals_at_one_million_queries_equal_oracle(data, big_q):
     """estimate_normals at Q = 1 M on 10 M points (pointcloud.py:173-203; C5-class Q): the one-sweep k-NN + covariance kernel with
     a few cell-ordered queries per wave.  A 3 000-query sample against the oracle's brute-force k-NN over the whole cloud -- indices
@@ -315,6 +318,7 @@ def test_normals_at_one_million_queries_equal_oracle(data, big_q):
     assert work["candidates"] <= 200 * len(sel), work              # (round 3's k-round search read ~20 x that)
 
 
+@pytest.mark.slow
 def test_mid_q_iteration_equals_oracle_at_full_size(data, big_q):
     """... and Q = 100 000 (SURVEY 8d's throughput point) on the same resident clouds."""
     Xf, Xm, H_true, _ = data

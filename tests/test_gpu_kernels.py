@@ -921,7 +921,7 @@ def test_rejection_longest_barrier_road_over_chained_launches():
     1 500 equal keys at the median (the window's analysis accepts the bin, but one block alone finds more of them than its list
     holds: the window misses after its SECOND sweep, three barriers), and 1 400 equal keys at the MAD's rank -- so the general
     form that follows walks all six digit passes for both statistics (more than 256 equal keys never fit the candidate list):
-    3 + 2 x 7 + 1 = 18 barriers per launch from the third launch of a run on.  All parameters fixed (infinite weights): every
+    3 + 2 x 7 = 17 barriers per launch from the third launch of a run on.  All parameters fixed (infinite weights): every
     iteration sees the same distances, so every launch must return the oracle's numbers."""
     from simpleicp_amd import _lib
     Q = 40_000
