@@ -91,7 +91,7 @@ __device__ __forceinline__ unsigned long long wsum_u64(unsigned long long v)
 //     stores (performed at the coherence point), and whatever they read again in the next phase stays in their L2;
 //   * 256 same-address read-modify-writes serialise at ~20 ns apiece (5 us): arrivals are counted in 8 groups (blockIdx & 7, a
 //     line each) whose last member reports to a top counter -- 32 + 8 in a row instead of 256.
-// The last arriver of a counter resets it BEFORE it reports upwards, the last of all then publishes the barrier's number in
+// The counters wrap to zero at their last arrival (atomicInc), the last arriver of all then publishes the barrier's number in
 // `gen`, the only word the waiting blocks poll.  Barrier numbers grow monotonically over the life of the buffer: the host hands
 // every launch the number it starts from (launch index * the kernel's barrier budget) -- nothing to reset between launches, and a
 // launch that leaves early leaves nothing behind.  Polling is bounded (about two seconds): a launch that cannot meet itself
@@ -118,12 +118,11 @@ __device__ __forceinline__ void grid_barrier(GridBar *B, unsigned long long numb
         const unsigned g = gridDim.x + absent, flat = g <= 64u ? 1u : 0u, c = flat ? 0u : (blockIdx.x & 7u);
         const unsigned n_c = flat ? g : ((g + 7u - c) >> 3), groups = flat ? 1u : 8u;
         bool opener = false;
-        if (__hip_atomic_fetch_add(&B->sub[c].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_c - 1u) {
-            __hip_atomic_store(&B->sub[c].v, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (__hip_atomic_fetch_add(&B->top.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u) {
-                __hip_atomic_store(&B->top.v, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // arrivals are counted with a WRAPPING increment (atomicInc: back to 0 at the last arrival), so the last arriver has nothing
+        // to reset before it reports upwards -- round 5 stored 0 and drained that store first: one dependent device-scope round trip
+        // per level, ~1 us each (profiles/r6)
+        if (atomicInc(&B->sub[c].v, n_c - 1u) == n_c - 1u) {
+            if (flat || atomicInc(&B->top.v, groups - 1u) == groups - 1u) {
                 __hip_atomic_store(&B->gen, number, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 opener = true;
             }

@@ -626,14 +626,19 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
     bool win = A.window != 0 && pmad > 0.0 && pmad < __builtin_inf() && pcnt > 0;
     const double hw_med = pmad * fmin(0.25, 75.0 / (double)pcnt), hw_mad = pmad * fmin(0.25, 47.0 / (double)pcnt);
     if (win) window_collect<EPT>(S, 0, key, okey(pmed - hw_med), okey(pmed + hw_med));
-    // survivors of the planarity test and the range of their distances: wave reductions + one barrier
-    dmn = wmin_f64(dmn); dmx = wmin_f64(-dmx);
-    if ((tid & 63) == 0) { S.wcnt[wid] = nflag; S.dmm[wid][0] = dmn; S.dmm[wid][1] = dmx; }
+    // survivors of the planarity test: wave counts + one barrier.  The RANGE of their distances (two wave reductions, the histogram
+    // selection's first interval) is only formed when that selection runs: a settled run reads both statistics off its windows
+    bool have_range = !win;
+    if (have_range) { dmn = wmin_f64(dmn); dmx = wmin_f64(-dmx); }
+    if ((tid & 63) == 0) { S.wcnt[wid] = nflag; if (have_range) { S.dmm[wid][0] = dmn; S.dmm[wid][1] = dmx; } }
     __syncthreads();
     long m = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) { m += S.wcnt[w]; dmn = fmin(dmn, S.dmm[w][0]); dmx = fmin(dmx, S.dmm[w][1]); }
-    unsigned long long klo = okey(dmn), khi = okey(-dmx);
+    for (int w = 0; w < NW; ++w) m += S.wcnt[w];
+    if (have_range) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { dmn = fmin(dmn, S.dmm[w][0]); dmx = fmin(dmx, S.dmm[w][1]); }
+    }
     tk[1] = clock64();
 
     if (m == 0) {
@@ -658,9 +663,6 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         if (which == 1) {
 #pragma unroll
             for (int e = 0; e < EPT; ++e) if (fl[e]) key[e] = okey(fabs(d[e] - med));
-            // |d - med| is monotone in d on either side of med: its range follows from the distances' own
-            const double u = fabs(oval(klo) - med), v = fabs(oval(khi) - med);
-            klo = okey(0.0); khi = okey(u > v ? u : v);
             tsel = clock64();
             if (win) {
                 window_collect<EPT>(S, 1, key, okey(fmax(pmad - hw_mad, 0.0)), okey(pmad + hw_mad));
@@ -675,7 +677,21 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
 #endif
         // (one miss ends the attempts of this launch: a median that moved takes the MAD with it)
         if (win) win = window_pick(S, which, (m - 1) / 2, (m & 1) == 0, ka, kb);
-        if (!win) block_select<EPT>(S, hc, key, (m - 1) / 2, (m & 1) == 0, klo, khi, ka, kb, nr);
+        if (!win) {
+            if (!have_range) {
+                // the window missed: the distances' range after all (dmn / dmx still hold this lane's own: d is untouched)
+                dmn = wmin_f64(dmn); dmx = wmin_f64(-dmx);
+                if ((tid & 63) == 0) { S.dmm[wid][0] = dmn; S.dmm[wid][1] = dmx; }
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { dmn = fmin(dmn, S.dmm[w][0]); dmx = fmin(dmx, S.dmm[w][1]); }
+                have_range = true;
+            }
+            // the interval that holds every key: the distances' own, or (|d - med| is monotone in d on either side of med) what follows from it
+            unsigned long long klo = okey(dmn), khi = okey(-dmx);
+            if (which == 1) { const double u = fabs(dmn - med), v = fabs(-dmx - med); klo = okey(0.0); khi = okey(u > v ? u : v); }
+            block_select<EPT>(S, hc, key, (m - 1) / 2, (m & 1) == 0, klo, khi, ka, kb, nr);
+        }
         const double mid = (oval(ka) + oval(kb)) / 2.0;
         if (which == 0) { med = mid; rounds[0] = nr; } else { mad = mid; rounds[1] = nr; }
     }
