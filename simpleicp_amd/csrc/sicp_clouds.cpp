@@ -32,7 +32,8 @@ int grid_build(sicp_ctx *c, int slot, long icp_queries)
 }
 
 // the cloud's subsample (every SUB_STRIDE-th point) and its grid
-constexpr long SUB_STRIDE = 64;       // (measured 64 / 16 / 8: 152 / 128 / 122 candidates per query of the cold search -- the subsample's own search pays the difference back)
+constexpr long SUB_STRIDE = 64;       // (measured 64 / 16 / 8: 152 / 128 / 122 candidates per query of the cold search -- the subsample's own search pays the difference back;
+                                      //  again in round 6 at the headline workload, 64 / 32 / 16: the cold first match 27.4 / 27.1 / 27.8 us -- while the clouds are metres apart the answer itself is far)
 int subsample_build(sicp_ctx *c, int slot)
 {
     Cloud &cl = c->cloud[slot];

@@ -86,7 +86,8 @@ struct TailShared {
     unsigned long long cand[CAND_MAX];
     unsigned ncand;
     unsigned wcnt[NW];
-    double out[64];                        // record / loop state on their way out (wave 0)
+    double out[64];                        // the record on its way out (wave 0)
+    double out2[64];                       // the next iteration's loop state on its way out (wave 1, at the same time)
 };
 
 // block-wide sums of NV values per lane; every lane returns with the totals (fixed order)
@@ -533,10 +534,10 @@ __device__ __forceinline__ void eval_ne_mfma(TailShared &S, const double (&x)[6]
 // (vmcnt(0)), then the ticket as one more such store.  No fence: the host reads nothing else this kernel wrote.  (Round 5 issued
 // __threadfence_system() AND a release store; measured side by side in round 6, profiles/r6: the same 13.0 us per launch -- the
 // kernel's end writes the L2 back anyway -- so the simpler form stays.)
-__device__ __forceinline__ void flush_out(TailShared &S, double *dst, int count)
+__device__ __forceinline__ void flush_state(TailShared &S, double *dst, int count)
 {
-    const int lane = threadIdx.x;
-    if (lane < count) dst[lane] = S.out[lane];
+    const int lane = threadIdx.x & 63;
+    if (lane < count) dst[lane] = S.out2[lane];
 }
 __device__ __forceinline__ void flush_rec(TailShared &S, double *rec, int count)
 {
@@ -847,8 +848,35 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
         const double cs = prev_std == 0.0 ? (rstd == 0.0 ? 0.0 : __builtin_inf()) : fabs((rstd - prev_std) / prev_std * 100.0);
         conv = cm < A.min_change && cs < A.min_change;
     }
-    if (wid != 0) return;
-    // ---- wave 0: the record (pinned host memory) and the next iteration's start (device) leave as two stores ----
+    if (wid > 1) return;
+    if (wid == 1) {
+        // ---- wave 1: the next iteration's start (estimate, its sin / cos, H(x) and the rigid inverse [R^T | -R^T t]) leaves as one
+        //      store -- while wave 0 assembles and publishes the record (every lane of every wave holds the same estimate) ----
+        if (tid == 64) {
+            IcpDev n;
+            double Hn[12];
+            euler_H(x, sc, Hn);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { n.x[j] = x[j]; n.sc[j] = sc[j]; }
+#pragma unroll
+            for (int j = 0; j < 12; ++j) n.H.m[j] = Hn[j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) n.Hinv.m[4 * i + j] = Hn[4 * j + i];
+                n.Hinv.m[4 * i + 3] = -(Hn[i] * Hn[3] + Hn[4 + i] * Hn[7] + Hn[8 + i] * Hn[11]);
+            }
+            n.w = w; n.prev_mean = rmean; n.prev_std = rstd;
+            n.done_iters = done_iters + 1; n.stop = (conv || !finite) ? 1 : 0; n.sel_m = (int)m; n.pad = 0;
+            n.sel_med = med; n.sel_mad = mad;
+            const double *src = reinterpret_cast<const double *>(&n);
+#pragma unroll
+            for (int j = 0; j < ST_DOUBLES; ++j) S.out2[j] = src[j];
+        }
+        flush_state(S, reinterpret_cast<double *>(st), ST_DOUBLES);
+        return;
+    }
+    // ---- wave 0: the record (pinned host memory) ----
     if (tid < 30) {
         // record layout of the 30 sums: 21 upper-triangle entries of J^T J (row-major), 6 of J^T r, sum r, sum r^2, n
         int u = 0, v = 0;
@@ -886,29 +914,6 @@ __global__ __launch_bounds__(TB, 1) void k_icp_tail(
     }
     flush_rec(S, rec, REC_TICKET);
     publish(rec, A.seq);
-    // the next iteration's start: estimate, its sin / cos, H(x) and the rigid inverse [R^T | -R^T t]
-    if (tid == 0) {
-        IcpDev n;
-        double Hn[12];
-        euler_H(x, sc, Hn);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) { n.x[j] = x[j]; n.sc[j] = sc[j]; }
-#pragma unroll
-        for (int j = 0; j < 12; ++j) n.H.m[j] = Hn[j];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) n.Hinv.m[4 * i + j] = Hn[4 * j + i];
-            n.Hinv.m[4 * i + 3] = -(Hn[i] * Hn[3] + Hn[4 + i] * Hn[7] + Hn[8 + i] * Hn[11]);
-        }
-        n.w = w; n.prev_mean = rmean; n.prev_std = rstd;
-        n.done_iters = done_iters + 1; n.stop = (conv || !finite) ? 1 : 0; n.sel_m = (int)m; n.pad = 0;
-        n.sel_med = med; n.sel_mad = mad;
-        const double *src = reinterpret_cast<const double *>(&n);
-#pragma unroll
-        for (int j = 0; j < ST_DOUBLES; ++j) S.out[j] = src[j];
-    }
-    flush_out(S, reinterpret_cast<double *>(st), ST_DOUBLES);
 }
 
 void launch_icp_tail(hipStream_t s, const double *qx, const double *qy, const double *qz, const float *normals,
