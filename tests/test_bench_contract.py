@@ -18,7 +18,7 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-RECORDS = sorted((ROOT / "profiles" / "r5").glob("bench_*.json"))
+RECORDS = sorted((ROOT / "profiles" / "r6").glob("bench_*.json"))
 CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline")
 
@@ -57,7 +57,7 @@ def test_committed_record_honours_the_contract(path):
 
 
 def test_final_headline_record_quotes_counter_traffic_of_its_own_tree():
-    d = json.loads((ROOT / "profiles" / "r5" / "bench_C4.json").read_text())
+    d = json.loads((ROOT / "profiles" / "r6" / "bench_C4.json").read_text())
     pmc = json.loads((ROOT / "profiles" / "latest_pmc.json").read_text())
     assert d["roofline"]["kernel"] == "k_icp_tail" and d["roofline"]["traffic"] == pytest.approx(pmc["k_icp_tail"], rel=1e-3)
     assert d["roofline_match"]["traffic"] == pytest.approx(pmc["k_grid_nn"], rel=1e-3)
@@ -68,7 +68,7 @@ def test_final_headline_record_quotes_counter_traffic_of_its_own_tree():
 
 def test_compact_line_keeps_the_contract_and_fits_a_log_tail():
     import bench
-    out = json.loads((ROOT / "profiles" / "r5" / "bench_C4.json").read_text())
+    out = json.loads((ROOT / "profiles" / "r6" / "bench_C4.json").read_text())
     line = bench.compact_line(out)
     text = json.dumps(line)
     assert len(text) < 8192 and "\n" not in text
