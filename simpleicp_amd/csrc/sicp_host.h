@@ -173,9 +173,10 @@ struct sicp_ctx {
     DevBuf<int64_t> bound_idx;
     int coarse_iters = 1;          // chained iterations (from a cold start) whose search is bounded by the subsample's (more than one helped nowhere)
     long coarse_min_n = 262144;    // ... for clouds of at least this many points
-    long nn16_min_q = 8192;        // SICP_NN16_MIN_Q: from this many queries per launch on the grid search runs four queries per wave (measured on 10 M
-                                   // points: steady match 10.2 us against 35.7 at 16 384 queries, 19.9 / 69.7 at 32 768 -- one wave per query stops
-                                   // being latency-bound at ~4 000 queries; its fused distance epilogue is worth a launch, ~4 us)
+    long nn16_min_q = 5120;        // SICP_NN16_MIN_Q: from this many queries per launch on the grid search runs four queries per wave.  Round 5 measured
+                                   // the crossover at 8 192 -- when the four-per-wave kernel still needed k_postmatch's launch behind it; with its own
+                                   // distance epilogue (round 6, below 65 536 queries) it wins from ~5 000: match per launch at 4 096 / 6 000 / 8 191
+                                   // queries 13.4 / 16.0 / 19.2 us with one wave per query, 15.3 / 14.5 / 15.6 with four (profiles/r6/nn16_crossover.txt)
     int nn16_filter = 2;           // SICP_NN16 = exact (0: k_grid_nn16) | far (1: the filtered search, one flavour) | near (2, default: the lean
                                    // flavour first, the full one for what it leaves)
     int dl_threads = 16;                  // host threads that fan a downloaded chunk out into the caller's arrays (run() at C4: 32 / 25 / 25 ms with 8 / 16 / 32)
