@@ -40,8 +40,8 @@ extern "C" {
  * sicp_cloud_download_columns, sicp_match_work; sicp_timing_enable(ctx, 2); every upload resets the slot's planarity
  * column.  3: + sicp_comm_activate, sicp_comm_info, sicp_device_memory; SICP_K_XCHG; sicp_comm_init bounded + handshake.  4: + sicp_knn_work, sicp_cloud_download_both; sicp_estimate_normals runs the one-sweep k-NN + covariance kernel.  5: + sicp_match_deferred, sicp_tail_cycles; kind 6 of sicp_last_match_kernel.
  * 6: + SICP_XCHG_MIN_U64 / SICP_XCHG_MAX_U64 (asked of a registered callback with count = 0 first: a callback written for ABI 5 answers
- * non-zero and keeps the all-gather exchange), sicp_tail_selection, sicp_exchange_info.  A binding checks sicp_abi_version() against the header it was written for. */
-#define SICP_ABI_VERSION 6
+ * non-zero and keeps the all-gather exchange), sicp_tail_selection, sicp_exchange_info.  7: + sicp_cloud_upload_start, sicp_cloud_upload_wait.  A binding checks sicp_abi_version() against the header it was written for. */
+#define SICP_ABI_VERSION 7
 
 #define SICP_OK               0
 #define SICP_ERR_INVALID     -1   /* bad argument / wrong call order                         */
@@ -72,6 +72,15 @@ int sicp_cloud_upload(sicp_ctx *ctx, int slot, const double *xyz, int64_t n, int
  * assigned, pointcloud.py:215-217): they are copied straight into the column-wise device layout. */
 int sicp_cloud_upload_columns(sicp_ctx *ctx, int slot, const double *x, const double *y, const double *z, int64_t n,
                               int64_t index_base);
+/* The same upload BEHIND the caller (ABI 7): xyz (rows) or x, y, z (columns), the other(s) NULL.  Returns once the device arrays are
+ * sized; a helper thread of the library moves the data on a stream of its own, so the caller can go on working on the OTHER slot
+ * (SimpleICP.run builds the fixed cloud's grid and normals behind the movable cloud's upload, simpleicp.py:161-178).  The source
+ * arrays must stay alive and unchanged until sicp_cloud_upload_wait -- or any other call naming the slot, which waits first and
+ * returns the upload's error if it had one (then the slot is empty).  One at a time: a start on the other slot waits for the first to finish (whose verdict stays with its own slot).  Clouds
+ * of at most 2^19 points and device pointers are uploaded on the spot. */
+int sicp_cloud_upload_start(sicp_ctx *ctx, int slot, const double *xyz, const double *x, const double *y, const double *z,
+                            int64_t n, int64_t index_base);
+int sicp_cloud_upload_wait(sicp_ctx *ctx, int slot);
 int sicp_cloud_size(sicp_ctx *ctx, int slot, int64_t *n_out);
 /* PointCloud.transform_by_H (pointcloud.py:205-217): in-place, contract (T).  */
 int sicp_cloud_transform(sicp_ctx *ctx, int slot, const double H[16]);

@@ -23,7 +23,7 @@ def timed(name):
     setattr(_lib.Context, name, wrap)
 
 
-for m in ("upload", "upload_columns", "download_both", "transform", "estimate_normals", "icp_setup", "icp_run", "icp_state", "icp_uncertainties"):
+for m in ("upload", "upload_columns", "upload_start", "upload_wait", "download_both", "transform", "estimate_normals", "icp_setup", "icp_run", "icp_state", "icp_uncertainties"):
     timed(m)
 
 

@@ -21,13 +21,13 @@ OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_TOO_FEW, ERR_NUMERIC, ERR_EXCHANGE 
 XCHG_ALLGATHER_F64, XCHG_SUM_F64, XCHG_MIN_U64, XCHG_MAX_U64 = 1, 2, 3, 4
 PART_CLOUD, PART_QUERIES = 0, 1
 K_KNN1, K_KNNK, K_NORMALEQ, K_SELECT, K_XCHG = 0, 1, 2, 3, 4
-ABI_VERSION = 6          # include/simpleicp_hip.h SICP_ABI_VERSION this binding was written for
+ABI_VERSION = 7          # include/simpleicp_hip.h SICP_ABI_VERSION this binding was written for
 KERNEL_NAMES = {K_KNN1: "match", K_KNNK: "knnk_scan", K_NORMALEQ: "solve", K_SELECT: "reject_select", K_XCHG: "exchange"}
 MATCH_KERNELS = {0: "k_knn1_scan", 1: "k_knn1_fscan", 2: "k_grid_nn", 3: "k_knn1_frec", 5: "k_grid_nn16", 6: "k_grid_nn16f"}
 
 EXPORTS = [
     "sicp_abi_version", "sicp_last_error", "sicp_device_count", "sicp_ctx_create", "sicp_ctx_destroy",
-    "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_upload_columns", "sicp_cloud_size", "sicp_cloud_transform",
+    "sicp_ctx_device_name", "sicp_cloud_upload", "sicp_cloud_upload_columns", "sicp_cloud_upload_start", "sicp_cloud_upload_wait", "sicp_cloud_size", "sicp_cloud_transform",
     "sicp_cloud_download", "sicp_cloud_download_columns", "sicp_cloud_download_both", "sicp_cloud_set_planarity", "sicp_knn", "sicp_select_in_range", "sicp_estimate_normals", "sicp_icp_setup", "sicp_icp_iterate",
     "sicp_icp_run", "sicp_icp_get_state", "sicp_icp_uncertainties", "sicp_icp_normal_equations", "sicp_params_to_H",
     "sicp_corr_match", "sicp_corr_reject_planarity", "sicp_corr_reject_distances", "sicp_estimate_parameters",
@@ -91,6 +91,8 @@ def load():
     L.sicp_ctx_device_name.argtypes = [vp, C.c_char_p, cint]
     L.sicp_cloud_upload.argtypes = [vp, cint, vp, i64, i64]
     L.sicp_cloud_upload_columns.argtypes = [vp, cint, vp, vp, vp, i64, i64]
+    L.sicp_cloud_upload_start.argtypes = [vp, cint, vp, vp, vp, vp, i64, i64]
+    L.sicp_cloud_upload_wait.argtypes = [vp, cint]
     L.sicp_cloud_size.argtypes = [vp, cint, C.POINTER(i64)]
     L.sicp_cloud_transform.argtypes = [vp, cint, vp]
     L.sicp_cloud_download.argtypes = [vp, cint, vp]
@@ -181,6 +183,7 @@ class Context:
             raise BackendError(self._L.sicp_last_error().decode(), rc)
         self.device = int(device)
         self._corr_owner = None      # the CorrPts object whose correspondences the context holds (simpleicp_amd/corrpts.py)
+        self._bg_src = {}            # slot -> the host arrays an upload_start is still reading (kept alive until the slot's next upload)
 
     # -- plumbing --
     def _chk(self, rc):
@@ -227,6 +230,33 @@ class Context:
             raise ValueError("x, y, z must be vectors of the same length")
         self._chk(self._L.sicp_cloud_upload_columns(self._h, slot, _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2]), n,
                                                     int(index_base)))
+
+    def upload_start(self, slot, xyz=None, columns=None, index_base=0):
+        """The same upload running BEHIND the caller (sicp_cloud_upload_start): (n,3) rows OR three contiguous columns.  Returns once
+        the device arrays are sized; any later call naming the slot waits for it first (and raises its error).  The source arrays are
+        kept alive here; the caller must not write to them before `upload_wait` / the next call on the slot."""
+        if (xyz is None) == (columns is None):
+            raise ValueError("xyz OR columns")
+        if xyz is not None:
+            src = [_f64(xyz) if isinstance(xyz, np.ndarray) else xyz]
+            n = int(src[0].shape[0])
+            if tuple(src[0].shape) != (n, 3):
+                raise ValueError("cloud must have shape (n, 3)")
+            args = (_ptr(src[0]), None, None, None)
+        else:
+            src = [_f64(np.asarray(v)) for v in columns]
+            n = len(src[0])
+            if len(src) != 3 or any(v.ndim != 1 or len(v) != n for v in src):
+                raise ValueError("x, y, z must be vectors of the same length")
+            args = (None, _ptr(src[0]), _ptr(src[1]), _ptr(src[2]))
+        self._bg_src[slot] = src
+        self._chk(self._L.sicp_cloud_upload_start(self._h, slot, *args, n, int(index_base)))
+
+    def upload_wait(self, slot):
+        try:
+            self._chk(self._L.sicp_cloud_upload_wait(self._h, slot))
+        finally:
+            self._bg_src.pop(slot, None)
 
     def size(self, slot):
         n = C.c_int64()

@@ -82,6 +82,7 @@ int check_slot(sicp_ctx *c, int slot, bool need_data)
 {
     if (!c) return fail(SICP_ERR_INVALID, "null ctx");
     if (slot != SICP_FIX && slot != SICP_MOV) return fail(SICP_ERR_INVALID, "slot must be SICP_FIX or SICP_MOV");
+    CHK(upload_join(c, slot));                            // (an upload still running behind the caller: wait, hand over its verdict)
     if (need_data && c->cloud[slot].n <= 0) return fail(SICP_ERR_INVALID, "cloud slot %d is empty", slot);
     return SICP_OK;
 }
@@ -198,6 +199,10 @@ SICP_EXPORT int sicp_ctx_destroy(sicp_ctx *c)
 {
     if (!c) return SICP_OK;
     (void)hipSetDevice(c->device);
+    for (int s = 0; s < 2; ++s) (void)upload_join(c, s);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); c->copy_stream = nullptr; }
+    if (c->h_bg) { (void)hipHostFree(c->h_bg); c->h_bg = nullptr; }
+    c->stage_bg.release(); c->bg_small.release();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)rccl()->CommDestroy(c->comm); c->comm = nullptr; }
     if (c->h_dl) { (void)hipHostFree(c->h_dl); c->h_dl = nullptr; }

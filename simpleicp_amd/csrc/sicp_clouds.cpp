@@ -2,6 +2,8 @@
 // subsample, its coarse twin, its companions, the orders queries are taken in).  Split from sicp_api.cpp (round 5).
 #include "sicp_host.h"
 
+#include <emmintrin.h>
+
 namespace sicph {
 
 // icp_queries: how many queries per launch the MATCH of an ICP run is about to send (its caller passes the rank's own count); -1: any
@@ -315,7 +317,22 @@ int query_order_build(sicp_ctx *c, long lo, long cnt, double h)
 }  // namespace sicph
 
 namespace sicph {
-// shared by the two upload flavours: validates, sizes the padded SoA arrays
+// An upload that runs behind its caller (sicp_cloud_upload_start): joined -- and its verdict delivered -- by the first call that names
+// the slot (check_slot), by sicp_cloud_upload_wait, by the next background upload and by sicp_ctx_destroy.
+int upload_join(sicp_ctx *c, int slot)
+{
+    BgUpload &b = c->bg[slot];
+    if (!b.active) return SICP_OK;
+    if (b.th.joinable()) b.th.join();
+    b.active = false;
+    if (b.rc != SICP_OK) {
+        c->cloud[slot].n = 0;                          // (nothing usable arrived)
+        return fail(b.rc, "%s", b.err.c_str());
+    }
+    return SICP_OK;
+}
+
+// shared by the upload flavours: validates, sizes the padded SoA arrays
 int upload_begin(sicp_ctx *c, int slot, int64_t n, int64_t index_base)
 {
     CHK(check_slot(c, slot, false));
@@ -326,23 +343,26 @@ int upload_begin(sicp_ctx *c, int slot, int64_t n, int64_t index_base)
     cl.n = n; cl.npad = round_up(n, TILE_PTS); cl.idx_base = index_base;
     cl.grid.valid = false; cl.sub_grid.valid = false; cl.coarse_grid.valid = false;
     cl.pl_n = 0;                                       // a new cloud has no planarity column until one is set
+    // (a new movable cloud: earlier matches are not its points -- neither the by-query ones nor those the filtered search keeps by slot,
+    // which an operator-route match in between would not rebuild)
+    if (slot == SICP_MOV) { c->have_prev_match = false; c->slot_cnt = -1; }
     CHK(cl.xyz.reserve((size_t)3 * cl.npad));
     return SICP_OK;
 }
 
 // ... and finishes: ONE statistics pass gives the largest norm (rounding-error bounds of the filtered / grid searches;
-// a non-finite cloud is refused like cKDTree would) and the bounding box the grid build starts from
-int cloud_stats(sicp_ctx *c, int slot)
+// a non-finite cloud is refused like cKDTree would) and the bounding box the grid build starts from.
+// (s, d_st, h_st: the stream and the 7-word scratch, device + pinned -- the ctx's own, or a background upload's)
+int cloud_stats_on(sicp_ctx *c, int slot, hipStream_t s, unsigned long long *d_st, double *h_st)
 {
     Cloud &cl = c->cloud[slot];
-    unsigned long long *d_st = (unsigned long long *)(c->small.p + 40);       // 7 u64
     unsigned long long h_init[7] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull, 0ull};
-    HIPCHK(hipMemcpyAsync(d_st, h_init, sizeof h_init, hipMemcpyHostToDevice, c->stream));
-    launch_cloud_stats(c->stream, cl.x(), cl.y(), cl.z(), cl.n, d_st);
+    HIPCHK(hipMemcpyAsync(d_st, h_init, sizeof h_init, hipMemcpyHostToDevice, s));
+    launch_cloud_stats(s, cl.x(), cl.y(), cl.z(), cl.n, d_st);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_small + 40, d_st, 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    CHK(sync(c));
-    unsigned long long hk[7]; std::memcpy(hk, c->h_small + 40, sizeof hk);
+    HIPCHK(hipMemcpyAsync(h_st, d_st, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (s == c->stream) CHK(sync(c)); else HIPCHK(hipStreamSynchronize(s));
+    unsigned long long hk[7]; std::memcpy(hk, h_st, sizeof hk);
     double nn; std::memcpy(&nn, &hk[6], sizeof nn);
     if (!std::isfinite(nn)) {
         cl.n = 0;                                    // like cKDTree (pointcloud.py:161,185): no search structure over NaN / inf
@@ -350,10 +370,12 @@ int cloud_stats(sicp_ctx *c, int slot)
     }
     cl.rmax = std::sqrt(nn) * (1.0 + 1e-12);
     for (int a = 0; a < 3; ++a) { cl.bb_lo[a] = key_to_double(hk[a]); cl.bb_hi[a] = key_to_double(hk[3 + a]); }
-    // (a new movable cloud: earlier matches are not its points -- neither the by-query ones nor those the filtered search keeps by slot,
-    // which an operator-route match in between would not rebuild)
-    if (slot == SICP_MOV) { c->have_prev_match = false; c->slot_cnt = -1; }
     return SICP_OK;
+}
+int cloud_stats(sicp_ctx *c, int slot)
+{
+    if (slot == SICP_MOV) { c->have_prev_match = false; c->slot_cnt = -1; }       // (sicp_cloud_transform comes here too: the points moved)
+    return cloud_stats_on(c, slot, c->stream, (unsigned long long *)(c->small.p + 40), c->h_small + 40);
 }
 int upload_end(sicp_ctx *c, int slot) { return cloud_stats(c, slot); }
 
@@ -363,11 +385,13 @@ int upload_end(sicp_ctx *c, int slot) { return cloud_stats(c, slot); }
 // ~0.1 ms per MB and always the same.  Rows are transposed (or columns copied) by the host on the way, chunk ch + 1 while chunk ch
 // is on the link.  Above UPLOAD_STAGED_MAX points the pinning is the smaller price.
 constexpr int64_t UPLOAD_STAGED_MAX = 1 << 19;       // (one chunk: ~1.5 ms of host copy at most)
+constexpr long DL_CH = 1L << 19;          // the download's chunks: 512 Ki points = 12 MiB
+constexpr int DL_RING = 4;                // ... in flight: the pinned block is DL_RING x 3 x DL_CH doubles (48 MiB), on first use
 int upload_staged(sicp_ctx *c, Cloud &cl, const double *xyz, const double *x, const double *y, const double *z, int64_t n)
 {
-    const long CH = 1L << 19;                                 // (the download's buffers: 2 x 3 x 512 Ki doubles)
-    if (!c->h_dl) HIPCHK(hipHostMalloc((void **)&c->h_dl, (size_t)2 * 3 * CH * sizeof(double), hipHostMallocDefault));
-    if (!c->dl_ev[0]) { HIPCHK(hipEventCreateWithFlags(&c->dl_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->dl_ev[1], hipEventDisableTiming)); }
+    const long CH = DL_CH;
+    if (!c->h_dl) HIPCHK(hipHostMalloc((void **)&c->h_dl, (size_t)DL_RING * 3 * DL_CH * sizeof(double), hipHostMallocDefault));      // (the download's ring; two of its buffers serve here)
+    for (auto &e : c->dl_ev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const long nchunks = (n + CH - 1) / CH;
     for (long ch = 0; ch < nchunks; ++ch) {
         const long lo = ch * CH, m = std::min<long>(CH, n - lo);
@@ -390,41 +414,102 @@ int upload_staged(sicp_ctx *c, Cloud &cl, const double *xyz, const double *x, co
     HIPCHK(hipGetLastError());
     return SICP_OK;
 }
+
+// a large cloud's way to the device: straight out of the caller's arrays (rows through an AoS staging block on the device, columns into
+// place), on stream s
+int upload_direct(sicp_ctx *c, Cloud &cl, const double *xyz, const double *x, const double *y, const double *z, int64_t n, hipStream_t s,
+                  DevBuf<double> &stage)
+{
+    if (xyz) {
+        CHK(stage.reserve((size_t)3 * n));
+        HIPCHK(hipMemcpyAsync(stage.p, xyz, (size_t)3 * n * sizeof(double), hipMemcpyDefault, s));
+        launch_aos_to_soa(s, stage.p, n, cl.npad, cl.x(), cl.y(), cl.z());
+    } else {
+        // the device layout is column-wise already: three copies straight into place, no staging, no transpose
+        HIPCHK(hipMemcpyAsync(cl.x(), x, (size_t)n * sizeof(double), hipMemcpyDefault, s));
+        HIPCHK(hipMemcpyAsync(cl.y(), y, (size_t)n * sizeof(double), hipMemcpyDefault, s));
+        HIPCHK(hipMemcpyAsync(cl.z(), z, (size_t)n * sizeof(double), hipMemcpyDefault, s));
+        launch_pad_fill(s, cl.x(), cl.y(), cl.z(), n, cl.npad);
+    }
+    HIPCHK(hipGetLastError());
+    return SICP_OK;
+}
+
+int upload_now(sicp_ctx *c, int slot, const double *xyz, const double *x, const double *y, const double *z, int64_t n, int64_t index_base)
+{
+    CHK(upload_begin(c, slot, n, index_base));
+    Cloud &cl = c->cloud[slot];
+    if (n <= UPLOAD_STAGED_MAX && c->upload_staged) CHK(upload_staged(c, cl, xyz, x, y, z, n));
+    else CHK(upload_direct(c, cl, xyz, x, y, z, n, c->stream, c->stage));
+    return upload_end(c, slot);
+}
+
+// The same upload on a helper thread with a stream, a staging block and statistics scratch of its own: a DMA out of pageable memory
+// holds the calling thread until it is done (4.5 ms per 10 M points, profiles/r6/pageable_async.txt), and run() has the fixed cloud's
+// grid and normals to build meanwhile.  Small clouds (the staged road shares the download's pinned ring) are uploaded on the spot.
+int upload_start(sicp_ctx *c, int slot, const double *xyz, const double *x, const double *y, const double *z, int64_t n, int64_t index_base)
+{
+    if (!c) return fail(SICP_ERR_INVALID, "null ctx");
+    if (slot != SICP_FIX && slot != SICP_MOV) return fail(SICP_ERR_INVALID, "slot must be SICP_FIX or SICP_MOV");
+    // one at a time (they share the stream and the scratch): the other slot's helper is waited for -- its verdict stays with ITS slot
+    if (c->bg[1 - slot].active && c->bg[1 - slot].th.joinable()) c->bg[1 - slot].th.join();
+    if (n <= UPLOAD_STAGED_MAX && c->upload_staged) return upload_now(c, slot, xyz, x, y, z, n, index_base);
+    CHK(upload_begin(c, slot, n, index_base));
+    if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->h_bg) HIPCHK(hipHostMalloc((void **)&c->h_bg, 8 * sizeof(double), hipHostMallocDefault));
+    CHK(c->bg_small.reserve(8));
+    if (xyz) CHK(c->stage_bg.reserve((size_t)3 * n));                    // (allocations stay on the calling thread)
+    BgUpload &b = c->bg[slot];
+    b.rc = SICP_OK; b.err.clear(); b.active = true;
+    try {
+        b.th = std::thread([c, slot, xyz, x, y, z, n, &b] {
+            auto body = [&]() -> int {
+                HIPCHK(hipSetDevice(c->device));
+                CHK(upload_direct(c, c->cloud[slot], xyz, x, y, z, n, c->copy_stream, c->stage_bg));
+                return cloud_stats_on(c, slot, c->copy_stream, (unsigned long long *)c->bg_small.p, c->h_bg);
+            };
+            b.rc = body();
+            if (b.rc != SICP_OK) { b.err = sicp_last_error(); (void)hipStreamSynchronize(c->copy_stream); }
+        });
+    } catch (...) {
+        // no thread to be had: upload here and now (an exception must not cross the C ABI)
+        b.active = false;
+        CHK(upload_direct(c, c->cloud[slot], xyz, x, y, z, n, c->stream, c->stage));
+        return upload_end(c, slot);
+    }
+    return SICP_OK;
+}
 }  // namespace sicph
 
 SICP_EXPORT int sicp_cloud_upload(sicp_ctx *c, int slot, const double *xyz, int64_t n, int64_t index_base)
 {
     if (!xyz) return fail(SICP_ERR_INVALID, "xyz is null");
-    CHK(upload_begin(c, slot, n, index_base));
-    Cloud &cl = c->cloud[slot];
-    if (n <= UPLOAD_STAGED_MAX && c->upload_staged) {
-        CHK(upload_staged(c, cl, xyz, nullptr, nullptr, nullptr, n));
-        return upload_end(c, slot);
-    }
-    CHK(c->stage.reserve((size_t)3 * n));
-    HIPCHK(hipMemcpyAsync(c->stage.p, xyz, (size_t)3 * n * sizeof(double), hipMemcpyDefault, c->stream));
-    launch_aos_to_soa(c->stream, c->stage.p, n, cl.npad, cl.x(), cl.y(), cl.z());
-    HIPCHK(hipGetLastError());
-    return upload_end(c, slot);
+    return upload_now(c, slot, xyz, nullptr, nullptr, nullptr, n, index_base);
 }
 
 SICP_EXPORT int sicp_cloud_upload_columns(sicp_ctx *c, int slot, const double *x, const double *y, const double *z, int64_t n,
                                           int64_t index_base)
 {
     if (!x || !y || !z) return fail(SICP_ERR_INVALID, "x / y / z is null");
-    CHK(upload_begin(c, slot, n, index_base));
-    Cloud &cl = c->cloud[slot];
-    if (n <= UPLOAD_STAGED_MAX && c->upload_staged) {
-        CHK(upload_staged(c, cl, nullptr, x, y, z, n));
-        return upload_end(c, slot);
-    }
-    // the device layout is column-wise already: three copies straight into place, no staging, no transpose
-    HIPCHK(hipMemcpyAsync(cl.x(), x, (size_t)n * sizeof(double), hipMemcpyDefault, c->stream));
-    HIPCHK(hipMemcpyAsync(cl.y(), y, (size_t)n * sizeof(double), hipMemcpyDefault, c->stream));
-    HIPCHK(hipMemcpyAsync(cl.z(), z, (size_t)n * sizeof(double), hipMemcpyDefault, c->stream));
-    launch_pad_fill(c->stream, cl.x(), cl.y(), cl.z(), n, cl.npad);
-    HIPCHK(hipGetLastError());
-    return upload_end(c, slot);
+    return upload_now(c, slot, nullptr, x, y, z, n, index_base);
+}
+
+SICP_EXPORT int sicp_cloud_upload_start(sicp_ctx *c, int slot, const double *xyz, const double *x, const double *y, const double *z,
+                                        int64_t n, int64_t index_base)
+{
+    if (!xyz && !(x && y && z)) return fail(SICP_ERR_INVALID, "xyz, or x / y / z");
+    if (xyz && (x || y || z)) return fail(SICP_ERR_INVALID, "xyz OR x / y / z, not both");
+    hipPointerAttribute_t at;
+    const void *first = xyz ? (const void *)xyz : (const void *)x;
+    if (hipPointerGetAttributes(&at, first) == hipSuccess && at.type == hipMemoryTypeDevice)
+        return upload_now(c, slot, xyz, x, y, z, n, index_base);           // (device memory: nothing holds the caller up)
+    (void)hipGetLastError();
+    return upload_start(c, slot, xyz, x, y, z, n, index_base);
+}
+
+SICP_EXPORT int sicp_cloud_upload_wait(sicp_ctx *c, int slot)
+{
+    return check_slot(c, slot, false);                 // (joins; hands over the upload's own verdict)
 }
 
 SICP_EXPORT int sicp_cloud_size(sicp_ctx *c, int slot, int64_t *n_out)
@@ -510,8 +595,43 @@ SICP_EXPORT int sicp_cloud_download_columns(sicp_ctx *c, int slot, double *x_out
 // The cloud as (n, 3) rows AND as three columns in ONE pass over the link (the Python mirror's transform_by_H needs both:
 // run() returns the rows, the DataFrame keeps the columns -- simpleicp.py:316, pointcloud.py:205-217).  Two plain downloads into
 // pageable memory cost 2 x 11-21 ms per 10 M points (the copy engine waits for the host's staging copies and page faults).
-// Here the columns are pulled chunk by chunk into a pinned double buffer at link speed while host threads fan the previous chunk
-// out into both destinations (the row form is a transpose the host does from the pinned chunk: nothing crosses the link twice).
+// Here the columns are pulled chunk by chunk into a ring of pinned buffers at link speed while host threads fan the chunks that have
+// landed out into both destinations (the row form is a transpose the host does from the pinned chunk: nothing crosses the link
+// twice).  Round 6: a ring of DL_RING chunks and no meeting of the threads per chunk -- worker t copies ITS rows of every chunk as
+// soon as the chunk is there, and a slow worker only holds up the reuse of a buffer four chunks later.  The two-buffer form met all
+// 16 threads at every chunk and slept 50 us at a time in between: 10.5 ms per 10 M points of which 0.4 were spent waiting for the
+// link (profiles/r6/download_parts_before.txt).  And the device packs the chunks first (x | y | z of a chunk back to back, 0.1 ms):
+// one 12 MiB piece per chunk for the copy engine instead of three small ones (45 -> 55 GB/s, profiles/r6/d2h_rate.txt).
+namespace sicph {
+// Streaming copy: count doubles from src to dst with non-temporal stores.  The destination is 240 + 240 MB that nobody reads soon: plain
+// stores would first pull every line in (480 MB of reads the fan-out does not need) and push the pinned ring -- which the copy
+// engine is writing -- out of the caches the threads read it from; with them the link ran at 44 GB/s beside the threads, 52 alone.
+static inline void stream_copy(double *dst, const double *src, long count)
+{
+    long i = 0;
+    if (((uintptr_t)dst & 15) && count > 0) { _mm_stream_si64((long long *)dst, *(const long long *)src); i = 1; }
+    for (; i + 1 < count; i += 2) _mm_stream_pd(dst + i, _mm_loadu_pd(src + i));
+    if (i < count) _mm_stream_si64((long long *)(dst + i), *(const long long *)(src + i));
+}
+
+// rows [a, e) of a pinned chunk (columns CH apart) into the caller's columns and / or rows starting at point `lo`
+static inline void fan_out(const double *b, long CH, long lo, long a, long e, double *xyz_out, double *x_out, double *y_out, double *z_out)
+{
+    if (e <= a) return;
+    if (x_out) {
+        stream_copy(x_out + lo + a, b + a, e - a);
+        stream_copy(y_out + lo + a, b + CH + a, e - a);
+        stream_copy(z_out + lo + a, b + 2 * CH + a, e - a);
+    }
+    if (xyz_out) {
+        long long *o = (long long *)(xyz_out + 3 * (lo + a));
+        const long long *bx = (const long long *)b, *by = (const long long *)(b + CH), *bz = (const long long *)(b + 2 * CH);
+        for (long i = a; i < e; ++i) { _mm_stream_si64(o, bx[i]); _mm_stream_si64(o + 1, by[i]); _mm_stream_si64(o + 2, bz[i]); o += 3; }
+    }
+    _mm_sfence();                                       // (the streamed stores are visible before the caller is told the chunk is done)
+}
+}  // namespace sicph
+
 SICP_EXPORT int sicp_cloud_download_both(sicp_ctx *c, int slot, double *xyz_out, double *x_out, double *y_out, double *z_out)
 {
     CHK(check_slot(c, slot, true));
@@ -519,12 +639,12 @@ SICP_EXPORT int sicp_cloud_download_both(sicp_ctx *c, int slot, double *xyz_out,
     if ((x_out || y_out || z_out) && !(x_out && y_out && z_out)) return fail(SICP_ERR_INVALID, "x_out / y_out / z_out: all or none");
     HIPCHK(hipSetDevice(c->device));
     Cloud &cl = c->cloud[slot];
-    const long n = cl.n, CH = 1L << 19;                       // 512 Ki points = 12 MiB per chunk
-    if (!c->h_dl) HIPCHK(hipHostMalloc((void **)&c->h_dl, (size_t)2 * 3 * CH * sizeof(double), hipHostMallocDefault));
-    if (!c->dl_ev[0]) { HIPCHK(hipEventCreateWithFlags(&c->dl_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->dl_ev[1], hipEventDisableTiming)); }
+    const long n = cl.n, CH = std::min<long>(DL_CH, round_up(n, 1024));      // (a small cloud is one chunk of its own size)
+    if (!c->h_dl) HIPCHK(hipHostMalloc((void **)&c->h_dl, (size_t)DL_RING * 3 * DL_CH * sizeof(double), hipHostMallocDefault));
+    for (auto &e : c->dl_ev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const long nchunks = (n + CH - 1) / CH;
-    // host threads that fan a chunk out: as many as this process may actually run on (cgroup / affinity limits, not the machine's
-    // core count), at most c->dl_threads (16), and none for clouds that are one chunk's worth of microseconds
+    // host threads that fan the chunks out: as many as this process may actually run on (cgroup / affinity limits, not the machine's
+    // core count), at most c->dl_threads, and none for clouds that are one chunk's worth of microseconds
     unsigned T = 1;
     {
         cpu_set_t set;
@@ -535,84 +655,86 @@ SICP_EXPORT int sicp_cloud_download_both(sicp_ctx *c, int slot, double *xyz_out,
         T = T < 2 ? 1 : (T > most ? most : T);
         if (n < (1L << 16)) T = 1;
     }
-    // waiting: a few polite spins, then sleep -- a spinner must not starve the thread it waits for in a one-CPU container
+    // waiting: spin while the wait is short (a chunk is ~0.12 ms of link time), then yield, and sleep only when nothing has moved for
+    // milliseconds -- a spinner must not starve the thread it waits for in a one-CPU container
     auto wait_until = [](auto &&cond) {
-        for (int spins = 0; !cond(); ++spins) {
-            if (spins < 256) std::this_thread::yield();
+        for (long spins = 0; !cond(); ++spins) {
+            if (spins < 4096) __builtin_ia32_pause();
+            else if (spins < 4096 + 4096) std::this_thread::yield();
             else std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
     };
+    CHK(c->stage.reserve((size_t)3 * nchunks * CH));
+    launch_pack_chunks(c->stream, cl.x(), cl.y(), cl.z(), n, CH, c->stage.p);
+    HIPCHK(hipGetLastError());
     auto enqueue = [&](long ch) -> int {
         const long lo = ch * CH, m = std::min(CH, n - lo);
-        double *b = c->h_dl + (size_t)(ch & 1) * 3 * CH;
-        HIPCHK(hipMemcpyAsync(b, cl.x() + lo, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(b + CH, cl.y() + lo, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(b + 2 * CH, cl.z() + lo, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipEventRecord(c->dl_ev[ch & 1], c->stream));
+        double *b = c->h_dl + (size_t)(ch % DL_RING) * 3 * CH;
+        HIPCHK(hipMemcpyAsync(b, c->stage.p + (size_t)3 * ch * CH, (size_t)(2 * CH + m) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->dl_ev[ch % DL_RING], c->stream));
         return SICP_OK;
     };
-    // workers: chunk `ready` is in its pinned buffer; worker t fans out its share and counts itself in `done`
-    std::atomic<long> ready{-1}, done{0};
+    // chunk `ready` and all before it are in their pinned buffers; parts[ch % DL_RING] counts the workers that are through with chunk ch
+    // (it only ever grows: chunk ch is done when it reaches W * (ch / DL_RING + 1))
+    unsigned W = T > 1 ? T - 1 : 1;                          // copying threads: with helpers, this thread only feeds the link
+    std::atomic<long> ready{-1};
+    std::atomic<long> parts[DL_RING];
+    for (auto &p : parts) p.store(0);
     std::atomic<bool> quit{false};
     auto work = [&](unsigned t) {
         for (long ch = 0; ch < nchunks; ++ch) {
-            wait_until([&] { return ready.load(std::memory_order_acquire) >= ch || quit.load(); });
-            if (quit.load()) return;
+            wait_until([&] { return ready.load(std::memory_order_acquire) >= ch || quit.load(std::memory_order_relaxed); });
+            if (quit.load(std::memory_order_relaxed)) return;
             const long lo = ch * CH, m = std::min(CH, n - lo);
-            const long a = m * t / T, e = m * (t + 1) / T;
-            const double *b = c->h_dl + (size_t)(ch & 1) * 3 * CH;
-            if (x_out) {
-                std::memcpy(x_out + lo + a, b + a, (size_t)(e - a) * sizeof(double));
-                std::memcpy(y_out + lo + a, b + CH + a, (size_t)(e - a) * sizeof(double));
-                std::memcpy(z_out + lo + a, b + 2 * CH + a, (size_t)(e - a) * sizeof(double));
-            }
-            if (xyz_out) {
-                double *o = xyz_out + 3 * (lo + a);
-                for (long i = a; i < e; ++i) { o[0] = b[i]; o[1] = b[CH + i]; o[2] = b[2 * CH + i]; o += 3; }
-            }
-            done.fetch_add(1, std::memory_order_release);
+            fan_out(c->h_dl + (size_t)(ch % DL_RING) * 3 * CH, CH, lo, m * t / W, m * (t + 1) / W, xyz_out, x_out, y_out, z_out);
+            parts[ch % DL_RING].fetch_add(1, std::memory_order_release);
         }
     };
     std::vector<std::thread> pool;
-    try {
-        for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
-    } catch (...) {
-        // no thread to be had (resource limits): nothing has been copied yet -- send the ones that started home and do it alone
-        // (an exception must not cross the C ABI)
-        quit.store(true);
-        for (auto &th : pool) th.join();
-        pool.clear();
-        quit.store(false);
-        T = 1;
-    }
-    int rc = nchunks > 0 ? enqueue(0) : SICP_OK;
-    for (long ch = 0; ch < nchunks && rc == SICP_OK; ++ch) {
-        // the buffer chunk ch + 1 lands in was chunk ch - 1's: every worker must be through with it
-        wait_until([&] { return done.load(std::memory_order_acquire) >= (long)(T - 1) * ch; });
-        if (ch + 1 < nchunks) rc = enqueue(ch + 1);
-        if (rc == SICP_OK && hipEventSynchronize(c->dl_ev[ch & 1]) != hipSuccess) rc = fail(SICP_ERR_HIP, "hipEventSynchronize failed");
-        if (rc != SICP_OK) break;
-        ready.store(ch, std::memory_order_release);
-        // this thread is worker 0 of the chunk
-        {
-            const long lo = ch * CH, m = std::min(CH, n - lo);
-            const long a = 0, e = m / T;
-            const double *b = c->h_dl + (size_t)(ch & 1) * 3 * CH;
-            if (x_out) {
-                std::memcpy(x_out + lo + a, b + a, (size_t)(e - a) * sizeof(double));
-                std::memcpy(y_out + lo + a, b + CH + a, (size_t)(e - a) * sizeof(double));
-                std::memcpy(z_out + lo + a, b + 2 * CH + a, (size_t)(e - a) * sizeof(double));
-            }
-            if (xyz_out) {
-                double *o = xyz_out + 3 * (lo + a);
-                for (long i = a; i < e; ++i) { o[0] = b[i]; o[1] = b[CH + i]; o[2] = b[2 * CH + i]; o += 3; }
-            }
+    if (T > 1) {
+        try {
+            for (unsigned t = 0; t < W; ++t) pool.emplace_back(work, t);
+        } catch (...) {
+            // no thread to be had (resource limits): nothing has been copied yet -- send the ones that started home and do it alone
+            // (an exception must not cross the C ABI)
+            quit.store(true);
+            for (auto &th : pool) th.join();
+            pool.clear();
+            quit.store(false);
+            T = 1; W = 1;
         }
-        // (the next round's wait covers the other workers; after the last chunk the joins do)
-        if (ch + 1 == nchunks) wait_until([&] { return done.load(std::memory_order_acquire) >= (long)(T - 1) * nchunks; });
+    }
+    auto chunk_done = [&](long ch) { return parts[ch % DL_RING].load(std::memory_order_acquire) >= (long)W * (ch / DL_RING + 1); };
+    int rc = SICP_OK;
+    double t_workers = 0, t_link = 0;                        // SICP_SOLVE_TRACE=host: where this thread waited
+    const double t_begin = c->host_trace ? wall_ms() : 0.0;
+    long issued = 0;
+    for (long ch = 0; ch < nchunks && rc == SICP_OK; ++ch) {
+        // keep the link fed: every chunk whose buffer is free again (the first DL_RING have fresh ones)
+        while (rc == SICP_OK && issued < nchunks && issued < ch + DL_RING && (issued < DL_RING || chunk_done(issued - DL_RING))) rc = enqueue(issued++);
+        if (rc != SICP_OK) break;
+        if (issued <= ch) {                                  // (only when the copying threads are DL_RING chunks behind)
+            const double t0 = c->host_trace ? wall_ms() : 0.0;
+            wait_until([&] { return chunk_done(ch - DL_RING); });
+            if (c->host_trace) t_workers += wall_ms() - t0;
+            --ch; continue;
+        }
+        const double t0 = c->host_trace ? wall_ms() : 0.0;
+        if (hipEventSynchronize(c->dl_ev[ch % DL_RING]) != hipSuccess) { rc = fail(SICP_ERR_HIP, "hipEventSynchronize failed"); break; }
+        if (c->host_trace) t_link += wall_ms() - t0;
+        ready.store(ch, std::memory_order_release);
+        if (pool.empty()) {                                  // alone: this thread copies the chunk out itself
+            const long lo = ch * CH, m = std::min(CH, n - lo);
+            fan_out(c->h_dl + (size_t)(ch % DL_RING) * 3 * CH, CH, lo, 0, m, xyz_out, x_out, y_out, z_out);
+            parts[ch % DL_RING].fetch_add(1, std::memory_order_release);
+        }
     }
     if (rc != SICP_OK) quit.store(true);
+    const double t_join = c->host_trace ? wall_ms() : 0.0;
     for (auto &th : pool) th.join();
+    if (c->host_trace)
+        std::fprintf(stderr, "[sicp] download_both: %ld chunks, %u copying threads, %.2f ms: waited %.2f for the link, %.2f for a free buffer, %.2f for the last chunks\n",
+                     nchunks, pool.empty() ? 1u : W, wall_ms() - t_begin, t_link, t_workers, wall_ms() - t_join);
     if (rc != SICP_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
     return sync(c);
 }

@@ -126,15 +126,29 @@ struct EventPair { hipEvent_t a, b; int kernel; };
 constexpr int REC_RING = 16;     // records in flight + being read
 
 inline long round_up(long v, long g) { return (v + g - 1) / g * g; }
+inline double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline bool is_observed(double w) { return w > 0 && std::isfinite(w); }
 inline void H16_to_Xf(const double H[16], Xf *o) { for (int i = 0; i < 12; ++i) o->m[i] = H[i]; }
 
 }  // namespace sicph
 using namespace sicph;
 
+// an upload running behind its caller (sicp_cloud_upload_start): the helper thread and what it left
+struct BgUpload {
+    std::thread th;
+    bool active = false;
+    int rc = SICP_OK;
+    std::string err;
+};
+
 struct sicp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // background uploads: their DMA, layout kernel and statistics pass
+    BgUpload bg[2];                // by slot; at most one is active
+    DevBuf<double> stage_bg;       // ... their AoS staging block
+    DevBuf<double> bg_small;       // ... their statistics scratch (7 words) and its pinned mirror
+    double *h_bg = nullptr;
     hipDeviceProp_t prop;
     Cloud cloud[2];
     DevBuf<double> stage;          // AoS staging for uploads / downloads / query sets
@@ -210,8 +224,8 @@ struct sicp_ctx {
     DevBuf<double> ne_partial;
     DevBuf<unsigned> ticket;
     double *h_small = nullptr;     // pinned mirror of `small`
-    double *h_dl = nullptr;        // pinned double buffer of sicp_cloud_download_both (2 x 3 x 512 Ki doubles), on first use
-    hipEvent_t dl_ev[2] = {nullptr, nullptr};
+    double *h_dl = nullptr;        // pinned buffers of sicp_cloud_download_both (a ring of 4 x 3 x 256 Ki doubles) and of the staged uploads (2 x 3 x 512 Ki), on first use
+    hipEvent_t dl_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool have_iter = false;
     bool have_corr = false;        // sicp_corr_match has run: m_idx / m_p2 / dist hold its correspondences, `keep` the alive mask
     DevBuf<float> corr_pl;         // per-correspondence planarity columns handed to sicp_corr_reject_planarity: pc1 [Q] | pc2 [Q]
@@ -348,6 +362,7 @@ int grid_build(sicp_ctx *c, int slot, long icp_queries = -1);
 int knnk_device(sicp_ctx *c, int slot, const double *qsoa, long Q, long qpad, int k, double *d2_out, int64_t *idx_out,
                 float *normals_out = nullptr, float *planarity_out = nullptr, bool *fused = nullptr);
 int cloud_stats(sicp_ctx *c, int slot);
+int upload_join(sicp_ctx *c, int slot);
 
 }  // namespace sicph
 

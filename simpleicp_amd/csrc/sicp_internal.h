@@ -189,6 +189,7 @@ hipError_t reject_by_select_one_launch(hipStream_t s, const double *dist, const 
 void launch_aos_to_soa(hipStream_t s, const double *aos, long n, long npad, double *x, double *y, double *z);
 void launch_found_mask(hipStream_t s, const int64_t *idx, long Q, uint8_t *out);
 void launch_pad_fill(hipStream_t s, double *x, double *y, double *z, long n, long npad);
+void launch_pack_chunks(hipStream_t s, const double *x, const double *y, const double *z, long n, long CH, double *out);
 void launch_soa_to_aos(hipStream_t s, const double *x, const double *y, const double *z, long n, double *aos);
 void launch_transform(hipStream_t s, double *x, double *y, double *z, long n, const Xf &H);
 void launch_gather_queries(hipStream_t s, const double *x, const double *y, const double *z, const int64_t *sel,

@@ -69,6 +69,18 @@ __global__ void k_soa_to_aos(const double *__restrict__ x, const double *__restr
     aos[3 * i] = x[i]; aos[3 * i + 1] = y[i]; aos[3 * i + 2] = z[i];
 }
 
+// the cloud in chunks of CH points, each chunk its x | y | z columns back to back: ONE contiguous piece per chunk for the copy engine
+// (sicp_cloud_download_both: three pieces of 2 MiB per chunk moved 45 GB/s, one of 12 MiB moves 55 -- profiles/r6/d2h_rate.txt)
+__global__ void k_pack_chunks(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z, long n, long CH,
+                              double *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long ch = i / CH, r = i - ch * CH;
+    double *o = out + 3 * ch * CH + r;
+    o[0] = x[i]; o[CH] = y[i]; o[2 * CH] = z[i];
+}
+
 // PointCloud.transform_by_H, pointcloud.py:205-217 -- in place, HBM-bound (48 B/point).
 __global__ void k_transform(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z, long n, Xf H)
 {
@@ -1112,6 +1124,10 @@ void launch_pad_fill(hipStream_t s, double *x, double *y, double *z, long n, lon
 void launch_soa_to_aos(hipStream_t s, const double *x, const double *y, const double *z, long n, double *aos)
 {
     if (n > 0) hipLaunchKernelGGL(k_soa_to_aos, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, n, aos);
+}
+void launch_pack_chunks(hipStream_t s, const double *x, const double *y, const double *z, long n, long CH, double *out)
+{
+    if (n > 0) hipLaunchKernelGGL(k_pack_chunks, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, z, n, CH, out);
 }
 void launch_transform(hipStream_t s, double *x, double *y, double *z, long n, const Xf &H)
 {

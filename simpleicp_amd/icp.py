@@ -100,8 +100,10 @@ class SimpleICP:
         ow = np.array(rbp_observation_weights, dtype=float)
         H = H_from_params(obs)
 
-        # both clouds go to HBM once and stay there (straight from the frames' storage: no host gather)
-        pc1._upload(ctx, _lib.FIX)
+        # both clouds go to HBM once and stay there (straight from the frames' storage: no host gather).  One process: each travels
+        # on the library's helper thread (a stream of its own) while this thread does what needs no device -- the masks -- and, behind
+        # the movable cloud's upload, the fixed cloud's grid and normals; the first call that names a slot waits for its upload
+        pc1._upload(ctx, _lib.FIX, background=not sharded)
         # CorrPts.match searches pc2.X_selected only and maps the hits through pc2.idx_selected (corrpts.py:131-135);
         # a movable cloud with a partial `selected` mask (e.g. the fixed cloud of an earlier run) is uploaded as
         # that subset, after the overlap pre-pass, which looks at ALL its points (simpleicp.py:157: pc2.X)
@@ -126,7 +128,12 @@ class SimpleICP:
             lo, hi = (0, n) if qshard else dist.shard_bounds(n, rank, world)
             pc2._upload(ctx, _lib.MOV, lo, hi, index_base=lo, rows=rows)
 
-        upload_movable()
+        sel0 = pc1._selection()           # carried along (_ALL or indices): every pass over the mask is a pass over N_f
+        if sharded:
+            upload_movable()
+        else:
+            pc2._upload(ctx, _lib.MOV, background=True)       # (waits for the fixed cloud's: one helper at a time)
+            ctx.upload_wait(_lib.FIX)                         # ... whose verdict (a non-finite coordinate) is raised here
         self._job = {"ranks": world, "partition": None, "exchange": None}
         if sharded:
             how = dist.attach(ctx, gn_shard=(not qshard) and os.environ.get("SICP_GN_SHARD", "") != "0"
@@ -136,7 +143,7 @@ class SimpleICP:
         else:
             dist.detach(ctx)
         try:
-            return self._run_uploaded(ctx, sharded, msel, n_search, upload_movable, t_start, obs, ow, H,
+            return self._run_uploaded(ctx, sharded, msel, n_search, upload_movable, sel0, t_start, obs, ow, H,
                                       correspondences, neighbors, min_planarity, max_overlap_distance, min_change,
                                       max_iterations, distance_weights, debug_dirpath)
         except BaseException:
@@ -151,13 +158,12 @@ class SimpleICP:
             # collective the other ranks never join
             dist.detach(ctx)
 
-    def _run_uploaded(self, ctx, sharded, msel, n_search, upload_movable, t_start, obs, ow, H, correspondences, neighbors,
+    def _run_uploaded(self, ctx, sharded, msel, n_search, upload_movable, sel, t_start, obs, ow, H, correspondences, neighbors,
                       min_planarity, max_overlap_distance, min_change, max_iterations, distance_weights, debug_dirpath):
         pc1, pc2 = self.pc1, self.pc2
         if debug_dirpath:
             X_fix, X_mov = pc1.X, pc2.X
 
-        sel = pc1._selection()            # carried along (_ALL or indices): every pass over the mask is a pass over N_f
         if np.isfinite(max_overlap_distance):
             _log.info("Consider partial overlap of point clouds ...")
             if sel is _ALL or len(sel):
@@ -180,6 +186,7 @@ class SimpleICP:
             _log.info("Estimate normals of selected points ...")
             pc1.estimate_normals(neighbors, _ctx=ctx, _uploaded=True, _sel=sel)
         normals, planarity = pc1._attributes_of(sel)
+        ctx.upload_wait(_lib.MOV)                # (the movable cloud's verdict -- a non-finite coordinate -- is raised here)
         if msel is not None:
             upload_movable(msel)                 # from here on the searched cloud is pc2's selected subset
         if "planarity" in pc2.columns:

@@ -94,10 +94,17 @@ class PointCloud(pd.DataFrame):
             return "soa", cols
         return "aos", self.X
 
-    def _upload(self, ctx, slot, lo=0, hi=None, index_base=0, rows=None):
+    def _upload(self, ctx, slot, lo=0, hi=None, index_base=0, rows=None, background=False):
         """Rows [lo, hi) (of the subset ``rows`` when given) into the library's slot; returns a row getter
-        ``rows(idx) -> (len(idx),3)``."""
+        ``rows(idx) -> (len(idx),3)``.  ``background``: the whole cloud on the library's helper thread (`Context.upload_start`); the
+        next call that names the slot waits for it."""
         kind, buf = self._xyz_buffers()
+        if background and rows is None and lo == 0 and hi is None:
+            if kind == "aos":
+                ctx.upload_start(slot, xyz=buf, index_base=index_base)
+                return lambda idx: buf[idx]
+            ctx.upload_start(slot, columns=buf, index_base=index_base)
+            return lambda idx: np.column_stack([b[idx] for b in buf])
         if rows is not None:
             part = rows[lo:hi]
             sub = buf[part] if kind == "aos" else np.column_stack([b[part] for b in buf])

@@ -21,6 +21,8 @@ def build_calls():
         "sicp_ctx_device_name": lambda: L.sicp_ctx_device_name(None, C.create_string_buffer(8), 8),
         "sicp_cloud_upload": lambda: L.sicp_cloud_upload(None, 0, buf, 1, 0),
         "sicp_cloud_upload_columns": lambda: L.sicp_cloud_upload_columns(None, 0, buf, buf, buf, 1, 0),
+        "sicp_cloud_upload_start": lambda: L.sicp_cloud_upload_start(None, 0, buf, None, None, None, 1, 0),
+        "sicp_cloud_upload_wait": lambda: L.sicp_cloud_upload_wait(None, 0),
         "sicp_cloud_size": lambda: L.sicp_cloud_size(None, 0, C.byref(i64)),
         "sicp_cloud_transform": lambda: L.sicp_cloud_transform(None, 0, buf),
         "sicp_cloud_download": lambda: L.sicp_cloud_download(None, 0, buf),

@@ -48,7 +48,7 @@ def io_round_trips(tmp):
 def abi_errors():
     L = _lib.load()
     import ctypes as C
-    assert L.sicp_abi_version() == 6
+    assert L.sicp_abi_version() == 7
     assert L.sicp_ctx_create(0, None) != 0 and b"null" in L.sicp_last_error()
     assert L.sicp_cloud_upload(None, 0, None, 0, 0) != 0
     assert L.sicp_icp_iterate(None, None, None) != 0

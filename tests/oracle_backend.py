@@ -40,6 +40,22 @@ class OracleContext:
     def upload_columns(self, slot, x, y, z, index_base=0):
         self.upload(slot, np.column_stack((x, y, z)), index_base)
 
+    def upload_start(self, slot, xyz=None, columns=None, index_base=0):
+        """Like the library: the verdict of a background upload is handed over by upload_wait / the next call on the slot."""
+        self._log("upload_start")
+        try:
+            self.upload(slot, xyz if xyz is not None else np.column_stack(columns), index_base)
+            self.calls.pop()                      # (the inner "upload")
+            self.__dict__.setdefault("_bg_err", {}).pop(slot, None)
+        except _lib.BackendError as e:
+            self.calls.pop()
+            self.__dict__.setdefault("_bg_err", {})[slot] = e
+
+    def upload_wait(self, slot):
+        e = self.__dict__.setdefault("_bg_err", {}).pop(slot, None)
+        if e is not None:
+            raise e
+
     def size(self, slot):
         return len(self.cloud[slot][0])
 

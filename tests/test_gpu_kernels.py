@@ -121,6 +121,72 @@ def test_upload_columns_equals_upload(ctx):
         ctx.upload_columns(_lib.MOV, np.zeros(3), np.zeros(4), np.zeros(3))
 
 
+@pytest.mark.parametrize("form", ["rows", "columns"])
+def test_background_upload_equals_the_plain_one(ctx, form):
+    """sicp_cloud_upload_start (ABI 7): the movable cloud travels on the library's helper thread while THIS thread builds the fixed
+    cloud's grid and normals (what run() does, simpleicp.py:161-178); afterwards the slot holds exactly what the plain upload leaves
+    -- coordinates, bounding box (the grid the match builds), statistics -- and searches answer bit for bit.  Sizes on both sides of the
+    staged-upload limit (2^19 points: those are uploaded on the spot)."""
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(5)
+    for n in (700_001, 40_000):
+        F = rng.uniform(-20, 20, (n, 3)); F[:, 2] = 0.3 * np.sin(F[:, 0]) + 0.01 * rng.normal(size=n)
+        M = F[rng.permutation(n)] + rng.normal(scale=0.01, size=(n, 3))
+        sel = np.arange(0, n, 37)
+        Qp = F[::211]
+        ctx.upload(_lib.FIX, F)
+        ctx.upload(_lib.MOV, M)
+        ref_knn = ctx.knn(_lib.MOV, Qp, k=1, H=_H(3))
+        ref_rows = ctx.download(_lib.MOV)
+        ref_nv = ctx.estimate_normals(_lib.FIX, sel, 10)
+        ctx.upload(_lib.MOV, F[:10])                           # (something else in the slot in between)
+        if form == "rows":
+            ctx.upload_start(_lib.MOV, xyz=M)
+        else:
+            ctx.upload_start(_lib.MOV, columns=[np.ascontiguousarray(M[:, j]) for j in range(3)])
+        ctx.upload(_lib.FIX, F)                                # the other slot: upload, grid and normals beside the helper thread
+        nv = ctx.estimate_normals(_lib.FIX, sel, 10)
+        assert np.array_equal(nv[0], ref_nv[0], equal_nan=True) and np.array_equal(nv[1], ref_nv[1], equal_nan=True)
+        got = ctx.knn(_lib.MOV, Qp, k=1, H=_H(3))              # (no explicit wait: the first call naming the slot joins)
+        assert np.array_equal(got[0], ref_knn[0]) and np.array_equal(got[1], ref_knn[1])
+        ctx.upload_wait(_lib.MOV)                              # idempotent
+        assert ctx.size(_lib.MOV) == n and np.array_equal(ctx.download(_lib.MOV), ref_rows)
+
+
+def test_background_upload_hands_its_error_to_the_next_call_on_the_slot(ctx):
+    """A non-finite movable cloud: the start returns, the verdict comes from upload_wait (or whatever names the slot next), the slot
+    is empty afterwards and usable again; a second start waits for the first; the other slot is never disturbed."""
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(6)
+    n = 600_000
+    F = rng.normal(size=(n, 3))
+    X = rng.normal(size=(n, 3)); X[n - 3, 2] = np.nan
+    ctx.upload(_lib.FIX, F)
+    ctx.upload_start(_lib.MOV, xyz=X)
+    assert ctx.size(_lib.FIX) == n                             # (FIX calls do not wait and do not fail)
+    with pytest.raises(_lib.BackendError, match="non-finite"):
+        ctx.upload_wait(_lib.MOV)
+    with pytest.raises(_lib.BackendError, match="empty"):
+        ctx.knn(_lib.MOV, np.zeros((2, 3)), k=1)
+    ctx.upload_start(_lib.MOV, xyz=X)
+    with pytest.raises(_lib.BackendError, match="non-finite"):
+        ctx.knn(_lib.MOV, np.zeros((2, 3)), k=1)               # the implicit join delivers it too
+    good = rng.normal(size=(n, 3))
+    ctx.upload_start(_lib.MOV, xyz=X)                          # a failing one in flight ...
+    ctx.upload_start(_lib.FIX, xyz=good)                       # ... is waited for by a start on the other slot (one helper at a time), its verdict stays with ITS slot
+    with pytest.raises(_lib.BackendError, match="non-finite"):
+        ctx.size(_lib.MOV)
+    assert ctx.knn(_lib.FIX, good[:5], k=1)[0][:, 0].tolist() == [0, 1, 2, 3, 4]
+    ctx.upload_start(_lib.MOV, xyz=good)
+    ctx.upload_start(_lib.FIX, xyz=F)                          # both arrive
+    i0 = ctx.knn(_lib.MOV, good[:5], k=1)[0][:, 0]
+    i1 = ctx.knn(_lib.FIX, F[:5], k=1)[0][:, 0]
+    assert np.array_equal(i0, np.arange(5)) and np.array_equal(i1, np.arange(5))
+    c2 = _lib.Context(0)                                       # a context destroyed with an upload in flight joins it first
+    c2.upload_start(_lib.MOV, xyz=good)
+    c2.close()
+
+
 @pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
 def test_non_finite_clouds_are_rejected_at_upload(ctx, bad):
     """cKDTree refuses NaN / inf data (pointcloud.py:161,185 would raise); so does the upload, either flavour,

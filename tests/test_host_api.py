@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/simpleicp_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert L.sicp_abi_version() == _lib.ABI_VERSION == 6
+    assert L.sicp_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_params_to_H_matches_reference_convention():
@@ -227,7 +227,7 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
     if torch.cuda.is_available():
         pytest.skip("a device is visible: the GPU flavour of this test runs the demo to the end")
     r = subprocess.run([str(exe), "20000", "500"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 3 and "ABI version 6" in r.stdout and "no HIP device" in r.stderr, (r.returncode, r.stdout, r.stderr)
+    assert r.returncode == 3 and "ABI version 7" in r.stdout and "no HIP device" in r.stderr, (r.returncode, r.stdout, r.stderr)
 
 
 @pytest.mark.gpu

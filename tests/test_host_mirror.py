@@ -80,7 +80,7 @@ def test_run_orchestration_on_the_stand_in(ctx, name, clouds):
     assert sum(a == b for a, b in zip(mine, theirs)) >= len(theirs) - 4          # a count can differ by one on a tie flip
     assert [m for m in mine if "|" not in m and "[" not in m] == [m for m in theirs if "|" not in m and "[" not in m]
     assert records[-1].startswith("Finished in ") and records[-1].endswith(" seconds!")
-    assert "icp_run" in ctx.calls and ctx.calls.count("upload") >= 2
+    assert "icp_run" in ctx.calls and ctx.calls.count("upload") + ctx.calls.count("upload_start") >= 2
 
 
 def _small_pair(clouds, n=4000):
