@@ -367,7 +367,7 @@ def _surface(n, seed, L=None):
 
 
 @pytest.mark.parametrize("case", ["uniform_small", "surface_1m", "offset_utm", "quantised_ties", "tiny_coords",
-                                  "clustered", "q_gt_1024", "far_queries", "degenerate_line", "identical_points",
+                                  "clustered", "q_gt_1024", "far_queries", "wide_balls", "degenerate_line", "identical_points",
                                   "single_point"])
 def test_filtered_scan_equals_brute_force(ctx_filter, case):
     from simpleicp_amd import _lib
@@ -392,6 +392,9 @@ def test_filtered_scan_equals_brute_force(ctx_filter, case):
     elif case == "far_queries":      # queries far outside the cloud's box: expanding search / huge radii
         P = rng.uniform(-1, 1, (100_000, 3))
         Qp = np.concatenate((rng.uniform(-1, 1, (50, 3)), rng.uniform(500, 600, (50, 3)), [[1e6, -1e6, 3.0]]))
+    elif case == "wide_balls":       # a cold iteration's searches: the answer lies several cells away, most rows of the ball are empty
+        P = _surface(400_000, 8)
+        Qp = _surface(400_000, 9)[::160] + np.column_stack((rng.uniform(-3, 3, 2500), rng.uniform(-3, 3, 2500), rng.uniform(1, 9, 2500)))
     elif case == "degenerate_line":  # zero extent on two axes
         P = np.zeros((70_000, 3)); P[:, 0] = np.round(rng.uniform(0, 100, 70_000), 2)
         Qp = np.column_stack((rng.uniform(-10, 110, 400), rng.normal(0, 1, 400), rng.normal(0, 1, 400)))
