@@ -193,7 +193,8 @@ struct sicp_ctx {
                                    // queries 13.4 / 16.0 / 19.2 us with one wave per query, 15.3 / 14.5 / 15.6 with four (profiles/r6/nn16_crossover.txt)
     int nn16_filter = 2;           // SICP_NN16 = exact (0: k_grid_nn16) | far (1: the filtered search, one flavour) | near (2, default: the lean
                                    // flavour first, the full one for what it leaves)
-    int dl_threads = 16;                  // host threads that fan a downloaded chunk out into the caller's arrays (run() at C4: 32 / 25 / 25 ms with 8 / 16 / 32)
+    int dl_threads = 16;                  // host threads of sicp_cloud_download_both: one feeds the link, the others fan the chunks out into the caller's arrays
+                                          // (round 6: with 15 of them the call waits 4.8 of its 5.3 ms for the link -- profiles/r6/download_parts_ring_packed_streamed.txt)
     int grid_cap_nonuniform_log2 = 27;    // log2 of the cell table's limit for clouds whose points crowd a few cells
     bool grid_pointwise = true;    // the cell size follows the POINT-weighted occupancy (false: the average over occupied cells only -- round 4's rule)
     long nn16f_min_q = 196608;     // SICP_NN16F_MIN_Q: from this many queries per launch on the many-queries search goes through the float32 filter
