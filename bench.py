@@ -922,9 +922,17 @@ def end_to_end(Xf, Xm, Q, k, kw):
         return dt, icp.last_run_info["iterations"], held
 
     one(False)                                           # first pass: context, allocator, page cache
-    dt, iters, _ = one(False)                            # the frames wrap arrays the caller still holds
+    # the frames wrap arrays the caller still holds; three passes, the middle one counts (a run() of 5-20 ms sits next to one-off
+    # costs of the same size: the runtime pinning an address range it has not seen, the allocator returning a block to the OS)
+    passes = []
+    for _ in range(3):
+        dt, iters, held = one(False)
+        passes.append(dt)
+        del held
+    dt = sorted(passes)[1]
     dt_own, _, _ = one(True)                             # the movable frame is the only owner of its (n,3) array
-    return {"seconds": dt, "iterations": iters, "iterations_per_s": iters / dt, "seconds_frame_owns_its_array": dt_own,
+    return {"seconds": dt, "iterations": iters, "iterations_per_s": iters / dt, "seconds_passes": passes,
+            "seconds_frame_owns_its_array": dt_own,
             "note": "SimpleICP.run() on DataFrames: upload, overlap pre-pass, normals, grid build, iterations to the "
                     "reference's convergence test (min_change=1), final transform + download; warm process.  "
                     "seconds_frame_owns_its_array: the same call when nothing else references the movable frame's "
