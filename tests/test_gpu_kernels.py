@@ -153,6 +153,50 @@ def test_background_upload_equals_the_plain_one(ctx, form):
         assert ctx.size(_lib.MOV) == n and np.array_equal(ctx.download(_lib.MOV), ref_rows)
 
 
+def test_background_upload_is_joined_by_every_entry_that_names_the_slot(ctx):
+    """No explicit wait anywhere: transform, the planarity column, select_in_range (either role), the normals, a whole chained run
+    and the download each find the cloud complete -- the same results as behind plain uploads."""
+    from simpleicp_amd import _lib
+    rng = np.random.default_rng(7)
+    n = 640_000
+    F = _surface(n, 21)
+    M = orc.transform(np.linalg.inv(_H(5)), _surface(n, 22))
+    sel = np.arange(0, n, 640)
+    z = np.zeros(6)
+
+    def flow(start):
+        out = {}
+        start(_lib.MOV, M)
+        ctx.transform(_lib.MOV, _H(6))                                   # joins MOV
+        out["moved"] = ctx.download(_lib.MOV)
+        start(_lib.MOV, M)
+        ctx.set_planarity(_lib.MOV, np.linspace(0, 1, n).astype(np.float32))
+        start(_lib.FIX, F)
+        out["near"] = ctx.select_in_range(_lib.FIX, _lib.MOV, sel, _H(5), 0.5)    # joins FIX (queries); MOV is there
+        start(_lib.MOV, M)                                               # (drops the planarity column, like every upload)
+        out["near2"] = ctx.select_in_range(_lib.FIX, _lib.MOV, sel, _H(5), 0.5)   # joins MOV (searched)
+        start(_lib.FIX, F)
+        nv, pl = ctx.estimate_normals(_lib.FIX, sel, 10)                 # joins FIX
+        out["nv"], out["pl"] = nv, pl
+        start(_lib.MOV, M)
+        ctx.icp_setup(sel, nv, pl)                                       # (names FIX only)
+        R = ctx.icp_run(z, z, z, 0.3, 1.0, max_iterations=3, min_change=0.0)      # joins MOV
+        out["x"] = np.array([r.x[:] for r in R])
+        out["state"] = ctx.icp_state()
+        return out
+
+    plain = flow(lambda slot, X: ctx.upload(slot, X))
+    behind = flow(lambda slot, X: ctx.upload_start(slot, xyz=X))
+    cols = flow(lambda slot, X: ctx.upload_start(slot, columns=[np.ascontiguousarray(X[:, j]) for j in range(3)]))
+    for other in (behind, cols):
+        for k, v in plain.items():
+            if k == "state":
+                assert all(np.array_equal(a, b) for a, b in zip(v, other[k]))
+            else:
+                assert np.array_equal(v, other[k], equal_nan=True), k
+    assert np.array_equal(plain["moved"], orc.transform(_H(6), M))
+
+
 def test_background_upload_hands_its_error_to_the_next_call_on_the_slot(ctx):
     """A non-finite movable cloud: the start returns, the verdict comes from upload_wait (or whatever names the slot next), the slot
     is empty afterwards and usable again; a second start waits for the first; the other slot is never disturbed."""
