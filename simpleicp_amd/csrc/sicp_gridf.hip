@@ -405,14 +405,11 @@ __global__ __launch_bounds__(256, FAR ? SICP_NN16F_FAR_OCC : SICP_NN16F_OCC) voi
                         // gb + T bounds the own-frame squared distance of a cloud point from above, with room for the difference
                         // between the frames on both sides (T = 2 E): nothing beyond it can beat or tie the answer
                         const double c2 = ((double)gb + (double)T) * (1.0 + 1e-6);
-                        if (c2 < cull2) {
-                            cull2 = c2;
-#pragma unroll
-                            for (int u = 0; u < 2; ++u) {
-                                const long rr = rb + (long)u * GS + gl;
-                                if (((todo >> (gl + u * GS)) & 1u) && rr < nrows_s) row_range(rr, b[u], len[u], lb2[u]);
-                            }
-                        }
+                        // (the rows the hit's ball no longer reaches are dropped below; the others keep the x ranges of the pass's ball.
+                        // Round 6: narrowing them to the hit's ball too -- the geometry and the offsets of every remaining row a second
+                        // time -- saved 8 % of the candidates and cost more: this kernel is bound by the instructions it issues, a
+                        // candidate is 13 of them.  Cold search of 1 M queries 1.97 -> 1.82 ms, profiles/r6/cold_search_no_second_geometry_pass.txt)
+                        if (c2 < cull2) cull2 = c2;
                     }
                     todo &= ((unsigned)(__ballot(len[0] > 0 && lb2[0] <= cull2) >> gbase) & GMASK) |
                             (((unsigned)(__ballot(len[1] > 0 && lb2[1] <= cull2) >> gbase) & GMASK) << GS);
