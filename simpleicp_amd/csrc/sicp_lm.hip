@@ -249,13 +249,18 @@ __global__ __launch_bounds__(LB) void k_lm_eval(
     {
         const int wid = tid >> 6, lane = tid & 63;
         double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (unsigned b0 = 0; b0 < gridDim.x; b0 += 8 * LW) {
+        double pv[4][8];                                        // (all of this wave's share in flight first: see k_lm_all)
+#pragma unroll
+        for (int st4 = 0; st4 < 4; ++st4)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const unsigned b = b0 + (unsigned)(wid * 8 + k);
-                if (b < gridDim.x) s8[k] += partial[(long)b * 64 + lane];
+                const unsigned b = (unsigned)st4 * 8u * LW + (unsigned)(wid * 8 + k);
+                pv[st4][k] = b < gridDim.x ? partial[(long)b * 64 + lane] : 0.0;
             }
-        }
+#pragma unroll
+        for (int st4 = 0; st4 < 4; ++st4)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const unsigned b = (unsigned)st4 * 8u * LW + (unsigned)(wid * 8 + k); if (b < gridDim.x) s8[k] += pv[st4][k]; }
         S.gp[wid][0][lane] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     }
     __syncthreads();
@@ -431,6 +436,7 @@ __global__ __launch_bounds__(LB) void k_lm_finish(
 // Same arithmetic in the same order as the launch-per-evaluation form with the same grid: bit-identical results.
 // ------------------------------------------------------------------------------------
 constexpr int LM_MAXB = 24;
+static_assert(4 * 8 * LW >= 256, "the fold of the block partials covers lm_eval_grid's cap in four steps");
 __global__ __launch_bounds__(LB) void k_lm_all(
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
     const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep, long Q, TailArgs A,
@@ -473,13 +479,20 @@ __global__ __launch_bounds__(LB) void k_lm_all(
             const double *all = partial + (long)((nb - 1) & 1) * g * 64;
             const int wid = tid >> 6, lane = tid & 63;
             double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (unsigned b0 = 0; b0 < g; b0 += 8 * LW) {
+            // every partial of this wave's share asked for before the first is added (a grid of 256 blocks: 32 loads per lane in flight
+            // instead of four dependent rounds of eight); the additions keep their order
+            double pv[4][8];
+#pragma unroll
+            for (int st4 = 0; st4 < 4; ++st4)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const unsigned b = b0 + (unsigned)(wid * 8 + k);
-                    if (b < g) s8[k] += __hip_atomic_load(&all[(long)b * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned b = (unsigned)st4 * 8u * LW + (unsigned)(wid * 8 + k);
+                    pv[st4][k] = b < g ? __hip_atomic_load(&all[(long)b * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
                 }
-            }
+#pragma unroll
+            for (int st4 = 0; st4 < 4; ++st4)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const unsigned b = (unsigned)st4 * 8u * LW + (unsigned)(wid * 8 + k); if (b < g) s8[k] += pv[st4][k]; }
             S.gp[wid][0][lane] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         }
         __syncthreads();
@@ -509,7 +522,7 @@ __global__ __launch_bounds__(LB) void k_lm_all(
 int lm_eval_grid(long Q)
 {
     // (one block per CU: same-address ticket atomics serialise at ~20 ns apiece across the 8 XCDs)
-    const long cap = 256;
+    const long cap = 256;                             // (the folds below take four steps of 8 * LW partials: static_assert)
     long g = ((Q + LB - 1) / LB + LCH - 1) / LCH;     // one round of LCH chunks per block, up to the cap
     if (g < 1) g = 1;
     if (g > cap) g = cap;
