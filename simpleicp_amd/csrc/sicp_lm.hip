@@ -66,12 +66,17 @@ __device__ void block_gram(LmShared &S, const double *__restrict__ qx, const dou
             r[c] = 0.0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) a[c][k] = 0.0;
-            if (in[c] && keep[i]) {
-                const double px = p2[3 * i], py = p2[3 * i + 1], pz = p2[3 * i + 2];
-                const float fx = normals[3 * i], fy = normals[3 * i + 1], fz = normals[3 * i + 2];
+            // (everything a correspondence needs is asked for together with its verdict -- one round trip, not the verdict first and
+            // the rest behind it: the quarter of the loads a rejected correspondence wastes costs less than the dependent round)
+            const long ic = in[c] ? i : 0;
+            const bool kp = keep[ic] != 0;
+            const double px = p2[3 * ic], py = p2[3 * ic + 1], pz = p2[3 * ic + 2];
+            const float fx = normals[3 * ic], fy = normals[3 * ic + 1], fz = normals[3 * ic + 2];
+            const double q0 = qx[ic], q1 = qy[ic], q2 = qz[ic];
+            if (in[c] && kp) {
                 double X, Y, Z;
                 xfm(H, px, py, pz, X, Y, Z);
-                r[c] = pdist(X - qx[i], Y - qy[i], Z - qz[i], fx, fy, fz);
+                r[c] = pdist(X - q0, Y - q1, Z - q2, fx, fy, fz);
                 const double nx = fx, ny = fy, nz = fz;
                 const double ux = X - x[3], uy = Y - x[4], uz = Z - x[5];          // R p
                 const double cx = uy * nz - uz * ny, cy = uz * nx - ux * nz, cz = ux * ny - uy * nx;   // (R p) x n
@@ -249,18 +254,13 @@ __global__ __launch_bounds__(LB) void k_lm_eval(
     {
         const int wid = tid >> 6, lane = tid & 63;
         double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        double pv[4][8];                                        // (all of this wave's share in flight first: see k_lm_all)
-#pragma unroll
-        for (int st4 = 0; st4 < 4; ++st4)
+        for (unsigned b0 = 0; b0 < gridDim.x; b0 += 8 * LW) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const unsigned b = (unsigned)st4 * 8u * LW + (unsigned)(wid * 8 + k);
-                pv[st4][k] = b < gridDim.x ? partial[(long)b * 64 + lane] : 0.0;
+                const unsigned b = b0 + (unsigned)(wid * 8 + k);
+                if (b < gridDim.x) s8[k] += partial[(long)b * 64 + lane];
             }
-#pragma unroll
-        for (int st4 = 0; st4 < 4; ++st4)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const unsigned b = (unsigned)st4 * 8u * LW + (unsigned)(wid * 8 + k); if (b < gridDim.x) s8[k] += pv[st4][k]; }
+        }
         S.gp[wid][0][lane] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     }
     __syncthreads();
@@ -437,6 +437,9 @@ __global__ __launch_bounds__(LB) void k_lm_finish(
 // ------------------------------------------------------------------------------------
 constexpr int LM_MAXB = 24;
 static_assert(4 * 8 * LW >= 256, "the fold of the block partials covers lm_eval_grid's cap in four steps");
+// AHEAD: the instantiation for grids of more than 8 * LW blocks (its fold keeps 32 loads per lane in flight: registers the small grids'
+// instantiation does better without -- with both forms in ONE kernel the minimisation of 10 000 correspondences took 28 us instead of 23.5)
+template <bool AHEAD>
 __global__ __launch_bounds__(LB) void k_lm_all(
     const double *__restrict__ qx, const double *__restrict__ qy, const double *__restrict__ qz,
     const float *__restrict__ normals, const double *__restrict__ p2, const uint8_t *__restrict__ keep, long Q, TailArgs A,
@@ -479,20 +482,31 @@ __global__ __launch_bounds__(LB) void k_lm_all(
             const double *all = partial + (long)((nb - 1) & 1) * g * 64;
             const int wid = tid >> 6, lane = tid & 63;
             double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            // every partial of this wave's share asked for before the first is added (a grid of 256 blocks: 32 loads per lane in flight
-            // instead of four dependent rounds of eight); the additions keep their order
-            double pv[4][8];
+            if constexpr (!AHEAD) {
+                for (unsigned b0 = 0; b0 < g; b0 += 8 * LW) {          // (one step here: g <= 8 * LW)
 #pragma unroll
-            for (int st4 = 0; st4 < 4; ++st4)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const unsigned b = (unsigned)st4 * 8u * LW + (unsigned)(wid * 8 + k);
-                    pv[st4][k] = b < g ? __hip_atomic_load(&all[(long)b * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                    for (int k = 0; k < 8; ++k) {
+                        const unsigned b = b0 + (unsigned)(wid * 8 + k);
+                        if (b < g) s8[k] += __hip_atomic_load(&all[(long)b * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
+            } else {
+                // more blocks than one step covers (up to 256: four steps): every partial of this wave's share is asked for before
+                // the first is added -- 32 loads per lane in flight instead of four dependent rounds of eight; the additions keep their
+                // order (same bits).  Minimisation at Q = 1 M: 72 -> 66 us per iteration.  (profiles/r6/q_sweep_lm_fold_loads_in_flight.txt)
+                double pv[4][8];
 #pragma unroll
-            for (int st4 = 0; st4 < 4; ++st4)
+                for (int st4 = 0; st4 < 4; ++st4)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { const unsigned b = (unsigned)st4 * 8u * LW + (unsigned)(wid * 8 + k); if (b < g) s8[k] += pv[st4][k]; }
+                    for (int k = 0; k < 8; ++k) {
+                        const unsigned b = (unsigned)st4 * 8u * LW + (unsigned)(wid * 8 + k);
+                        pv[st4][k] = b < g ? __hip_atomic_load(&all[(long)b * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                    }
+#pragma unroll
+                for (int st4 = 0; st4 < 4; ++st4)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const unsigned b = (unsigned)st4 * 8u * LW + (unsigned)(wid * 8 + k); if (b < g) s8[k] += pv[st4][k]; }
+            }
             S.gp[wid][0][lane] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         }
         __syncthreads();
@@ -548,10 +562,15 @@ void launch_lm_all(hipStream_t s, const double *qx, const double *qy, const doub
                    double *partial, void *bar, unsigned long long *bar_total, double *resid0, double *resid1, double *rec, unsigned absent)
 {
     // every block must be resident at once (grid barrier): never more blocks than the device can hold
-    const long resident = resident_blocks((const void *)k_lm_all, LB);
+    const bool ahead = lm_eval_grid(Q) > 8 * LW;
+    const long resident = ahead ? resident_blocks((const void *)k_lm_all<true>, LB) : resident_blocks((const void *)k_lm_all<false>, LB);
     const unsigned g = (unsigned)std::min<long>(lm_eval_grid(Q), resident);
-    hipLaunchKernelGGL(k_lm_all, dim3(g), dim3(LB), 0, s, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, partial,
-                       (GridBar *)bar, *bar_total, resid0, resid1, rec, absent);
+    if (ahead && g > 8u * LW)
+        hipLaunchKernelGGL(k_lm_all<true>, dim3(g), dim3(LB), 0, s, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, partial,
+                           (GridBar *)bar, *bar_total, resid0, resid1, rec, absent);
+    else
+        hipLaunchKernelGGL(k_lm_all<false>, dim3(std::min(g, 8u * LW)), dim3(LB), 0, s, qx, qy, qz, normals, p2, keep, Q, A, st, L, rj4, stats, partial,
+                           (GridBar *)bar, *bar_total, resid0, resid1, rec, absent);
     *bar_total += (unsigned long long)LM_MAXB;
 }
 size_t lm_bar_bytes() { return sizeof(GridBar); }
